@@ -1,0 +1,201 @@
+/*
+ * slamit.h — C-ABI of libslamit_hip.so: the MI355X (gfx950) implementation of the ORB-SLAM2
+ * per-frame hot path of serviceberry3/weiner_slamit_v2.
+ *
+ * Every entry point replaces one reference interface (paths relative to
+ * oRB_SLAM2_Android/src/main/jni/ORB_SLAM2/ unless they start with Thirdparty/):
+ *
+ *   slamit_orb_*        <- ORBextractor::ORBextractor / operator()      include/ORBextractor.h:45-85,
+ *                                                                        src/ORBextractor.cc:415-482,1064-1136
+ *   slamit_orb_level    <- public member ORBextractor::mvImagePyramid    include/ORBextractor.h:85
+ *   slamit_hamming_*    <- ORBmatcher::DescriptorDistance + best/second  src/ORBmatcher.cc:1651-1667, 85-117,
+ *                          selection loops                               440-461, 1404-1428
+ *   slamit_ba_*         <- Optimizer::LocalBundleAdjustment (the g2o     src/Optimizer.cc:453-778 and
+ *                          BlockSolver_6_3 + Levenberg it instantiates)  Thirdparty/g2o/g2o/core/block_solver.hpp
+ *
+ * Conventions: plain C types only; `int` status return (0 = SLAMIT_OK, <0 = error, text from
+ * slamit_last_error()); nothing throws across the boundary; the caller owns every buffer it
+ * passes; the library owns device memory inside opaque handles.  Functions with the suffix
+ * `_dev` take DEVICE pointers (HBM-resident buffers, e.g. a torch tensor's data_ptr) and a HIP
+ * stream handle (`void*` = hipStream_t, NULL = the handle's own stream) and do not synchronise;
+ * all others take HOST pointers and return when the result is in the caller's memory.
+ * A handle may be used by one thread at a time; distinct handles are independent (the reference
+ * runs two extractors on two threads for stereo, src/Frame.cc:93-94).
+ */
+#ifndef SLAMIT_H
+#define SLAMIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMIT_OK 0
+#define SLAMIT_ERR_ARG (-1)      /* bad argument / unsupported geometry */
+#define SLAMIT_ERR_DEVICE (-2)   /* HIP runtime error (no GPU, launch failure, out of memory) */
+#define SLAMIT_ERR_CAPACITY (-3) /* caller buffer too small */
+#define SLAMIT_ERR_STATE (-4)    /* call order (e.g. level requested before any extract) */
+
+#define SLAMIT_DESC_BYTES 32
+#define SLAMIT_EDGE_THRESHOLD 19 /* src/ORBextractor.cc:79 */
+
+/* Field order and size identical to cv::KeyPoint (28 bytes) so the ORBextractor shim can
+ * memcpy into std::vector<cv::KeyPoint>. */
+typedef struct slamit_kp {
+    float x, y;     /* level-0 pixel coordinates (already multiplied by the level scale) */
+    float size;     /* (float)(int)(31 * scale[octave])        src/ORBextractor.cc:857,866 */
+    float angle;    /* degrees in [0,360], fastAtan2 of IC     src/ORBextractor.cc:108 */
+    float response; /* FAST-9/16 corner score */
+    int32_t octave;
+    int32_t class_id; /* always -1 */
+} slamit_kp;
+
+/* ---- ORB extractor --------------------------------------------------------------------- */
+
+typedef struct slamit_orb_params {
+    int32_t nfeatures;  /* 1000 (tracking) / 2000 (initialiser)  src/Tracking.cc:149,162 */
+    float scale_factor; /* 1.2f */
+    int32_t nlevels;    /* 8, at most SLAMIT_MAX_LEVELS */
+    int32_t ini_th_fast; /* 20 */
+    int32_t min_th_fast; /* 7 */
+    int32_t width, height; /* frame geometry is fixed per handle */
+    int32_t max_batch;     /* frames per extract_batch call the handle is sized for (>=1) */
+} slamit_orb_params;
+
+#define SLAMIT_MAX_LEVELS 16
+
+typedef struct slamit_orb slamit_orb;
+
+int slamit_orb_create(const slamit_orb_params* params, int device, slamit_orb** out);
+void slamit_orb_destroy(slamit_orb* h);
+
+/* Scale tables (GetScaleFactors & friends, include/ORBextractor.h:64-82). Each out array has
+ * nlevels entries; any may be NULL. */
+int slamit_orb_tables(const slamit_orb* h, float* scale, float* inv_scale, float* sigma2,
+                      float* inv_sigma2, int32_t* features_per_level);
+
+/* Upper bound on keypoints one frame can return: nfeatures + 3*nlevels (the octree may
+ * overshoot each level's quota by up to 3, src/ORBextractor.cc:743-744). */
+int slamit_orb_max_keypoints(const slamit_orb* h);
+
+/* One frame, host buffers: gray is h rows of `stride` bytes. Writes *n_out keypoints
+ * (level-major order as the reference concatenates them) and n_out*32 descriptor bytes.
+ * cap must be >= slamit_orb_max_keypoints(). Empty image (w or h == 0 at create) -> n_out = 0. */
+int slamit_orb_extract(slamit_orb* h, const uint8_t* gray, size_t stride, slamit_kp* kps,
+                       uint8_t* desc, int cap, int* n_out);
+
+/* nframes frames, host buffers; frame f at gray + f*frame_stride; outputs for frame f at
+ * kps + f*cap, desc + f*cap*32, n_out[f]. */
+int slamit_orb_extract_batch(slamit_orb* h, const uint8_t* gray, size_t stride,
+                             size_t frame_stride, int nframes, slamit_kp* kps, uint8_t* desc,
+                             int cap, int* n_out);
+
+/* Same, device buffers (all pointers are HBM addresses), asynchronous on `stream`. */
+int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t stride,
+                                 size_t frame_stride, int nframes, slamit_kp* d_kps,
+                                 uint8_t* d_desc, int cap, int32_t* d_n_out, void* stream);
+
+/* mvImagePyramid[level] of frame `frame` of the last extract call: copies the padded plane
+ * ((w+38) x (h+38), REFLECT_101 border of 19) to host memory. dst may be NULL to query sizes;
+ * *w,*h are the un-padded level size, the plane is (*h+38) rows of (*w+38) bytes. */
+int slamit_orb_level(slamit_orb* h, int frame, int level, uint8_t* dst, size_t dst_bytes, int* w,
+                     int* h_out);
+
+/* Stage outputs of the last extract call, for parity debugging (host buffers):
+ *  candidates of (frame, level) before the octree as (x, y, score) int32 triplets, x/y relative
+ *  to the (16,16) detection border like vToDistributeKeys (src/ORBextractor.cc:840-845), sorted
+ *  in the reference's (cell row, cell col, y, x) order. */
+int slamit_orb_debug_candidates(slamit_orb* h, int frame, int level, int32_t* xys, int cap,
+                                int* n_out);
+
+/* ---- Hamming matcher -------------------------------------------------------------------- */
+
+/* For each of nq query descriptors: best and second-best Hamming distance over the train
+ * descriptors, and the index of the best (strict '<', first index wins; the reference's
+ * selection rule, src/ORBmatcher.cc:1404-1428). With nt == 0: best = second = 256, idx = -1. */
+int slamit_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx,
+                         int32_t* best, int32_t* second);
+
+/* Batched device form: pair p matches d_q + p*q_stride (nq[p] rows) against d_t + p*t_stride
+ * (nt[p] rows); outputs at p*out_stride. d_nq / d_nt are device int32 arrays (they are the
+ * d_n_out of extract_batch_dev), max_n bounds both. */
+int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size_t q_stride,
+                                   const uint8_t* d_t, const int32_t* d_nt, size_t t_stride,
+                                   int npairs, int max_n, int32_t* d_best_idx, int32_t* d_best,
+                                   int32_t* d_second, size_t out_stride, int device, void* stream);
+
+/* Full distance matrix (nq x nt, uint16), the batched form of DescriptorDistance. */
+int slamit_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out);
+
+/* ---- Local bundle adjustment ------------------------------------------------------------ */
+
+typedef struct slamit_ba_problem {
+    int32_t n_kf;           /* local + fixed keyframes */
+    int32_t n_pt;
+    int32_t n_edge;
+    const double* kf_pose;  /* n_kf x 12: R row-major (9) then t (3), world->camera, already widened
+                               from float like Converter::toSE3Quat (src/Converter.cc:37-47) */
+    const uint8_t* kf_fixed; /* n_kf: 1 = fixed vertex (KF id 0 or lFixedCameras) */
+    const double* kf_intr;  /* n_kf x 4: fx fy cx cy */
+    const double* pt_xyz;   /* n_pt x 3 */
+    const int32_t* edge_kf; /* n_edge, in the reference's insertion order (per point, per observation) */
+    const int32_t* edge_pt; /* n_edge */
+    const double* edge_uv;  /* n_edge x 2 */
+    const double* edge_inv_sigma2; /* n_edge */
+} slamit_ba_problem;
+
+typedef struct slamit_ba_opts {
+    int32_t its_robust;     /* 5   src/Optimizer.cc:660 */
+    int32_t its_final;      /* 10  src/Optimizer.cc:707 */
+    double huber_delta;     /* (double)(float)sqrt(5.991)  src/Optimizer.cc:569 */
+    double chi2_gate;       /* 5.991 src/Optimizer.cc:680,723 */
+    const volatile uint8_t* stop; /* nullable; polled like SparseOptimizer::terminate() */
+} slamit_ba_opts;
+
+#define SLAMIT_BA_MAX_ITS 32
+
+typedef struct slamit_ba_stats {
+    int32_t n_its[2];                       /* LM iterations run in stage 1 / stage 2 */
+    double chi2[2][SLAMIT_BA_MAX_ITS];      /* robust cost after each iteration */
+    double lambda[2][SLAMIT_BA_MAX_ITS];    /* lambda after each iteration */
+    int32_t trials[2][SLAMIT_BA_MAX_ITS];   /* LM trials used by each iteration */
+    double chi2_init[2];                    /* cost before the first iteration of each stage */
+} slamit_ba_stats;
+
+typedef struct slamit_ba_result {
+    double* kf_pose;        /* n_kf x 12 out */
+    double* pt_xyz;         /* n_pt x 3 out */
+    double* edge_chi2;      /* n_edge out: chi2 at the final estimate */
+    uint8_t* edge_outlier;  /* n_edge out: 1 = chi2 > gate or depth <= 0 at the end (vToErase) */
+    uint8_t* edge_stage1_outlier; /* n_edge out: 1 = removed after the robust stage (setLevel(1)) */
+    slamit_ba_stats* stats; /* nullable */
+} slamit_ba_result;
+
+typedef struct slamit_ba slamit_ba;
+
+/* A BA handle owns device workspaces sized for up to max_kf/max_pt/max_edge and max_batch
+ * independent windows. */
+int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int device,
+                     slamit_ba** out);
+void slamit_ba_destroy(slamit_ba* h);
+
+/* One window, host buffers, synchronous. */
+int slamit_ba_solve(slamit_ba* h, const slamit_ba_problem* prob, const slamit_ba_opts* opts,
+                    slamit_ba_result* res);
+
+/* nwin independent windows solved concurrently (one workgroup cluster per window). */
+int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs,
+                          const slamit_ba_opts* opts, slamit_ba_result* results);
+
+/* ---- misc -------------------------------------------------------------------------------- */
+
+const char* slamit_last_error(void);
+const char* slamit_version(void);
+int slamit_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMIT_H */

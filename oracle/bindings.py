@@ -1,0 +1,214 @@
+"""ctypes bindings of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Import this module only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under weiner_slamit_v2_amd/ may import it (tests/test_layout.py checks that).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+assert KP_DTYPE.itemsize == 28
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+
+
+def build(force=False):
+    """Compile the oracle libraries with the committed Makefile (g++, seconds)."""
+    need = force or not all(
+        os.path.exists(os.path.join(HERE, n)) for n in ("liborb_oracle.so",)
+    )
+    if need:
+        subprocess.check_call(["make", "-s", "-C", HERE, "-f", os.path.join(HERE, "Makefile"), "all"])
+
+
+def _ptr(a, t=_u8p):
+    return a.ctypes.data_as(t)
+
+
+_orb = None
+
+
+def orb_lib():
+    global _orb
+    if _orb is None:
+        build()
+        L = C.CDLL(os.path.join(HERE, "liborb_oracle.so"))
+        L.orb_oracle_create.restype = C.c_void_p
+        L.orb_oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orb_oracle_destroy.argtypes = [C.c_void_p]
+        L.orb_oracle_tables.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _i32p, _i32p]
+        L.orb_oracle_extract.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p, C.c_int]
+        L.orb_oracle_level_size.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
+        L.orb_oracle_level.argtypes = [C.c_void_p, C.c_int, _u8p]
+        L.orb_oracle_blurred.argtypes = [C.c_void_p, C.c_int, _u8p]
+        L.orb_oracle_candidates.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_int]
+        L.orb_oracle_level_kps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orb_oracle_resize.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int]
+        L.orb_oracle_blur.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]
+        L.orb_oracle_gauss_taps.argtypes = [_i32p]
+        L.orb_oracle_fast_atan2.restype = C.c_float
+        L.orb_oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orb_oracle_round.argtypes = [C.c_double]
+        L.orb_oracle_fast.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]
+        L.orb_oracle_octree.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]
+        L.orb_oracle_descriptor.argtypes = [C.c_float, C.c_float, C.c_float, _u8p, C.c_int, _u8p]
+        L.orb_oracle_cossin.argtypes = [C.c_float, _f32p, _f32p]
+        L.orb_oracle_distance.argtypes = [_u8p, _u8p]
+        L.orb_oracle_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
+        L.orb_oracle_matrix.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint16)]
+        _orb = L
+    return _orb
+
+
+class OrbOracle:
+    """ORBextractor restatement (oracle/orb_oracle.cc)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = orb_lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orb_oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orb_oracle_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        per = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.orb_oracle_tables(self.h, _ptr(sc, _f32p), _ptr(isc, _f32p), _ptr(s2, _f32p), _ptr(is2, _f32p),
+                                 _ptr(per, _i32p), _ptr(umax, _i32p))
+        return {"scale": sc, "inv_scale": isc, "sigma2": s2, "inv_sigma2": is2, "per_level": per, "umax": umax}
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape if img.size else (0, 0)
+        cap = self.nfeatures + 3 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.orb_oracle_extract(self.h, _ptr(img), w, h, w, kps.ctypes.data, _ptr(desc), cap)
+        assert n >= 0, "oracle keypoint capacity"
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        assert self.L.orb_oracle_level_size(self.h, level, C.byref(w), C.byref(h)) == 0
+        return w.value, h.value
+
+    def level(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h + 38, w + 38), np.uint8)
+        assert self.L.orb_oracle_level(self.h, level, _ptr(out)) == 0
+        return out
+
+    def blurred(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        if self.L.orb_oracle_blurred(self.h, level, _ptr(out)) != 0:
+            return None
+        return out
+
+    def candidates(self, level):
+        n = self.L.orb_oracle_candidates(self.h, level, None, 0)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        self.L.orb_oracle_candidates(self.h, level, _ptr(out, _i32p), n)
+        return out[:n]
+
+    def level_kps(self, level):
+        n = self.L.orb_oracle_level_kps(self.h, level, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.orb_oracle_level_kps(self.h, level, out.ctypes.data, n)
+        return out[:n]
+
+
+def resize(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    orb_lib().orb_oracle_resize(_ptr(src), src.shape[1], src.shape[0], src.shape[1], _ptr(dst), dw, dh, dw)
+    return dst
+
+
+def blur(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    orb_lib().orb_oracle_blur(_ptr(src), src.shape[1], src.shape[0], src.shape[1], _ptr(dst), src.shape[1])
+    return dst
+
+
+def gauss_taps():
+    t = np.zeros(7, np.int32)
+    orb_lib().orb_oracle_gauss_taps(_ptr(t, _i32p))
+    return t
+
+
+def fast_atan2(y, x):
+    return orb_lib().orb_oracle_fast_atan2(float(y), float(x))
+
+
+def cv_round(v):
+    return orb_lib().orb_oracle_round(float(v))
+
+
+def fast(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros((max(cap, 1), 3), np.int32)
+    n = orb_lib().orb_oracle_fast(_ptr(img), img.shape[1], img.shape[0], img.shape[1], threshold, _ptr(out, _i32p), cap)
+    return out[:n]
+
+
+def octree(xyr, min_x, max_x, min_y, max_y, n_target):
+    xyr = np.ascontiguousarray(xyr, np.float32)
+    cap = n_target + 8 + len(xyr)
+    out = np.zeros((cap, 3), np.float32)
+    n = orb_lib().orb_oracle_octree(_ptr(xyr, _f32p), len(xyr), min_x, max_x, min_y, max_y, n_target,
+                                    _ptr(out, _f32p), cap)
+    return out[:n]
+
+
+def descriptor(img, kx, ky, angle_deg):
+    img = np.ascontiguousarray(img, np.uint8)
+    d = np.zeros(32, np.uint8)
+    orb_lib().orb_oracle_descriptor(float(kx), float(ky), float(angle_deg), _ptr(img), img.shape[1], _ptr(d))
+    return d
+
+
+def cossin(angle_rad):
+    c, s = C.c_float(), C.c_float()
+    orb_lib().orb_oracle_cossin(float(angle_rad), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return orb_lib().orb_oracle_distance(_ptr(a), _ptr(b))
+
+
+def best2(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx, b, s = (np.zeros(len(q), np.int32) for _ in range(3))
+    orb_lib().orb_oracle_best2(_ptr(q), len(q), _ptr(t), len(t), _ptr(idx, _i32p), _ptr(b, _i32p), _ptr(s, _i32p))
+    return idx, b, s
+
+
+def matrix(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    out = np.zeros((len(q), len(t)), np.uint16)
+    orb_lib().orb_oracle_matrix(_ptr(q), len(q), _ptr(t), len(t), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out

@@ -1,0 +1,196 @@
+"""Deterministic synthetic inputs for the hot path.
+
+Frames: 3-octave value noise + high-contrast axis-aligned / rotated rectangles and checker
+patches + uniform noise, so every pyramid level holds far more FAST-20 corners than its quota
+and some cells need the FAST-7 fallback.  Everything is drawn from numpy's frozen legacy
+MT19937 stream (RandomState) and built from exact float64 elementwise arithmetic, so the same
+seed gives the same bytes on any host.
+
+BA windows: the 50-keyframe x 2000-point problem of SURVEY.md §8d (arc trajectory, reference
+intrinsics of Tracking.cc:77-80, float32-rounded inputs widened to float64 the way
+Converter.cc:37-47,110-116 does).
+"""
+import numpy as np
+
+FRAME_SEED = 0xC0FFEE
+
+
+def _value_noise(rs, h, w, cell, amp):
+    gh, gw = h // cell + 2, w // cell + 2
+    g = rs.uniform(-1.0, 1.0, size=(gh, gw))
+    ys = np.arange(h, dtype=np.float64) / cell
+    xs = np.arange(w, dtype=np.float64) / cell
+    y0 = np.floor(ys).astype(np.int64)
+    x0 = np.floor(xs).astype(np.int64)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+
+
+def synth_frame(width, height, index=0, n_shapes=None, seed=FRAME_SEED):
+    """uint8 (height, width) frame number `index`."""
+    rs = np.random.RandomState((seed + index) & 0x7FFFFFFF)
+    img = np.full((height, width), 128.0)
+    for cell, amp in ((64, 64.0), (16, 32.0), (4, 16.0)):
+        img += _value_noise(rs, height, width, cell, amp)
+    if n_shapes is None:
+        n_shapes = int(round(400.0 * (width * height) / (640.0 * 480.0)))
+    yy, xx = np.mgrid[0:height, 0:width]
+    for _ in range(n_shapes):
+        kind = rs.randint(0, 3)
+        cx, cy = rs.randint(0, width), rs.randint(0, height)
+        sw, sh = rs.randint(6, 41), rs.randint(6, 41)
+        delta = float(rs.randint(60, 121)) * (1.0 if rs.randint(0, 2) else -1.0)
+        x0, x1 = max(cx - 30, 0), min(cx + 31, width)
+        y0, y1 = max(cy - 30, 0), min(cy + 31, height)
+        lx = (xx[y0:y1, x0:x1] - cx).astype(np.float64)
+        ly = (yy[y0:y1, x0:x1] - cy).astype(np.float64)
+        if kind == 0:  # axis-aligned rectangle
+            m = (np.abs(lx) * 2 <= sw) & (np.abs(ly) * 2 <= sh)
+            img[y0:y1, x0:x1] += delta * m
+        elif kind == 1:  # rotated rectangle
+            th = rs.uniform(0.0, np.pi)
+            c, s = np.cos(th), np.sin(th)
+            u, v = c * lx + s * ly, -s * lx + c * ly
+            m = (np.abs(u) * 2 <= sw) & (np.abs(v) * 2 <= sh)
+            img[y0:y1, x0:x1] += delta * m
+        else:  # 2x2 checker patch
+            m = (np.abs(lx) * 2 <= sw) & (np.abs(ly) * 2 <= sh)
+            sign = np.where((lx >= 0) ^ (ly >= 0), 1.0, -1.0)
+            img[y0:y1, x0:x1] += delta * m * sign
+    img += rs.randint(-4, 5, size=(height, width))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def warp_frame(frame, index=0, seed=FRAME_SEED):
+    """Frame B = frame A under a known similarity (rot +-10 deg, scale 0.9-1.1, shift <= 20 px),
+    nearest-neighbour sampled with integer-exact index maps, + noise +-2."""
+    h, w = frame.shape
+    rs = np.random.RandomState((seed ^ 0x5EED) + index)
+    ang = rs.uniform(-10.0, 10.0) * np.pi / 180.0
+    sc = rs.uniform(0.9, 1.1)
+    tx, ty = rs.uniform(-20, 20, size=2)
+    yy, xx = np.mgrid[0:h, 0:w]
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    c, s = np.cos(ang) / sc, np.sin(ang) / sc
+    sx = c * (xx - cx - tx) + s * (yy - cy - ty) + cx
+    sy = -s * (xx - cx - tx) + c * (yy - cy - ty) + cy
+    ix = np.clip(np.rint(sx).astype(np.int64), 0, w - 1)
+    iy = np.clip(np.rint(sy).astype(np.int64), 0, h - 1)
+    out = frame[iy, ix].astype(np.int64) + rs.randint(-2, 3, size=(h, w))
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def synth_batch(width, height, n, first=0, seed=FRAME_SEED):
+    return np.stack([synth_frame(width, height, first + i, seed=seed) for i in range(n)])
+
+
+def flat_frame(width, height, value=90):
+    return np.full((height, width), value, dtype=np.uint8)
+
+
+def noise_frame(width, height, seed=1):
+    return np.random.RandomState(seed).randint(0, 256, size=(height, width)).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# Bundle-adjustment windows
+# ---------------------------------------------------------------------------------------------
+
+INTRINSICS = (526.69, 540.36, 313.07, 238.39)  # Tracking.cc:77-80
+
+
+def _hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=np.float64)
+
+
+def se3_exp(xi):
+    """xi = [omega(3), upsilon(3)] -> (R, t), same closed form as g2o SE3Quat::exp."""
+    w, u = np.asarray(xi[:3], float), np.asarray(xi[3:], float)
+    th = np.linalg.norm(w)
+    W = _hat(w)
+    if th < 1e-5:
+        R = np.eye(3) + W + W @ W
+        V = R
+    else:
+        W2 = W @ W
+        R = np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * W2
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * W + (th - np.sin(th)) / th ** 3 * W2
+    return R, V @ u
+
+
+def _inv_sigma2_table(nlevels=8, scale=1.2):
+    s = np.float32(1.0)
+    out = []
+    for _ in range(nlevels):
+        out.append(np.float32(1.0) / (s * s))
+        s = np.float32(s * np.float64(np.float32(scale)))
+    return np.array(out, dtype=np.float32)
+
+
+def synth_ba(n_kf=50, n_pt=2000, obs_per_pt=8, outlier_frac=0.03, seed=12345, n_fixed=1):
+    """Returns a dict of numpy arrays laid out as include/slamit.h:slamit_ba_problem wants them.
+
+    obs_per_pt = None or >= n_kf gives the dense pattern (every point in every keyframe)."""
+    rs = np.random.RandomState(seed)
+    fx, fy, cx, cy = INTRINSICS
+    Rs, ts = [], []
+    for k in range(n_kf):
+        R, t = se3_exp([0.0, 0.02 * k, 0.0, -0.1 * k, 0.0, 0.0])
+        Rs.append(R)
+        ts.append(t)
+    pts = np.stack([rs.uniform(0.5, 4.5, n_pt), rs.uniform(-1.5, 1.5, n_pt), rs.uniform(4.0, 8.0, n_pt)], 1)
+    dense = obs_per_pt is None or obs_per_pt >= n_kf
+    inv_sig = _inv_sigma2_table()
+    quota = np.array([217, 181, 151, 126, 105, 87, 73, 60], dtype=np.float64)
+    quota /= quota.sum()
+    e_kf, e_pt, e_uv, e_is = [], [], [], []
+    for p in range(n_pt):
+        if dense:
+            kfs = range(n_kf)
+        else:
+            start = rs.randint(0, n_kf - obs_per_pt + 1)
+            kfs = range(start, start + obs_per_pt)
+        for k in kfs:
+            Xc = Rs[k] @ pts[p] + ts[k]
+            u = fx * Xc[0] / Xc[2] + cx + rs.normal(0.0, 1.0)
+            v = fy * Xc[1] / Xc[2] + cy + rs.normal(0.0, 1.0)
+            if rs.uniform() < outlier_frac:
+                u += rs.choice([-30.0, 30.0])
+                v += rs.choice([-30.0, 30.0])
+            octave = rs.choice(8, p=quota)
+            e_kf.append(k)
+            e_pt.append(p)
+            e_uv.append((u, v))
+            e_is.append(inv_sig[octave])
+    # perturbed initial estimates, rounded to float32 then widened (Converter.cc)
+    poses = np.zeros((n_kf, 12))
+    for k in range(n_kf):
+        if k < n_fixed:
+            R, t = Rs[k], ts[k]
+        else:
+            dR, dt = se3_exp(rs.normal(0.0, 0.005, 6))
+            R, t = dR @ Rs[k], dR @ ts[k] + dt
+        poses[k, :9] = R.reshape(-1)
+        poses[k, 9:] = t
+    poses = poses.astype(np.float32).astype(np.float64)
+    pts0 = (pts + rs.normal(0.0, 0.02, pts.shape)).astype(np.float32).astype(np.float64)
+    fixed = np.zeros(n_kf, dtype=np.uint8)
+    fixed[:n_fixed] = 1
+    intr = np.tile(np.array([fx, fy, cx, cy], dtype=np.float32).astype(np.float64), (n_kf, 1))
+    return {
+        "kf_pose": np.ascontiguousarray(poses),
+        "kf_fixed": fixed,
+        "kf_intr": np.ascontiguousarray(intr),
+        "pt_xyz": np.ascontiguousarray(pts0),
+        "edge_kf": np.array(e_kf, dtype=np.int32),
+        "edge_pt": np.array(e_pt, dtype=np.int32),
+        "edge_uv": np.array(e_uv, dtype=np.float32).astype(np.float64),
+        "edge_inv_sigma2": np.array(e_is, dtype=np.float32).astype(np.float64),
+        "truth_pose": np.array([np.concatenate([Rs[k].reshape(-1), ts[k]]) for k in range(n_kf)]),
+        "truth_pt": pts,
+    }
