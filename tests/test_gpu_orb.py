@@ -1,0 +1,182 @@
+"""GPU parity: HIP ORB extractor + Hamming matcher (through the C-ABI) vs the CPU oracle.
+
+Bar: bit-exact keypoints (position, octave, response, angle bits, size), descriptors, pyramid
+bytes, FAST candidate lists, match indices/distances.
+"""
+import numpy as np
+import pytest
+
+from oracle import bindings as ob
+from weiner_slamit_v2_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same(kg, dg, ko, do, tag=""):
+    assert len(kg) == len(ko), "%s keypoint count %d vs oracle %d" % (tag, len(kg), len(ko))
+    for f in ("octave", "x", "y", "response", "size", "class_id"):
+        assert np.array_equal(kg[f], ko[f]), "%s field %s differs" % (tag, f)
+    assert np.array_equal(kg["angle"].view(np.uint32), ko["angle"].view(np.uint32)), "%s angle bits differ" % tag
+    assert np.array_equal(dg, do), "%s descriptors differ" % tag
+
+
+def _check_frame(ext, orc, img, tag, stages=True):
+    kg, dg = ext(img)
+    ko, do = orc.extract(img)
+    if stages:
+        for l in range(orc.nlevels):
+            assert np.array_equal(ext.level(0, l), orc.level(l)), "%s pyramid level %d differs" % (tag, l)
+            cg, co = ext.debug_candidates(0, l), orc.candidates(l)
+            assert np.array_equal(cg, co), "%s FAST candidates level %d differ (%d vs %d)" % (tag, l, len(cg), len(co))
+    _assert_same(kg, dg, ko, do, tag)
+    return kg, dg
+
+
+def test_tables_match_oracle():
+    ext = api.ORBextractor(1000, 1.2, 8, 20, 7)
+    t = ob.OrbOracle(1000).tables()
+    assert np.array_equal(ext.GetScaleFactors(), t["scale"])
+    assert np.array_equal(ext.GetInverseScaleFactors(), t["inv_scale"])
+    assert np.array_equal(ext.GetScaleSigmaSquares(), t["sigma2"])
+    assert np.array_equal(ext.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
+    assert np.array_equal(ext.features_per_level(), t["per_level"])
+    assert ext.GetLevels() == 8 and abs(ext.GetScaleFactor() - 1.2) < 1e-7
+
+
+@pytest.mark.parametrize("index", [0, 1, 2])
+def test_vga_1000_bit_exact(index):
+    """BASELINE config 2 (extract half): 640x480, 1000 features, 8 levels."""
+    ext, orc = api.ORBextractor(1000, 1.2, 8, 20, 7), ob.OrbOracle(1000)
+    kg, _ = _check_frame(ext, orc, synth.synth_frame(640, 480, index), "vga[%d]" % index)
+    assert len(kg) >= 1000
+
+
+def test_vga_2000_initializer_extractor():
+    ext, orc = api.ORBextractor(2000, 1.2, 8, 20, 7), ob.OrbOracle(2000)
+    _check_frame(ext, orc, synth.synth_frame(640, 480, 5), "vga2000")
+
+
+def test_720p_2000():
+    """BASELINE config 3 geometry: 1280x720, 2000 features (two octree roots)."""
+    ext, orc = api.ORBextractor(2000, 1.2, 8, 20, 7), ob.OrbOracle(2000)
+    _check_frame(ext, orc, synth.synth_frame(1280, 720, 7), "720p", stages=True)
+
+
+def test_edge_images():
+    ext, orc = api.ORBextractor(1000, 1.2, 8, 20, 7), ob.OrbOracle(1000)
+    # flat: zero keypoints on every level
+    k, d = ext(synth.flat_frame(640, 480))
+    assert len(k) == 0 and d.shape == (0, 32)
+    # pure noise: worst-case candidate count, many equal-score ties
+    _check_frame(ext, orc, synth.noise_frame(640, 480, 3), "noise")
+    # low contrast: cells that need the minThFAST retry
+    low = ((synth.synth_frame(640, 480, 1).astype(np.int32) - 128) // 6 + 128).astype(np.uint8)
+    _check_frame(ext, orc, low, "lowcontrast")
+    c = ext.debug_candidates(0, 0)
+    assert ((c[:, 2] >= 7) & (c[:, 2] < 20)).any()
+    # saturated blocks: blur saturation and score ties
+    blocks = (np.kron(np.random.RandomState(9).randint(0, 2, (30, 40)), np.ones((16, 16))) * 255).astype(np.uint8)
+    _check_frame(ext, orc, blocks, "blocks")
+    # sparse: fewer candidates than the quota on the top levels (octree ends early)
+    sparse = np.full((480, 640), 100, np.uint8)
+    rs = np.random.RandomState(4)
+    for _ in range(60):
+        x, y = rs.randint(30, 600), rs.randint(30, 440)
+        sparse[y:y + 9, x:x + 9] = 220
+    _check_frame(ext, orc, sparse, "sparse")
+    # empty image (ORBextractor.cc:1068)
+    k, d = ext(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0
+
+
+@pytest.mark.parametrize("w,h,nf,nl,sf", [(317, 251, 500, 4, 1.2), (752, 480, 1200, 8, 1.2), (640, 480, 300, 3, 1.5),
+                                          (200, 340, 400, 3, 1.3)])
+def test_odd_geometries(w, h, nf, nl, sf):
+    ext, orc = api.ORBextractor(nf, sf, nl, 20, 7), ob.OrbOracle(nf, sf, nl, 20, 7)
+    _check_frame(ext, orc, synth.synth_frame(w, h, 11), "%dx%d" % (w, h))
+
+
+def test_thresholds_other_than_default():
+    ext, orc = api.ORBextractor(800, 1.2, 6, 35, 12), ob.OrbOracle(800, 1.2, 6, 35, 12)
+    _check_frame(ext, orc, synth.synth_frame(640, 480, 13), "th35/12")
+
+
+def test_batch_equals_single_and_oracle():
+    frames = np.stack([synth.synth_frame(640, 480, 20), synth.flat_frame(640, 480), synth.noise_frame(640, 480, 2),
+                       synth.synth_frame(640, 480, 21)])
+    ext, orc = api.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=4), ob.OrbOracle(1000)
+    ks, ds = ext.extract_batch(frames)
+    for i in range(len(frames)):
+        ko, do = orc.extract(frames[i])
+        _assert_same(ks[i], ds[i], ko, do, "batch[%d]" % i)
+    # the handle is reusable and deterministic
+    ks2, ds2 = ext.extract_batch(frames)
+    for i in range(len(frames)):
+        assert np.array_equal(ks[i], ks2[i]) and np.array_equal(ds[i], ds2[i])
+
+
+def test_device_buffer_entry_point():
+    import torch
+
+    frames = np.stack([synth.synth_frame(640, 480, 30 + i) for i in range(3)])
+    ext, orc = api.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=3), ob.OrbOracle(1000)
+    ext._bind(640, 480, 3)
+    cap = ext.max_keypoints
+    d_frames = torch.from_numpy(frames).cuda()
+    d_kps = torch.zeros((3, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((3, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(3, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ext.extract_batch_dev(d_frames, d_kps, d_desc, d_n, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(3, cap, 28)
+    for i in range(3):
+        ko, do = orc.extract(frames[i])
+        kg = kps[i, :n[i]].copy().view(api.KP_DTYPE).reshape(-1)
+        _assert_same(kg, d_desc[i, :n[i]].cpu().numpy(), ko, do, "dev[%d]" % i)
+
+
+# ---- Hamming ------------------------------------------------------------------------------------
+
+def test_hamming_random_and_ties():
+    rs = np.random.RandomState(0)
+    q = rs.randint(0, 256, (1003, 32)).astype(np.uint8)
+    t = rs.randint(0, 256, (997, 32)).astype(np.uint8)
+    t[500] = q[3]
+    t[600] = t[100]      # duplicate train rows: the first index must win
+    t[601] = t[100]
+    q[7] = t[100]
+    gi, gb, gs = api.ORBmatcher.best2(q, t)
+    oi, obest, osec = ob.best2(q, t)
+    assert np.array_equal(gi, oi) and np.array_equal(gb, obest) and np.array_equal(gs, osec)
+    assert gb[7] == 0 and gi[7] == 100 and gs[7] == 0
+    assert np.array_equal(api.ORBmatcher.distance_matrix(q[:70], t[:130]), ob.matrix(q[:70], t[:130]))
+    assert api.ORBmatcher.DescriptorDistance(q[0], t[0]) == ob.distance(q[0], t[0])
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 0), (64, 3), (65, 257), (2, 1000), (300, 2)])
+def test_hamming_ragged(nq, nt):
+    rs = np.random.RandomState(nq * 1000 + nt)
+    q = rs.randint(0, 4, (nq, 32)).astype(np.uint8)  # few distinct values: lots of equal distances
+    t = rs.randint(0, 4, (nt, 32)).astype(np.uint8)
+    gi, gb, gs = api.ORBmatcher.best2(q, t)
+    oi, obest, osec = ob.best2(q, t)
+    assert np.array_equal(gi, oi) and np.array_equal(gb, obest) and np.array_equal(gs, osec)
+
+
+def test_extract_then_match_pair():
+    """BASELINE config 2 end to end: frame A vs its warped copy B, all-pairs best/second +
+    TH_LOW / ratio 0.9 acceptance, indices identical to the oracle's."""
+    a = synth.synth_frame(640, 480, 40)
+    b = synth.warp_frame(a, 40)
+    ext, orc = api.ORBextractor(1000, 1.2, 8, 20, 7), ob.OrbOracle(1000)
+    ka, da = ext(a)
+    kb, db = ext(b)
+    _assert_same(kb, db, *orc.extract(b), "warped")
+    m = api.ORBmatcher(0.9, True)
+    qi, ti = m.match(da, db)
+    oi, obest, osec = ob.best2(da, db)
+    ok = (obest <= 50) & (obest.astype(np.float32) < np.float32(0.9) * osec.astype(np.float32))
+    assert np.array_equal(qi, np.nonzero(ok)[0]) and np.array_equal(ti, oi[ok])
+    assert len(qi) > 100  # the warp is mild: many true matches

@@ -1,0 +1,369 @@
+"""Python binding of libslamit_hip.so (the C-ABI of include/slamit.h) — used by tests and bench.py.
+
+The classes keep the reference's names and argument meaning:
+  ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)   include/ORBextractor.h:50-57
+  ORBmatcher.DescriptorDistance / best2 / TH_LOW / TH_HIGH              include/ORBmatcher.h:41-89
+  Optimizer.LocalBundleAdjustment                                        include/Optimizer.h:45
+There is NO CPU fallback: if the library is missing or no GPU is usable every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libslamit_hip.so")
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+
+MAX_ITS = 32
+
+
+class SlamitError(RuntimeError):
+    pass
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("n_pt", C.c_int32), ("n_edge", C.c_int32),
+                ("kf_pose", C.c_void_p), ("kf_fixed", C.c_void_p), ("kf_intr", C.c_void_p),
+                ("pt_xyz", C.c_void_p), ("edge_kf", C.c_void_p), ("edge_pt", C.c_void_p),
+                ("edge_uv", C.c_void_p), ("edge_inv_sigma2", C.c_void_p)]
+
+
+class BaOpts(C.Structure):
+    _fields_ = [("its_robust", C.c_int32), ("its_final", C.c_int32), ("huber_delta", C.c_double),
+                ("chi2_gate", C.c_double), ("stop", C.c_void_p)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("n_its", C.c_int32 * 2), ("chi2", (C.c_double * MAX_ITS) * 2),
+                ("lambda_", (C.c_double * MAX_ITS) * 2), ("trials", (C.c_int32 * MAX_ITS) * 2),
+                ("chi2_init", C.c_double * 2)]
+
+
+class BaResult(C.Structure):
+    _fields_ = [("kf_pose", C.c_void_p), ("pt_xyz", C.c_void_p), ("edge_chi2", C.c_void_p),
+                ("edge_outlier", C.c_void_p), ("edge_stage1_outlier", C.c_void_p), ("stats", C.c_void_p)]
+
+
+_lib = None
+
+EXPORTS = [
+    "slamit_orb_create", "slamit_orb_destroy", "slamit_orb_tables", "slamit_orb_max_keypoints",
+    "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
+    "slamit_orb_debug_candidates", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
+    "slamit_hamming_matrix", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
+    "slamit_ba_solve_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
+]
+
+
+def lib():
+    """Loads the HIP library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlamitError(
+                "libslamit_hip.so is not built: run `python -m weiner_slamit_v2_amd.build` "
+                "(there is no CPU fallback)")
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7 /
+        # libhsa-runtime64; if ours loaded /opt/rocm's copy first, torch.cuda would later find
+        # "No HIP GPUs".  Importing torch first makes our DT_NEEDED resolve to the copy torch
+        # already mapped (same SONAME).  Pure C/C++ users link /opt/rocm and never see this.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+        L.slamit_orb_create.argtypes = [C.POINTER(OrbParams), i32, C.POINTER(vp)]
+        L.slamit_orb_destroy.argtypes = [vp]
+        L.slamit_orb_destroy.restype = None
+        L.slamit_orb_tables.argtypes = [vp] + [vp] * 5
+        L.slamit_orb_max_keypoints.argtypes = [vp]
+        L.slamit_orb_extract.argtypes = [vp, vp, sz, vp, vp, i32, vp]
+        L.slamit_orb_extract_batch.argtypes = [vp, vp, sz, sz, i32, vp, vp, i32, vp]
+        L.slamit_orb_extract_batch_dev.argtypes = [vp, vp, sz, sz, i32, vp, vp, i32, vp, vp]
+        L.slamit_orb_level.argtypes = [vp, i32, i32, vp, sz, vp, vp]
+        L.slamit_orb_debug_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
+        L.slamit_hamming_best2.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+        L.slamit_hamming_best2_batch_dev.argtypes = [vp, vp, sz, vp, vp, sz, i32, i32, vp, vp, vp, sz, i32, vp]
+        L.slamit_hamming_matrix.argtypes = [vp, i32, vp, i32, vp]
+        if hasattr(L, "slamit_ba_create"):
+            L.slamit_ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+            L.slamit_ba_destroy.argtypes = [vp]
+            L.slamit_ba_destroy.restype = None
+            L.slamit_ba_solve.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaOpts), C.POINTER(BaResult)]
+            L.slamit_ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaProblem), C.POINTER(BaOpts), C.POINTER(BaResult)]
+        L.slamit_last_error.restype = C.c_char_p
+        L.slamit_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SlamitError("%s failed (%d): %s" % (what, rc, lib().slamit_last_error().decode()))
+
+
+def device_count():
+    return lib().slamit_device_count()
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ORBextractor:
+    """ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) on one GPU.
+
+    Frame geometry is bound lazily on the first image (the reference accepts any cv::Mat; the
+    device workspace is sized per geometry and re-created if it changes)."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7,
+                 device=0, max_batch=1):
+        self.params = (int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST))
+        self.device = device
+        self.max_batch = max_batch
+        self._h = None
+        self._geom = None
+
+    # -- handle management --
+    def _bind(self, width, height, batch=1):
+        if self._h is not None and self._geom == (width, height) and batch <= self.max_batch:
+            return
+        self.close()
+        self.max_batch = max(self.max_batch, batch)
+        p = OrbParams(self.params[0], self.params[1], self.params[2], self.params[3], self.params[4],
+                      width, height, self.max_batch)
+        h = C.c_void_p()
+        _check(lib().slamit_orb_create(C.byref(p), self.device, C.byref(h)), "slamit_orb_create")
+        self._h = h
+        self._geom = (width, height)
+        self.max_keypoints = lib().slamit_orb_max_keypoints(h)
+
+    def close(self):
+        if self._h is not None:
+            lib().slamit_orb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- getters of the reference class --
+    def GetLevels(self):
+        return self.params[2]
+
+    def GetScaleFactor(self):
+        return self.params[1]
+
+    def _tables(self):
+        if self._h is None:
+            self._bind(640, 480)
+        n = self.params[2]
+        out = [np.zeros(n, np.float32) for _ in range(4)] + [np.zeros(n, np.int32)]
+        _check(lib().slamit_orb_tables(self._h, *[_np_ptr(a) for a in out]), "slamit_orb_tables")
+        return out
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        return self._tables()[4]
+
+    # -- operator() --
+    def __call__(self, image, mask=None):
+        """image: uint8 (H, W) numpy array. Returns (keypoints[KP_DTYPE], descriptors[n,32])."""
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (ORBextractor.cc:1075)"
+        k, d = self.extract_batch(image[None])
+        return k[0], d[0]
+
+    def extract_batch(self, frames):
+        """frames: uint8 (B, H, W) host array -> lists of per-frame keypoints / descriptors."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        b, hh, ww = frames.shape
+        self._bind(ww, hh, b)
+        cap = self.max_keypoints
+        kps = np.zeros((b, cap), KP_DTYPE)
+        desc = np.zeros((b, cap, 32), np.uint8)
+        n = np.zeros(b, np.int32)
+        _check(lib().slamit_orb_extract_batch(self._h, _np_ptr(frames), ww, ww * hh, b, _np_ptr(kps), _np_ptr(desc),
+                                              cap, _np_ptr(n)), "slamit_orb_extract_batch")
+        return [kps[i, :n[i]].copy() for i in range(b)], [desc[i, :n[i]].copy() for i in range(b)]
+
+    def extract_batch_dev(self, d_frames, d_kps, d_desc, d_n, stream=None):
+        """torch uint8 CUDA tensor (B,H,W) -> fills d_kps (B,cap,7 float32 view), d_desc (B,cap,32), d_n (B)."""
+        b, hh, ww = d_frames.shape
+        self._bind(ww, hh, b)
+        cap = d_kps.shape[1]
+        _check(lib().slamit_orb_extract_batch_dev(
+            self._h, d_frames.data_ptr(), d_frames.stride(1), d_frames.stride(0), b, d_kps.data_ptr(),
+            d_desc.data_ptr(), cap, d_n.data_ptr(), stream), "slamit_orb_extract_batch_dev")
+
+    def level(self, frame, level):
+        """mvImagePyramid[level] of `frame` of the last call, padded plane (h+38, w+38)."""
+        w, h = C.c_int(), C.c_int()
+        _check(lib().slamit_orb_level(self._h, frame, level, None, 0, C.byref(w), C.byref(h)), "slamit_orb_level")
+        out = np.zeros((h.value + 38, w.value + 38), np.uint8)
+        _check(lib().slamit_orb_level(self._h, frame, level, _np_ptr(out), out.size, C.byref(w), C.byref(h)),
+               "slamit_orb_level")
+        return out
+
+    def debug_candidates(self, frame, level):
+        n = C.c_int()
+        _check(lib().slamit_orb_debug_candidates(self._h, frame, level, None, 0, C.byref(n)), "debug_candidates")
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        _check(lib().slamit_orb_debug_candidates(self._h, frame, level, _np_ptr(out), n.value, C.byref(n)),
+               "debug_candidates")
+        return out[:n.value]
+
+
+class ORBmatcher:
+    TH_HIGH = 100      # ORBmatcher.cc:37
+    TH_LOW = 50        # :38
+    HISTO_LENGTH = 30  # :39
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio = nnratio
+        self.mbCheckOrientation = checkOri
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(1, 32)
+        return int(ORBmatcher.distance_matrix(a, b)[0, 0])
+
+    @staticmethod
+    def distance_matrix(q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros((len(q), len(t)), np.uint16)
+        _check(lib().slamit_hamming_matrix(_np_ptr(q), len(q), _np_ptr(t), len(t), _np_ptr(out)), "slamit_hamming_matrix")
+        return out
+
+    @staticmethod
+    def best2(q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx, best, second = (np.zeros(len(q), np.int32) for _ in range(3))
+        _check(lib().slamit_hamming_best2(_np_ptr(q), len(q), _np_ptr(t), len(t), _np_ptr(idx), _np_ptr(best),
+                                          _np_ptr(second)), "slamit_hamming_best2")
+        return idx, best, second
+
+    def match(self, q, t, th=None):
+        """All-pairs match with the reference's acceptance rule: best <= th and best < nnratio*second
+        (ORBmatcher.cc:1430-1436 style). Returns query indices and their matched train indices."""
+        th = self.TH_LOW if th is None else th
+        idx, best, second = self.best2(q, t)
+        ok = (best <= th) & (best.astype(np.float32) < np.float32(self.mfNNratio) * second.astype(np.float32))
+        return np.nonzero(ok)[0], idx[ok]
+
+    @staticmethod
+    def best2_batch_dev(d_q, d_nq, d_t, d_nt, d_idx, d_best, d_second, max_n, device=0, stream=None):
+        """torch tensors: d_q/d_t (P, cap, 32) uint8, d_nq/d_nt (P) int32, outputs (P, cap) int32."""
+        p = d_q.shape[0]
+        _check(lib().slamit_hamming_best2_batch_dev(
+            d_q.data_ptr(), d_nq.data_ptr(), d_q.stride(0), d_t.data_ptr(), d_nt.data_ptr(), d_t.stride(0), p, max_n,
+            d_idx.data_ptr(), d_best.data_ptr(), d_second.data_ptr(), d_idx.stride(0), device, stream),
+            "slamit_hamming_best2_batch_dev")
+
+
+def _ba_problem(arrs):
+    keep = {}
+    for k, dt in (("kf_pose", np.float64), ("kf_fixed", np.uint8), ("kf_intr", np.float64), ("pt_xyz", np.float64),
+                  ("edge_kf", np.int32), ("edge_pt", np.int32), ("edge_uv", np.float64), ("edge_inv_sigma2", np.float64)):
+        keep[k] = np.ascontiguousarray(arrs[k], dtype=dt)
+    p = BaProblem(len(keep["kf_fixed"]), len(keep["pt_xyz"]), len(keep["edge_kf"]),
+                  *[keep[k].ctypes.data for k in ("kf_pose", "kf_fixed", "kf_intr", "pt_xyz", "edge_kf", "edge_pt",
+                                                   "edge_uv", "edge_inv_sigma2")])
+    return p, keep
+
+
+HUBER_MONO = float(np.float32(np.sqrt(5.991)))  # Optimizer.cc:569 stores sqrt(5.991) in a float
+
+
+class Optimizer:
+    """Optimizer::LocalBundleAdjustment on POD inputs (the KeyFrame/MapPoint gathering of
+    Optimizer.cc:456-504 stays with the caller)."""
+
+    def __init__(self, max_kf=64, max_pt=4096, max_edge=262144, max_batch=1, device=0):
+        h = C.c_void_p()
+        _check(lib().slamit_ba_create(max_kf, max_pt, max_edge, max_batch, device, C.byref(h)), "slamit_ba_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            lib().slamit_ba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _result(n_kf, n_pt, n_e):
+        out = {"kf_pose": np.zeros((n_kf, 12)), "pt_xyz": np.zeros((n_pt, 3)), "edge_chi2": np.zeros(n_e),
+               "edge_outlier": np.zeros(n_e, np.uint8), "edge_stage1_outlier": np.zeros(n_e, np.uint8)}
+        st = BaStats()
+        r = BaResult(out["kf_pose"].ctypes.data, out["pt_xyz"].ctypes.data, out["edge_chi2"].ctypes.data,
+                     out["edge_outlier"].ctypes.data, out["edge_stage1_outlier"].ctypes.data, C.addressof(st))
+        return r, out, st
+
+    @staticmethod
+    def _stats(st):
+        n = list(st.n_its)
+        return {"n_its": n, "chi2": [list(st.chi2[s])[:n[s]] for s in range(2)],
+                "lambda": [list(st.lambda_[s])[:n[s]] for s in range(2)],
+                "trials": [list(st.trials[s])[:n[s]] for s in range(2)], "chi2_init": list(st.chi2_init)}
+
+    def LocalBundleAdjustment(self, problem, its_robust=5, its_final=10, huber_delta=HUBER_MONO, chi2_gate=5.991,
+                              stop=None):
+        p, keep = _ba_problem(problem)
+        o = BaOpts(its_robust, its_final, huber_delta, chi2_gate, stop.ctypes.data if stop is not None else None)
+        r, out, st = self._result(p.n_kf, p.n_pt, p.n_edge)
+        _check(lib().slamit_ba_solve(self._h, C.byref(p), C.byref(o), C.byref(r)), "slamit_ba_solve")
+        out["stats"] = self._stats(st)
+        return out
+
+    def LocalBundleAdjustmentBatch(self, problems, its_robust=5, its_final=10, huber_delta=HUBER_MONO,
+                                   chi2_gate=5.991):
+        n = len(problems)
+        P = (BaProblem * n)()
+        R = (BaResult * n)()
+        keeps, outs, sts = [], [], []
+        for i, prob in enumerate(problems):
+            P[i], keep = _ba_problem(prob)
+            keeps.append(keep)
+            R[i], out, st = self._result(P[i].n_kf, P[i].n_pt, P[i].n_edge)
+            outs.append(out)
+            sts.append(st)
+        o = BaOpts(its_robust, its_final, huber_delta, chi2_gate, None)
+        _check(lib().slamit_ba_solve_batch(self._h, n, P, C.byref(o), R), "slamit_ba_solve_batch")
+        for out, st in zip(outs, sts):
+            out["stats"] = self._stats(st)
+        return outs

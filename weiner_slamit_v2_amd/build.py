@@ -1,0 +1,70 @@
+"""Builds libslamit_hip.so (HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+
+    python -m weiner_slamit_v2_amd.build [--force]
+
+The library is git-ignored but travels to the GPU box with the snapshot.  hipcc cross-compiles
+without a GPU.  -ffp-contract=off is part of the numerics (bit-exact float paths).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libslamit_hip.so")
+SOURCES = ["slamit_misc.hip", "orb_kernels.hip", "orb_api.hip", "hamming.hip", "ba_kernels.hip", "ba_api.hip"]
+FLAGS = [
+    "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
+]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    objs = []
+    procs = []
+    for src in sources():
+        obj = src[:-4] + ".o"
+        cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(out.decode(errors="replace"))
+        elif verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

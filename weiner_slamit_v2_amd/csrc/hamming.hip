@@ -1,0 +1,155 @@
+// hamming.hip — 256-bit Hamming matching (include/slamit.h, slamit_hamming_*).
+//
+// Replaces ORBmatcher::DescriptorDistance (ORB_SLAM2/src/ORBmatcher.cc:1651-1667) and the
+// best / second-best selection loops that call it (:85-117, :440-461, :1404-1428):
+//     if (d < best) { second = best; best = d; idx = j; } else if (d < second) second = d;
+// i.e. best = minimum distance with the FIRST index on ties, second = second smallest value of
+// the multiset.  That pair is an associative reduction, so the train set is split over 4 lanes
+// per query and merged with cross-lane shuffles:
+//     merge((b1,i1,s1),(b2,i2,s2)) = (b1,i1,min(s1,b2)) if (b1,i1) < (b2,i2) else (b2,i2,min(s2,b1)).
+// Workgroup = 256 threads = 64 queries x 4 train slices; train descriptors stream through LDS in
+// tiles of 256 rows (8 KB), read as broadcast ds_read_b128; distance = 8 x (v_xor + v_bcnt).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../../include/slamit.h"
+#include "slamit_internal.h"
+
+#define HM_TILE 256
+
+__global__ __launch_bounds__(256) void hamming_best2_kernel(
+    const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed, size_t q_stride,
+    const uint8_t* __restrict__ t, const int* __restrict__ nt_arr, int nt_fixed, size_t t_stride,
+    int* __restrict__ best_idx, int* __restrict__ best, int* __restrict__ second, size_t out_stride) {
+    __shared__ uint4 tile[HM_TILE * 2];
+    const int pair = blockIdx.y;
+    const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
+    const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
+    const int tid = threadIdx.x;
+    const int qi = blockIdx.x * 64 + (tid >> 2);
+    const int slice = tid & 3;
+    if (blockIdx.x * 64 >= nq) return;  // uniform
+    const uint4* Q = reinterpret_cast<const uint4*>(q + (size_t)pair * q_stride);
+    const uint4* T = reinterpret_cast<const uint4*>(t + (size_t)pair * t_stride);
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    const bool live = qi < nq;
+    if (live) { a0 = Q[2 * (size_t)qi]; a1 = Q[2 * (size_t)qi + 1]; }
+    int b = 256, s = 256, bi = -1;
+    for (int base = 0; base < nt; base += HM_TILE) {
+        const int rows = min(HM_TILE, nt - base);
+        __syncthreads();
+        for (int i = tid; i < rows * 2; i += 256) tile[i] = T[2 * (size_t)base + i];
+        __syncthreads();
+        for (int j = slice; j < rows; j += 4) {
+            uint4 t0 = tile[2 * j], t1 = tile[2 * j + 1];
+            int d = __popc(a0.x ^ t0.x) + __popc(a0.y ^ t0.y) + __popc(a0.z ^ t0.z) + __popc(a0.w ^ t0.w) +
+                    __popc(a1.x ^ t1.x) + __popc(a1.y ^ t1.y) + __popc(a1.z ^ t1.z) + __popc(a1.w ^ t1.w);
+            if (d < b) { s = b; b = d; bi = base + j; }
+            else if (d < s) s = d;
+        }
+    }
+    // merge the 4 slices of each query (lanes 4k..4k+3)
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+        int ob = __shfl_xor(b, m, 64), os = __shfl_xor(s, m, 64), oi = __shfl_xor(bi, m, 64);
+        // (b, bi) < (ob, oi) lexicographically; an empty slice has b = 256, bi = -1 and never wins
+        bool mine = (b < ob) || (b == ob && (oi < 0 || (bi >= 0 && bi < oi)));
+        if (mine) s = min(s, ob);
+        else { s = min(os, b); b = ob; bi = oi; }
+    }
+    if (live && slice == 0) {
+        size_t o = (size_t)pair * out_stride + qi;
+        best_idx[o] = bi; best[o] = b; second[o] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t* __restrict__ q, int nq,
+                                                             const uint8_t* __restrict__ t, int nt,
+                                                             uint16_t* __restrict__ out) {
+    __shared__ uint4 tile[64 * 2];
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const uint4* Q = reinterpret_cast<const uint4*>(q);
+    const uint4* T = reinterpret_cast<const uint4*>(t);
+    const int rows = min(64, nt - j0);
+    for (int i = tid; i < rows * 2; i += 256) tile[i] = T[2 * (size_t)j0 + i];
+    __syncthreads();
+    const int j = tid & 63;
+    for (int ii = tid >> 6; ii < 64; ii += 4) {
+        int i = i0 + ii;
+        if (i >= nq || j >= rows) continue;
+        uint4 a0 = Q[2 * (size_t)i], a1 = Q[2 * (size_t)i + 1];
+        uint4 t0 = tile[2 * j], t1 = tile[2 * j + 1];
+        int d = __popc(a0.x ^ t0.x) + __popc(a0.y ^ t0.y) + __popc(a0.z ^ t0.z) + __popc(a0.w ^ t0.w) +
+                __popc(a1.x ^ t1.x) + __popc(a1.y ^ t1.y) + __popc(a1.z ^ t1.z) + __popc(a1.w ^ t1.w);
+        out[(size_t)i * nt + j0 + j] = (uint16_t)d;
+    }
+}
+
+extern "C" {
+
+int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size_t q_stride, const uint8_t* d_t,
+                                   const int32_t* d_nt, size_t t_stride, int npairs, int max_n,
+                                   int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, size_t out_stride,
+                                   int device, void* stream) {
+    if (npairs < 0 || max_n < 0 || !d_q || !d_t || !d_nq || !d_nt || !d_best_idx || !d_best || !d_second)
+        return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_best2_batch_dev: bad argument");
+    if ((q_stride & 15) || (t_stride & 15) || ((uintptr_t)d_q & 15) || ((uintptr_t)d_t & 15))
+        return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_best2_batch_dev: descriptors must be 16-byte aligned");
+    if (npairs == 0 || max_n == 0) return SLAMIT_OK;
+    HIP_TRY(hipSetDevice(device));
+    dim3 grid((max_n + 63) / 64, npairs);
+    hipLaunchKernelGGL(hamming_best2_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_q, d_nq, 0, q_stride, d_t, d_nt,
+                       0, t_stride, d_best_idx, d_best, d_second, out_stride);
+    HIP_TRY(hipGetLastError());
+    return SLAMIT_OK;
+}
+
+int slamit_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx, int32_t* best,
+                         int32_t* second) {
+    if (nq < 0 || nt < 0 || (nq && (!q || !best_idx || !best || !second)) || (nt && !t))
+        return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_best2: bad argument");
+    if (nq == 0) return SLAMIT_OK;
+    uint8_t *dq = nullptr, *dt = nullptr;
+    int* dout = nullptr;
+    hipError_t e = hipMalloc((void**)&dq, (size_t)nq * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&dt, std::max<size_t>((size_t)nt * 32, 32));
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, sizeof(int) * 3 * (size_t)nq);
+    if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nt) e = hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + 63) / 64, 1), dim3(256), 0, 0, dq, (const int*)nullptr, nq,
+                           (size_t)0, dt, (const int*)nullptr, nt, (size_t)0, dout, dout + nq, dout + 2 * (size_t)nq, (size_t)0);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(best_idx, dout, sizeof(int) * nq, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(best, dout + nq, sizeof(int) * nq, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(second, dout + 2 * (size_t)nq, sizeof(int) * nq, hipMemcpyDeviceToHost);
+    hipFree(dq); hipFree(dt); hipFree(dout);
+    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_hamming_best2");
+    return SLAMIT_OK;
+}
+
+int slamit_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out) {
+    if (nq < 0 || nt < 0 || ((nq && nt) && (!q || !t || !out))) return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_matrix: bad argument");
+    if (nq == 0 || nt == 0) return SLAMIT_OK;
+    uint8_t *dq = nullptr, *dt = nullptr;
+    uint16_t* dout = nullptr;
+    hipError_t e = hipMalloc((void**)&dq, (size_t)nq * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&dt, (size_t)nt * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, sizeof(uint16_t) * (size_t)nq * nt);
+    if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hamming_matrix_kernel, dim3((nt + 63) / 64, (nq + 63) / 64), dim3(256), 0, 0, dq, nq, dt, nt, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(uint16_t) * (size_t)nq * nt, hipMemcpyDeviceToHost);
+    hipFree(dq); hipFree(dt); hipFree(dout);
+    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_hamming_matrix");
+    return SLAMIT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+// orb_api.hip — C-ABI of the ORB extractor (include/slamit.h, slamit_orb_*): handle, HBM layout,
+// coefficient tables and the launch sequence.  Mirrors the interface of ORB_SLAM2::ORBextractor
+// (include/ORBextractor.h:45-111, src/ORBextractor.cc:415-482,1064-1168).  No CPU compute path:
+// every entry point fails with SLAMIT_ERR_DEVICE when no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/slamit.h"
+#include "orb_types.h"
+#include "slamit_internal.h"
+
+// kernels (orb_kernels.hip)
+hipError_t orbk_upload_pattern(hipStream_t st);
+void orbk_resize(hipStream_t st, const uint8_t* src, int sw, int sh, size_t sstride, size_t sframe,
+                 uint8_t* dst, int dw, int dh, size_t dstride, size_t dframe, const int* xofs,
+                 const short* ialpha, const int* yofs, const short* ibeta, int nframes);
+void orbk_fast(hipStream_t st, const OrbLevel* levels, int nlevels, int cells_per_frame, const uint8_t* img0,
+               size_t img0_stride, size_t img0_frame, const uint8_t* pyr, unsigned long long* cand,
+               size_t cand_frame_stride, int* cand_count, int iniTh, int minTh, int nframes);
+size_t orbk_octree_smem(int node_cap);
+hipError_t orbk_octree_prepare(int node_cap);
+void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
+                 size_t cand_frame_stride, const int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
+                 OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int nframes,
+                 int level_override);
+void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0, size_t img0_stride,
+                   size_t img0_frame, const uint8_t* pyr, OrbLevelKp* lkp, size_t kp_frame_stride,
+                   const int* kp_count, int max_kp, int nframes);
+void orbk_blur(hipStream_t st, const uint8_t* src, int w, int h, size_t sstride, size_t sframe, uint8_t* dst,
+               size_t dstride, size_t dframe, int nframes);
+void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,
+                   const OrbLevelKp* lkp, size_t kp_frame_stride, const int* kp_count, slamit_kp* out_kps,
+                   uint8_t* out_desc, int out_cap, int* out_n, int max_kp, int nframes);
+void orbk_pad(hipStream_t st, const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst);
+void orbk_decode_candidates(hipStream_t st, const OrbLevel* levels, int level, const unsigned long long* K, int n,
+                            unsigned long long* order_out, int* xys);
+
+namespace {
+
+inline int cv_round(double v) { return (int)lrint(v); }  // cvRound: half-to-even
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline short sat_short(float v) {
+    int iv = cv_round((double)v);
+    return (short)(iv < -32768 ? -32768 : iv > 32767 ? 32767 : iv);
+}
+
+// per-axis tables of cv::resize INTER_LINEAR 8U (fixed point, 11 bits); `clampx` applies the
+// x-axis rule (offset clamped and weight zeroed at both ends), the y axis keeps its weights
+void resize_axis(int dn, int sn, bool clampx, std::vector<int>& ofs, std::vector<short>& coef) {
+    double inv_scale = (double)dn / sn;
+    double scale = 1. / inv_scale;
+    ofs.resize(dn);
+    coef.resize(2 * (size_t)dn);
+    for (int d = 0; d < dn; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floor(f);
+        f -= s;
+        if (clampx) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= sn - 1) { f = 0; s = sn - 1; }
+        }
+        ofs[d] = s;
+        coef[2 * d] = sat_short((1.f - f) * 2048.f);
+        coef[2 * d + 1] = sat_short(f * 2048.f);
+    }
+}
+
+}  // namespace
+
+struct slamit_orb {
+    slamit_orb_params p;
+    int device;
+    hipStream_t stream;
+    int nlevels;
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> per_level;
+    std::vector<OrbLevel> levels;
+    int cells_per_frame, node_cap, max_kp_level, max_out;
+    size_t pyr_frame_total, blur_frame_total;
+    size_t cand_frame_stride, kp_frame_stride;
+    // device memory
+    OrbLevel* d_levels;
+    uint8_t* d_pyr;
+    uint8_t* d_blur;
+    unsigned long long* d_cand;
+    uint32_t* d_ws_xy;
+    uint16_t* d_ws_node;
+    int* d_counts;  // [2][max_batch][nlevels]: cand_count, kp_count
+    OrbLevelKp* d_lkp;
+    int* d_tab_i[ORB_MAX_LEVELS][2];      // xofs, yofs per level (level >= 1)
+    short* d_tab_s[ORB_MAX_LEVELS][2];    // ialpha, ibeta
+    // staging for the host-pointer entry points
+    uint8_t* d_in;
+    size_t d_in_stride, d_in_frame;
+    slamit_kp* d_out_kps;
+    uint8_t* d_out_desc;
+    int* d_out_n;
+    uint8_t* d_scratch;  // padded plane / debug scratch
+    size_t scratch_bytes;
+    // last call (for slamit_orb_level / debug getters)
+    const uint8_t* last_img0;
+    size_t last_stride, last_frame;
+    int last_nframes;
+};
+
+static void orb_free(slamit_orb* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipFree(h->d_levels); hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cand); hipFree(h->d_ws_xy);
+    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
+    hipFree(h->d_out_desc); hipFree(h->d_out_n); hipFree(h->d_scratch);
+    for (int l = 0; l < ORB_MAX_LEVELS; ++l)
+        for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" {
+
+int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) {
+    if (!p || !out) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: null argument");
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > ORB_MAX_LEVELS || p->nfeatures < 1 || !(p->scale_factor > 1.f) ||
+        p->ini_th_fast < 1 || p->ini_th_fast > 255 || p->min_th_fast < 1 || p->min_th_fast > 255 ||
+        p->width < 0 || p->height < 0 || p->max_batch < 1)
+        return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: parameter out of range");
+    HIP_TRY(hipSetDevice(device));
+    slamit_orb* h = new slamit_orb();
+    h->p = *p;
+    h->device = device;
+    h->stream = nullptr;
+    h->last_img0 = nullptr; h->last_nframes = 0;
+    const int nl = h->nlevels = p->nlevels;
+
+    // ---- scale tables and quotas (ORBextractor.cc:422-455; scaleFactor is a double member) ----
+    const double scaleFactor = (double)p->scale_factor;
+    h->scale.assign(nl, 1.f); h->sigma2.assign(nl, 1.f); h->inv_scale.assign(nl, 1.f); h->inv_sigma2.assign(nl, 1.f);
+    for (int i = 1; i < nl; ++i) {
+        h->scale[i] = (float)(h->scale[i - 1] * scaleFactor);
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < nl; ++i) { h->inv_scale[i] = 1.0f / h->scale[i]; h->inv_sigma2[i] = 1.0f / h->sigma2[i]; }
+    h->per_level.assign(nl, 0);
+    {
+        float factor = (float)(1.0f / scaleFactor);
+        float nDesired = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+        int sum = 0;
+        for (int l = 0; l < nl - 1; ++l) {
+            h->per_level[l] = cv_round(nDesired);
+            sum += h->per_level[l];
+            nDesired *= factor;
+        }
+        h->per_level[nl - 1] = std::max(p->nfeatures - sum, 0);
+    }
+    h->max_out = p->nfeatures + 3 * nl;
+
+    // ---- level geometry (ORBextractor.cc:1143-1147, 789-803, 556-571) ----
+    h->levels.assign(nl, OrbLevel());
+    size_t pyr_off = 0, blur_off = 0, cand_off = 0;
+    int kp_off = 0, cell_base = 0;
+    h->node_cap = 8; h->max_kp_level = 1;
+    int sum_cap = 0;
+    const bool empty = p->width == 0 || p->height == 0;
+    for (int l = 0; l < nl && !empty; ++l) {
+        OrbLevel& L = h->levels[l];
+        float sc = h->inv_scale[l];
+        L.w = cv_round((float)p->width * sc);
+        L.h = cv_round((float)p->height * sc);
+        L.stride = (int)round_up((size_t)std::max(L.w, 1), 64);
+        L.quota = h->per_level[l];
+        L.plane_bytes = (size_t)L.stride * std::max(L.h, 1);
+        L.blur_bytes = L.plane_bytes;
+        if (l >= 1) { L.plane_off = pyr_off; pyr_off += round_up(L.plane_bytes, 256); } else L.plane_off = 0;
+        L.blur_off = blur_off; blur_off += round_up(L.blur_bytes, 256);
+        L.maxBorderX = L.w - ORB_MIN_BORDER; L.maxBorderY = L.h - ORB_MIN_BORDER;
+        const float width = (float)(L.maxBorderX - ORB_MIN_BORDER), height = (float)(L.maxBorderY - ORB_MIN_BORDER);
+        L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
+        if (L.w < 1 || L.h < 1 || L.nCols < 1 || L.nRows < 1) {
+            // the reference divides by zero on such a level; refuse the geometry
+            orb_free(h);
+            return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: pyramid level smaller than one 30x30 FAST cell");
+        }
+        L.wCell = (int)ceil(width / L.nCols); L.hCell = (int)ceil(height / L.nRows);
+        L.cell_base = cell_base; L.ncells = L.nCols * L.nRows; cell_base += L.ncells;
+        L.cand_cap = L.ncells * ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);  // NMS: <= 1 per 2x2 in a cell
+        L.cand_off = cand_off; cand_off += round_up((size_t)L.cand_cap, 64);
+        const int bw = L.maxBorderX - ORB_MIN_BORDER, bh = L.maxBorderY - ORB_MIN_BORDER;
+        L.nIni = (int)round(static_cast<float>(bw) / bh);
+        if (L.nIni < 1 || L.nIni > ORB_MAX_ROOTS) {
+            orb_free(h);
+            return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: unsupported aspect ratio (octree roots)");
+        }
+        L.hX = static_cast<float>(bw) / L.nIni;
+        for (int i = 0; i < L.nIni; ++i) {
+            L.rootUL[i] = (int)(L.hX * static_cast<float>(i));
+            L.rootUR[i] = (int)(L.hX * static_cast<float>(i + 1));
+        }
+        L.boxH = bh;
+        L.kp_cap = std::max(L.quota, 4 * L.nIni) + 4;
+        L.kp_off = kp_off; kp_off += L.kp_cap;
+        L.scale = h->scale[l];
+        L.patch_size = (float)(int)(31 * h->scale[l]);
+        h->node_cap = std::max(h->node_cap, L.kp_cap);
+        h->max_kp_level = std::max(h->max_kp_level, L.kp_cap);
+        sum_cap += L.kp_cap;
+    }
+    h->max_out = std::max(h->max_out, sum_cap);
+    h->cells_per_frame = cell_base;
+    h->pyr_frame_total = pyr_off; h->blur_frame_total = blur_off;
+    h->cand_frame_stride = cand_off; h->kp_frame_stride = (size_t)kp_off;
+    // frames are the outer dimension of every per-frame array: plane(level, f) = base + level_off + f*frame_total
+    for (int l = 0; l < nl; ++l) {
+        h->levels[l].plane_bytes = h->pyr_frame_total;   // stride between frames of the same level
+        h->levels[l].blur_bytes = h->blur_frame_total;
+    }
+    if (orbk_octree_smem(h->node_cap) > 160 * 1024 - 1024) {
+        orb_free(h);
+        return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: nfeatures too large for the LDS octree");
+    }
+
+    const size_t B = (size_t)p->max_batch;
+    hipError_t e = hipSuccess;
+#define ALLOC(ptr, bytes) if (e == hipSuccess) e = hipMalloc((void**)&(ptr), std::max<size_t>((bytes), 256))
+    ALLOC(h->d_levels, sizeof(OrbLevel) * nl);
+    ALLOC(h->d_pyr, h->pyr_frame_total * B);
+    ALLOC(h->d_blur, h->blur_frame_total * B);
+    ALLOC(h->d_cand, sizeof(unsigned long long) * h->cand_frame_stride * B);
+    ALLOC(h->d_ws_xy, sizeof(uint32_t) * h->cand_frame_stride * B);
+    ALLOC(h->d_ws_node, sizeof(uint16_t) * h->cand_frame_stride * B);
+    ALLOC(h->d_counts, sizeof(int) * 2 * B * nl);
+    ALLOC(h->d_lkp, sizeof(OrbLevelKp) * h->kp_frame_stride * B);
+    h->d_in_stride = round_up((size_t)std::max(p->width, 1), 64);
+    h->d_in_frame = h->d_in_stride * std::max(p->height, 1);
+    ALLOC(h->d_in, h->d_in_frame * B);
+    ALLOC(h->d_out_kps, sizeof(slamit_kp) * (size_t)h->max_out * B);
+    ALLOC(h->d_out_desc, (size_t)SLAMIT_DESC_BYTES * h->max_out * B);
+    ALLOC(h->d_out_n, sizeof(int) * B);
+    h->scratch_bytes = std::max<size_t>((size_t)(p->width + 38) * (p->height + 38),
+                                        (sizeof(unsigned long long) + 3 * sizeof(int)) * (h->cand_frame_stride + 64));
+    ALLOC(h->d_scratch, h->scratch_bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !empty) e = hipMemcpy(h->d_levels, h->levels.data(), sizeof(OrbLevel) * nl, hipMemcpyHostToDevice);
+    for (int l = 1; l < nl && e == hipSuccess && !empty; ++l) {
+        std::vector<int> xo, yo;
+        std::vector<short> xa, ya;
+        resize_axis(h->levels[l].w, h->levels[l - 1].w, true, xo, xa);
+        resize_axis(h->levels[l].h, h->levels[l - 1].h, false, yo, ya);
+        ALLOC(h->d_tab_i[l][0], xo.size() * 4); ALLOC(h->d_tab_i[l][1], yo.size() * 4);
+        ALLOC(h->d_tab_s[l][0], xa.size() * 2); ALLOC(h->d_tab_s[l][1], ya.size() * 2);
+        if (e == hipSuccess) e = hipMemcpy(h->d_tab_i[l][0], xo.data(), xo.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->d_tab_i[l][1], yo.data(), yo.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->d_tab_s[l][0], xa.data(), xa.size() * 2, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->d_tab_s[l][1], ya.data(), ya.size() * 2, hipMemcpyHostToDevice);
+    }
+#undef ALLOC
+    if (e == hipSuccess) e = orbk_upload_pattern(h->stream);
+    if (e == hipSuccess) e = orbk_octree_prepare(h->node_cap);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        orb_free(h);
+        return slamit_fail_hip(e, "slamit_orb_create");
+    }
+    *out = h;
+    return SLAMIT_OK;
+}
+
+void slamit_orb_destroy(slamit_orb* h) { orb_free(h); }
+
+int slamit_orb_tables(const slamit_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                      int32_t* features_per_level) {
+    if (!h) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_tables: null handle");
+    for (int i = 0; i < h->nlevels; ++i) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->inv_scale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->inv_sigma2[i];
+        if (features_per_level) features_per_level[i] = h->per_level[i];
+    }
+    return SLAMIT_OK;
+}
+
+int slamit_orb_max_keypoints(const slamit_orb* h) { return h ? h->max_out : 0; }
+
+int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t stride, size_t frame_stride,
+                                 int nframes, slamit_kp* d_kps, uint8_t* d_desc, int cap, int32_t* d_n_out,
+                                 void* stream) {
+    if (!h || !d_n_out || nframes < 0) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: bad argument");
+    if (nframes > h->p.max_batch) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_extract_batch_dev: nframes > max_batch");
+    if (nframes == 0) return SLAMIT_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const int nl = h->nlevels;
+    if (h->p.width == 0 || h->p.height == 0) {  // ORBextractor.cc:1068: empty image -> nothing
+        HIP_TRY(hipMemsetAsync(d_n_out, 0, sizeof(int) * nframes, st));
+        h->last_nframes = 0;
+        return SLAMIT_OK;
+    }
+    if (!d_gray || !d_kps || !d_desc) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: null buffer");
+    if (cap < h->max_out) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_extract_batch_dev: cap < slamit_orb_max_keypoints()");
+    if (stride < (size_t)h->p.width || (nframes > 1 && frame_stride < stride * (size_t)h->p.height))
+        return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: stride smaller than the frame");
+    int* cand_count = h->d_counts;
+    int* kp_count = h->d_counts + (size_t)h->p.max_batch * nl;
+    HIP_TRY(hipMemsetAsync(cand_count, 0, sizeof(int) * nframes * nl, st));
+    // K1: pyramid, level l from level l-1
+    for (int l = 1; l < nl; ++l) {
+        const OrbLevel& S = h->levels[l - 1];
+        const OrbLevel& D = h->levels[l];
+        const uint8_t* src = l == 1 ? d_gray : h->d_pyr + S.plane_off;
+        size_t sstride = l == 1 ? stride : (size_t)S.stride;
+        size_t sframe = l == 1 ? frame_stride : h->pyr_frame_total;
+        orbk_resize(st, src, S.w, S.h, sstride, sframe, h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride,
+                    h->pyr_frame_total, h->d_tab_i[l][0], h->d_tab_s[l][0], h->d_tab_i[l][1], h->d_tab_s[l][1], nframes);
+    }
+    // K2: FAST + NMS + per-cell threshold fallback -> candidate lists
+    orbk_fast(st, h->d_levels, nl, h->cells_per_frame, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
+              h->cand_frame_stride, cand_count, h->p.ini_th_fast, h->p.min_th_fast, nframes);
+    // K4: octree
+    orbk_octree(st, h->d_levels, nl, h->d_cand, h->cand_frame_stride, cand_count, h->d_ws_xy, h->d_ws_node, h->d_lkp,
+                h->kp_frame_stride, kp_count, h->node_cap, nframes, -1);
+    // K5: orientation
+    orbk_ic_angle(st, h->d_levels, nl, d_gray, stride, frame_stride, h->d_pyr, h->d_lkp, h->kp_frame_stride, kp_count,
+                  h->max_kp_level, nframes);
+    // K6: blur every level
+    for (int l = 0; l < nl; ++l) {
+        const OrbLevel& L = h->levels[l];
+        const uint8_t* src = l == 0 ? d_gray : h->d_pyr + L.plane_off;
+        orbk_blur(st, src, L.w, L.h, l == 0 ? stride : (size_t)L.stride, l == 0 ? frame_stride : h->pyr_frame_total,
+                  h->d_blur + L.blur_off, (size_t)L.stride, h->blur_frame_total, nframes);
+    }
+    // K7: descriptors + output records
+    orbk_describe(st, h->d_levels, nl, h->d_blur, h->d_lkp, h->kp_frame_stride, kp_count, d_kps, d_desc, cap, d_n_out,
+                  h->max_kp_level, nframes);
+    HIP_TRY(hipGetLastError());
+    h->last_img0 = d_gray; h->last_stride = stride; h->last_frame = frame_stride; h->last_nframes = nframes;
+    return SLAMIT_OK;
+}
+
+int slamit_orb_extract_batch(slamit_orb* h, const uint8_t* gray, size_t stride, size_t frame_stride, int nframes,
+                             slamit_kp* kps, uint8_t* desc, int cap, int* n_out) {
+    if (!h || !n_out || nframes < 0) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch: bad argument");
+    if (nframes > h->p.max_batch) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_extract_batch: nframes > max_batch");
+    if (nframes == 0) return SLAMIT_OK;
+    if (h->p.width == 0 || h->p.height == 0) {
+        for (int f = 0; f < nframes; ++f) n_out[f] = 0;
+        return SLAMIT_OK;
+    }
+    if (!gray || !kps || !desc) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch: null buffer");
+    if (cap < h->max_out) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_extract_batch: cap < slamit_orb_max_keypoints()");
+    HIP_TRY(hipSetDevice(h->device));
+    const int W = h->p.width, H = h->p.height;
+    for (int f = 0; f < nframes; ++f)
+        HIP_TRY(hipMemcpy2DAsync(h->d_in + f * h->d_in_frame, h->d_in_stride, gray + (size_t)f * frame_stride, stride, W, H,
+                                 hipMemcpyHostToDevice, h->stream));
+    int rc = slamit_orb_extract_batch_dev(h, h->d_in, h->d_in_stride, h->d_in_frame, nframes, h->d_out_kps, h->d_out_desc,
+                                          h->max_out, h->d_out_n, h->stream);
+    if (rc != SLAMIT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(n_out, h->d_out_n, sizeof(int) * nframes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int f = 0; f < nframes; ++f) {
+        int n = n_out[f];
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync(kps + (size_t)f * cap, h->d_out_kps + (size_t)f * h->max_out, sizeof(slamit_kp) * n,
+                                   hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(desc + (size_t)f * cap * SLAMIT_DESC_BYTES, h->d_out_desc + (size_t)f * h->max_out * SLAMIT_DESC_BYTES,
+                                   (size_t)SLAMIT_DESC_BYTES * n, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAMIT_OK;
+}
+
+int slamit_orb_extract(slamit_orb* h, const uint8_t* gray, size_t stride, slamit_kp* kps, uint8_t* desc, int cap,
+                       int* n_out) {
+    return slamit_orb_extract_batch(h, gray, stride, stride * (size_t)(h ? h->p.height : 0), 1, kps, desc, cap, n_out);
+}
+
+int slamit_orb_level(slamit_orb* h, int frame, int level, uint8_t* dst, size_t dst_bytes, int* w, int* h_out) {
+    if (!h || level < 0 || level >= h->nlevels) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_level: bad level");
+    if (h->p.width == 0 || h->p.height == 0) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_level: empty image");
+    const OrbLevel& L = h->levels[level];
+    if (w) *w = L.w;
+    if (h_out) *h_out = L.h;
+    if (!dst) return SLAMIT_OK;
+    if (frame < 0 || frame >= h->last_nframes || !h->last_img0) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_level: no such frame in the last extract call");
+    size_t need = (size_t)(L.w + 38) * (L.h + 38);
+    if (dst_bytes < need) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_level: dst too small");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint8_t* src = level == 0 ? h->last_img0 + (size_t)frame * h->last_frame
+                                    : h->d_pyr + L.plane_off + (size_t)frame * h->pyr_frame_total;
+    orbk_pad(h->stream, src, L.w, L.h, level == 0 ? h->last_stride : (size_t)L.stride, h->d_scratch);
+    HIP_TRY(hipMemcpyAsync(dst, h->d_scratch, need, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAMIT_OK;
+}
+
+int slamit_orb_debug_candidates(slamit_orb* h, int frame, int level, int32_t* xys, int cap, int* n_out) {
+    if (!h || level < 0 || level >= h->nlevels || !n_out) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_debug_candidates: bad argument");
+    if (frame < 0 || frame >= h->last_nframes) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_debug_candidates: no such frame");
+    HIP_TRY(hipSetDevice(h->device));
+    const OrbLevel& L = h->levels[level];
+    int n = 0;
+    HIP_TRY(hipMemcpy(&n, h->d_counts + frame * h->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    n = std::min(n, L.cand_cap);
+    *n_out = n;
+    if (!xys || n == 0) return SLAMIT_OK;
+    if (cap < n) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_debug_candidates: cap too small");
+    unsigned long long* d_order = (unsigned long long*)h->d_scratch;
+    int* d_xys = (int*)(d_order + round_up((size_t)n, 64));
+    orbk_decode_candidates(h->stream, h->d_levels, level, h->d_cand + L.cand_off + (size_t)frame * h->cand_frame_stride, n, d_order, d_xys);
+    std::vector<unsigned long long> order(n);
+    std::vector<int> raw(3 * (size_t)n);
+    HIP_TRY(hipMemcpyAsync(order.data(), d_order, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(raw.data(), d_xys, sizeof(int) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // present in the reference's vToDistributeKeys order (the device list is unordered)
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return order[a] < order[b]; });
+    for (int i = 0; i < n; ++i) { xys[3 * i] = raw[3 * idx[i]]; xys[3 * i + 1] = raw[3 * idx[i] + 1]; xys[3 * i + 2] = raw[3 * idx[i] + 2]; }
+    return SLAMIT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// orb_types.h — host/device shared descriptors of the ORB pipeline's HBM layout.
+#ifndef SLAMIT_ORB_TYPES_H
+#define SLAMIT_ORB_TYPES_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#define ORB_MAX_LEVELS 16
+#define ORB_MAX_ROOTS 8          // octree root nodes = round(width/height) of the detection box
+#define ORB_MIN_BORDER 16        // EDGE_THRESHOLD - 3   (ORBextractor.cc:789)
+#define ORB_CELL_MAX 59          // wCell, hCell < 60 because nCols = floor(width/30)
+#define ORB_TILE_MAX (ORB_CELL_MAX + 6)
+
+// One pyramid level.  Planes of all frames of a batch are stored level-major:
+//   plane(level, frame) = pyr + plane_off + frame * plane_bytes, rows of `stride` bytes
+// (stride = w rounded up to 64 so every row starts on a 64-byte boundary).  Level 0 lives in
+// the caller's buffer (its own stride / frame stride) and has no plane of its own.
+struct OrbLevel {
+    int32_t w, h;
+    int32_t stride;
+    int32_t quota;             // mnFeaturesPerLevel[level]
+    uint64_t plane_off;        // bytes, in the pyramid buffer (levels >= 1) ...
+    uint64_t plane_bytes;      // ... per frame
+    uint64_t blur_off;         // bytes, in the blurred-pyramid buffer (all levels)
+    uint64_t blur_bytes;
+    // FAST cell grid (ORBextractor.cc:797-803)
+    int32_t nCols, nRows, wCell, hCell;
+    int32_t maxBorderX, maxBorderY;   // w - 16, h - 16
+    int32_t cell_base;         // index of this level's first cell in the per-frame cell list
+    int32_t ncells;
+    // candidate list of (frame, level): cand + cand_off + frame * cand_frame_stride  (elements)
+    uint64_t cand_off;
+    int32_t cand_cap;
+    // octree roots (ORBextractor.cc:556-576)
+    int32_t nIni;
+    float hX;
+    int32_t rootUL[ORB_MAX_ROOTS], rootUR[ORB_MAX_ROOTS];
+    int32_t boxH;              // maxBorderY - minBorderY
+    // level keypoints: lkp + kp_off + frame * kp_frame_stride
+    int32_t kp_off, kp_cap;    // kp_cap = node capacity = max(quota, 4*nIni) + 4
+    float scale;               // mvScaleFactor[level]
+    float patch_size;          // (float)(int)(31 * scale)
+};
+
+struct OrbLevelKp {            // a keypoint in level coordinates, after the octree
+    int16_t x, y;
+    float response;
+    float angle;
+};
+
+#endif
