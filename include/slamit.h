@@ -97,6 +97,15 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
                                  size_t frame_stride, int nframes, slamit_kp* d_kps,
                                  uint8_t* d_desc, int cap, int32_t* d_n_out, void* stream);
 
+/* Per-stage device timing with HIP events recorded on the launch stream (the counterpart of
+ * g2o's G2OBatchStatistics idea, Thirdparty/g2o/g2o/core/batch_stats.h:39-77, for the extractor).
+ * Reads (and clears) what was accumulated since the last call into stage_ms / stage_calls
+ * (either may be NULL), then switches recording on/off.  Stages: 0 pyramid resize, 1 FAST cells,
+ * 2 octree, 3 IC angle, 4 Gaussian blur, 5 rBRIEF + output.  A "call" is one stage of one
+ * extract_batch call (the resize and blur stages launch one kernel per level). */
+#define SLAMIT_ORB_STAGES 6
+int slamit_orb_profile(slamit_orb* h, int enable, float* stage_ms, int32_t* stage_calls, int nstages);
+
 /* mvImagePyramid[level] of frame `frame` of the last extract call: copies the padded plane
  * ((w+38) x (h+38), REFLECT_101 border of 19) to host memory. dst may be NULL to query sizes;
  * *w,*h are the un-padded level size, the plane is (*h+38) rows of (*w+38) bytes. */

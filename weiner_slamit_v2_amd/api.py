@@ -60,7 +60,7 @@ _lib = None
 EXPORTS = [
     "slamit_orb_create", "slamit_orb_destroy", "slamit_orb_tables", "slamit_orb_max_keypoints",
     "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
-    "slamit_orb_debug_candidates", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
+    "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
     "slamit_hamming_matrix", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
     "slamit_ba_solve_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
 ]
@@ -93,6 +93,7 @@ def lib():
         L.slamit_orb_extract_batch.argtypes = [vp, vp, sz, sz, i32, vp, vp, i32, vp]
         L.slamit_orb_extract_batch_dev.argtypes = [vp, vp, sz, sz, i32, vp, vp, i32, vp, vp]
         L.slamit_orb_level.argtypes = [vp, i32, i32, vp, sz, vp, vp]
+        L.slamit_orb_profile.argtypes = [vp, i32, vp, vp, i32]
         L.slamit_orb_debug_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
         L.slamit_hamming_best2.argtypes = [vp, i32, vp, i32, vp, vp, vp]
         L.slamit_hamming_best2_batch_dev.argtypes = [vp, vp, sz, vp, vp, sz, i32, i32, vp, vp, vp, sz, i32, vp]
@@ -222,6 +223,15 @@ class ORBextractor:
         _check(lib().slamit_orb_extract_batch_dev(
             self._h, d_frames.data_ptr(), d_frames.stride(1), d_frames.stride(0), b, d_kps.data_ptr(),
             d_desc.data_ptr(), cap, d_n.data_ptr(), stream), "slamit_orb_extract_batch_dev")
+
+    STAGES = ("resize", "fast", "octree", "angle", "blur", "describe")
+
+    def profile(self, enable):
+        """Returns {stage: (total_ms, calls)} accumulated since the last call; sets recording."""
+        ms = np.zeros(6, np.float32)
+        calls = np.zeros(6, np.int32)
+        _check(lib().slamit_orb_profile(self._h, int(enable), _np_ptr(ms), _np_ptr(calls), 6), "slamit_orb_profile")
+        return {s: (float(ms[i]), int(calls[i])) for i, s in enumerate(self.STAGES)}
 
     def level(self, frame, level):
         """mvImagePyramid[level] of `frame` of the last call, padded plane (h+38, w+38)."""

@@ -105,6 +105,10 @@ struct slamit_orb {
     int* d_out_n;
     uint8_t* d_scratch;  // padded plane / debug scratch
     size_t scratch_bytes;
+    // optional per-stage hipEvent timing (slamit_orb_profile)
+    int prof_on;
+    std::vector<hipEvent_t> prof_ev;   // pairs (begin, end)
+    std::vector<int> prof_stage;       // stage id of each pair
     // last call (for slamit_orb_level / debug getters)
     const uint8_t* last_img0;
     size_t last_stride, last_frame;
@@ -119,6 +123,7 @@ static void orb_free(slamit_orb* h) {
     hipFree(h->d_out_desc); hipFree(h->d_out_n); hipFree(h->d_scratch);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
+    for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -289,6 +294,18 @@ int slamit_orb_tables(const slamit_orb* h, float* scale, float* inv_scale, float
 
 int slamit_orb_max_keypoints(const slamit_orb* h) { return h ? h->max_out : 0; }
 
+// stage ids reported by slamit_orb_profile
+enum { ST_RESIZE = 0, ST_FAST, ST_OCTREE, ST_ANGLE, ST_BLUR, ST_DESCRIBE, ST_COUNT };
+
+static void prof_mark(slamit_orb* h, hipStream_t st, int stage, bool begin) {
+    if (!h->prof_on || h->prof_ev.size() >= 2 * 16384) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    hipEventRecord(e, st);
+    h->prof_ev.push_back(e);
+    if (begin) h->prof_stage.push_back(stage);
+}
+
 int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t stride, size_t frame_stride,
                                  int nframes, slamit_kp* d_kps, uint8_t* d_desc, int cap, int32_t* d_n_out,
                                  void* stream) {
@@ -311,6 +328,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     int* kp_count = h->d_counts + (size_t)h->p.max_batch * nl;
     HIP_TRY(hipMemsetAsync(cand_count, 0, sizeof(int) * nframes * nl, st));
     // K1: pyramid, level l from level l-1
+    prof_mark(h, st, ST_RESIZE, true);
     for (int l = 1; l < nl; ++l) {
         const OrbLevel& S = h->levels[l - 1];
         const OrbLevel& D = h->levels[l];
@@ -320,25 +338,36 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
         orbk_resize(st, src, S.w, S.h, sstride, sframe, h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride,
                     h->pyr_frame_total, h->d_tab_i[l][0], h->d_tab_s[l][0], h->d_tab_i[l][1], h->d_tab_s[l][1], nframes);
     }
+    prof_mark(h, st, ST_RESIZE, false);
     // K2: FAST + NMS + per-cell threshold fallback -> candidate lists
+    prof_mark(h, st, ST_FAST, true);
     orbk_fast(st, h->d_levels, nl, h->cells_per_frame, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
               h->cand_frame_stride, cand_count, h->p.ini_th_fast, h->p.min_th_fast, nframes);
+    prof_mark(h, st, ST_FAST, false);
     // K4: octree
+    prof_mark(h, st, ST_OCTREE, true);
     orbk_octree(st, h->d_levels, nl, h->d_cand, h->cand_frame_stride, cand_count, h->d_ws_xy, h->d_ws_node, h->d_lkp,
                 h->kp_frame_stride, kp_count, h->node_cap, nframes, -1);
+    prof_mark(h, st, ST_OCTREE, false);
     // K5: orientation
+    prof_mark(h, st, ST_ANGLE, true);
     orbk_ic_angle(st, h->d_levels, nl, d_gray, stride, frame_stride, h->d_pyr, h->d_lkp, h->kp_frame_stride, kp_count,
                   h->max_kp_level, nframes);
+    prof_mark(h, st, ST_ANGLE, false);
     // K6: blur every level
+    prof_mark(h, st, ST_BLUR, true);
     for (int l = 0; l < nl; ++l) {
         const OrbLevel& L = h->levels[l];
         const uint8_t* src = l == 0 ? d_gray : h->d_pyr + L.plane_off;
         orbk_blur(st, src, L.w, L.h, l == 0 ? stride : (size_t)L.stride, l == 0 ? frame_stride : h->pyr_frame_total,
                   h->d_blur + L.blur_off, (size_t)L.stride, h->blur_frame_total, nframes);
     }
+    prof_mark(h, st, ST_BLUR, false);
     // K7: descriptors + output records
+    prof_mark(h, st, ST_DESCRIBE, true);
     orbk_describe(st, h->d_levels, nl, h->d_blur, h->d_lkp, h->kp_frame_stride, kp_count, d_kps, d_desc, cap, d_n_out,
                   h->max_kp_level, nframes);
+    prof_mark(h, st, ST_DESCRIBE, false);
     HIP_TRY(hipGetLastError());
     h->last_img0 = d_gray; h->last_stride = stride; h->last_frame = frame_stride; h->last_nframes = nframes;
     return SLAMIT_OK;
@@ -381,6 +410,25 @@ int slamit_orb_extract_batch(slamit_orb* h, const uint8_t* gray, size_t stride, 
 int slamit_orb_extract(slamit_orb* h, const uint8_t* gray, size_t stride, slamit_kp* kps, uint8_t* desc, int cap,
                        int* n_out) {
     return slamit_orb_extract_batch(h, gray, stride, stride * (size_t)(h ? h->p.height : 0), 1, kps, desc, cap, n_out);
+}
+
+int slamit_orb_profile(slamit_orb* h, int enable, float* stage_ms, int32_t* stage_calls, int nstages) {
+    if (!h) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_profile: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (stage_ms || stage_calls) {
+        for (int i = 0; i < nstages; ++i) { if (stage_ms) stage_ms[i] = 0.f; if (stage_calls) stage_calls[i] = 0; }
+        for (size_t i = 0; i < h->prof_stage.size() && 2 * i + 1 < h->prof_ev.size(); ++i) {
+            HIP_TRY(hipEventSynchronize(h->prof_ev[2 * i + 1]));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+            int s = h->prof_stage[i];
+            if (s < nstages) { if (stage_ms) stage_ms[s] += ms; if (stage_calls) stage_calls[s] += 1; }
+        }
+    }
+    for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
+    h->prof_ev.clear(); h->prof_stage.clear();
+    h->prof_on = enable;
+    return SLAMIT_OK;
 }
 
 int slamit_orb_level(slamit_orb* h, int frame, int level, uint8_t* dst, size_t dst_bytes, int* w, int* h_out) {
