@@ -1,0 +1,465 @@
+// ba_oracle.cc — CPU ORACLE for Optimizer::LocalBundleAdjustment.  TEST INFRASTRUCTURE ONLY.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library
+// (oracle/libba_oracle.so).  Nothing under weiner_slamit_v2_amd/ links or calls it.
+//
+// A from-scratch, single-threaded, fp64 restatement of what g2o does for the reference's local
+// BA (reference paths: "S/" = ORB_SLAM2/src/, "G/" = Thirdparty/g2o/g2o/):
+//   schedule, gates             S/Optimizer.cc:659-743
+//   residual / Jacobians        G/types/types_six_dof_expmap.h:90-101, .cpp:103-147
+//   Huber weighting             G/core/robust_kernel_impl.cpp:77-90, G/core/base_edge.h:96-102
+//   normal equations            G/core/base_binary_edge.hpp:55-120, G/core/block_solver.hpp:502-560
+//   Schur complement + solve    G/core/block_solver.hpp:367-486 (dense LDLt here instead of
+//                               G/solvers/linear_solver_eigen.h's sparse SimplicialLDLT)
+//   Levenberg-Marquardt control G/core/optimization_algorithm_levenberg.cpp:61-189
+//   manifold updates            G/types/se3quat.h:218-253,103-109,276-281, types_sba.h:52-56
+//
+// PARITY STATUS: PINNED.  The reference's own g2o + Eigen compile in the authoring container
+// (oracle/Makefile.ref -> oracle/_ref/libba_ref.so, driven by oracle/ba_ref_harness.cc); this
+// restatement is checked against it there (tests/test_oracle_ba.py::test_vs_reference_g2o) and
+// against the golden vectors it produced (tests/golden/ba_*.npz, tools/gen_ba_golden.py), which
+// travel to the GPU box.
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../include/slamit.h"
+
+namespace {
+
+struct Pose { double q[4]; double t[3]; };  // q = (x, y, z, w), world -> camera
+
+inline void quat_to_R(const double q[4], double R[9]) {
+    // Eigen::Quaterniond::toRotationMatrix
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+inline void R_to_quat(const double m[9], double q[4]) {
+    // Eigen's rotation matrix -> quaternion (Shepperd, trace branch first)
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+
+inline void quat_normalize(double q[4]) {  // SE3Quat::normalizeRotation
+    if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+
+inline void quat_mul(const double a[4], const double b[4], double r[4]) {
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+
+inline void quat_rot(const double q[4], const double v[3], double r[3]) {
+    // Eigen: v + w*uv + u x uv, uv = 2 (u x v)
+    double uv[3] = {2 * (q[1] * v[2] - q[2] * v[1]), 2 * (q[2] * v[0] - q[0] * v[2]), 2 * (q[0] * v[1] - q[1] * v[0])};
+    r[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    r[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    r[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+
+inline void mat3_mul(const double a[9], const double b[9], double c[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+// T <- exp(update) * T, update = [omega, upsilon]     (SE3Quat::exp, VertexSE3Expmap::oplusImpl)
+void pose_oplus(Pose& T, const double* u) {
+    const double* w = u;
+    const double* ups = u + 3;
+    double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double O2[9];
+    mat3_mul(O, O, O2);
+    double R[9], V[9];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i];
+        memcpy(V, R, sizeof(R));
+    } else {
+        double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+        for (int i = 0; i < 9; ++i) {
+            double I = (i % 4 == 0 ? 1.0 : 0.0);
+            R[i] = I + a * O[i] + b * O2[i];
+            V[i] = I + b * O[i] + c * O2[i];
+        }
+    }
+    double qe[4], te[3];
+    R_to_quat(R, qe);
+    quat_normalize(qe);  // SE3Quat(q, t) constructor normalises
+    for (int i = 0; i < 3; ++i) te[i] = V[3 * i] * ups[0] + V[3 * i + 1] * ups[1] + V[3 * i + 2] * ups[2];
+    // result = exp * T :  t = te + qe * T.t ; q = qe * T.q ; normalise
+    double rt[3];
+    quat_rot(qe, T.t, rt);
+    double nq[4];
+    quat_mul(qe, T.q, nq);
+    for (int i = 0; i < 3; ++i) T.t[i] = te[i] + rt[i];
+    memcpy(T.q, nq, sizeof(nq));
+    quat_normalize(T.q);
+}
+
+struct Edge {
+    int kf, pt;
+    double u, v, w;
+    bool active, robust;
+    double err[2];
+    double chi2;
+};
+
+struct Problem {
+    int K, P, E;
+    std::vector<Pose> poses;
+    std::vector<uint8_t> fixed;
+    std::vector<double> intr, pts;
+    std::vector<Edge> edges;
+    double delta, gate;
+    const volatile uint8_t* stop;
+    // index mapping of the current stage
+    std::vector<int> pose_col;  // -1 = fixed, else block index among free poses
+    int nfree;
+};
+
+inline bool stopped(const Problem& pb) { return pb.stop && *pb.stop; }
+
+// computeActiveErrors + activeRobustChi2
+double compute_errors(Problem& pb) {
+    double total = 0;
+    const double dsqr = pb.delta * pb.delta;
+    for (int e = 0; e < pb.E; ++e) {
+        Edge& ed = pb.edges[e];
+        if (!ed.active) continue;
+        const Pose& T = pb.poses[ed.kf];
+        double Xc[3];
+        quat_rot(T.q, &pb.pts[3 * ed.pt], Xc);
+        for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
+        const double* in = &pb.intr[4 * ed.kf];
+        ed.err[0] = ed.u - (Xc[0] / Xc[2] * in[0] + in[2]);  // project2d then *fx + cx
+        ed.err[1] = ed.v - (Xc[1] / Xc[2] * in[1] + in[3]);
+        ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1];
+        if (ed.robust) {
+            if (ed.chi2 <= dsqr) total += ed.chi2;
+            else total += 2 * sqrt(ed.chi2) * pb.delta - dsqr;
+        } else total += ed.chi2;
+    }
+    return total;
+}
+
+struct System {
+    int np, nl;
+    std::vector<double> Hpp, Hll, Hpl, bp, bl;  // Hpp nfree*36 (row-major 6x6), Hll P*9, Hpl E*18 (6x3), b
+};
+
+void build_system(Problem& pb, System& S) {
+    S.np = pb.nfree; S.nl = pb.P;
+    S.Hpp.assign((size_t)S.np * 36, 0.0); S.Hll.assign((size_t)pb.P * 9, 0.0); S.Hpl.assign((size_t)pb.E * 18, 0.0);
+    S.bp.assign((size_t)S.np * 6, 0.0); S.bl.assign((size_t)pb.P * 3, 0.0);
+    const double dsqr = pb.delta * pb.delta;
+    for (int e = 0; e < pb.E; ++e) {
+        const Edge& ed = pb.edges[e];
+        if (!ed.active) continue;
+        const Pose& T = pb.poses[ed.kf];
+        const double* in = &pb.intr[4 * ed.kf];
+        const double fx = in[0], fy = in[1];
+        double Xc[3], R[9];
+        quat_rot(T.q, &pb.pts[3 * ed.pt], Xc);
+        for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
+        quat_to_R(T.q, R);
+        const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
+        // _jacobianOplusXi = -1/z * tmp * R
+        double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+        double A[6];
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c)
+                A[3 * r + c] = -1. / z * (tmp[3 * r] * R[c] + tmp[3 * r + 1] * R[3 + c] + tmp[3 * r + 2] * R[6 + c]);
+        double B[12];
+        B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx;
+        B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+        B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy;
+        B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+        double rho1 = 1.0;
+        if (ed.robust && ed.chi2 > dsqr) rho1 = pb.delta / sqrt(ed.chi2);
+        const double wO = rho1 * ed.w;                       // weightedOmega = rho[1] * information
+        const double r0 = -ed.w * ed.err[0] * rho1, r1 = -ed.w * ed.err[1] * rho1;  // omega_r
+        double* bl = &S.bl[3 * ed.pt];
+        double* Hl = &S.Hll[9 * ed.pt];
+        for (int i = 0; i < 3; ++i) {
+            bl[i] += A[i] * r0 + A[3 + i] * r1;
+            for (int j = 0; j < 3; ++j) Hl[3 * i + j] += (A[i] * A[j] + A[3 + i] * A[3 + j]) * wO;
+        }
+        const int col = pb.pose_col[ed.kf];
+        if (col >= 0) {
+            double* bq = &S.bp[6 * col];
+            double* Hp = &S.Hpp[36 * col];
+            double* Hx = &S.Hpl[18 * (size_t)e];
+            for (int i = 0; i < 6; ++i) {
+                bq[i] += B[i] * r0 + B[6 + i] * r1;
+                for (int j = 0; j < 6; ++j) Hp[6 * i + j] += (B[i] * B[j] + B[6 + i] * B[6 + j]) * wO;
+                for (int j = 0; j < 3; ++j) Hx[3 * i + j] += (B[i] * A[j] + B[6 + i] * A[3 + j]) * wO;
+            }
+        }
+    }
+}
+
+inline bool inv3(const double* m, double* o) {
+    double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
+    double det = m[0] * c0 + m[1] * c1 + m[2] * c2;
+    double id = 1.0 / det;
+    o[0] = c0 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c1 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c2 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return true;
+}
+
+// dense LDLt without pivoting on the upper triangle; false if a pivot is exactly zero
+// (what SimplicialLDLT reports as NumericalIssue)
+bool ldlt_solve(std::vector<double>& A, int n, std::vector<double>& b) {
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k] * A[(size_t)k * n + k];
+        if (d == 0.0 || !std::isfinite(d)) return false;
+        A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k] * A[(size_t)k * n + k];
+            A[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * b[k]; b[i] = s; }
+    for (int i = 0; i < n; ++i) b[i] /= A[(size_t)i * n + i];
+    for (int i = n - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * b[k]; b[i] = s; }
+    return true;
+}
+
+// BlockSolver::solve with the diagonal already augmented by lambda. x = [poses | points]
+bool solve_schur(const Problem& pb, const System& S, double lambda, const std::vector<std::vector<int> >& pt_edges,
+                 std::vector<double>& x) {
+    const int n = 6 * S.np;
+    std::vector<double> Sm((size_t)n * n, 0.0), bs(S.bp), Dinv((size_t)pb.P * 9), coeff(n, 0.0);
+    for (int k = 0; k < S.np; ++k)
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) Sm[(size_t)(6 * k + i) * n + 6 * k + j] = S.Hpp[36 * k + 6 * i + j] + (i == j ? lambda : 0.0);
+    for (int p = 0; p < pb.P; ++p) {
+        double D[9];
+        for (int i = 0; i < 9; ++i) D[i] = S.Hll[9 * p + i] + (i % 4 == 0 ? lambda : 0.0);
+        double* Di = &Dinv[9 * (size_t)p];
+        inv3(D, Di);
+        double db[3];
+        for (int i = 0; i < 3; ++i) db[i] = Di[3 * i] * S.bl[3 * p] + Di[3 * i + 1] * S.bl[3 * p + 1] + Di[3 * i + 2] * S.bl[3 * p + 2];
+        const std::vector<int>& es = pt_edges[p];
+        for (size_t a = 0; a < es.size(); ++a) {
+            const int e1 = es[a], c1 = pb.pose_col[pb.edges[e1].kf];
+            if (c1 < 0) continue;
+            const double* B1 = &S.Hpl[18 * (size_t)e1];
+            double BD[18];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 3; ++j) BD[3 * i + j] = B1[3 * i] * Di[j] + B1[3 * i + 1] * Di[3 + j] + B1[3 * i + 2] * Di[6 + j];
+            for (int i = 0; i < 6; ++i) coeff[6 * c1 + i] += B1[3 * i] * db[0] + B1[3 * i + 1] * db[1] + B1[3 * i + 2] * db[2];
+            for (size_t b2 = 0; b2 < es.size(); ++b2) {
+                const int e2 = es[b2], c2 = pb.pose_col[pb.edges[e2].kf];
+                if (c2 < 0) continue;
+                const double* B2 = &S.Hpl[18 * (size_t)e2];
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j)
+                        Sm[(size_t)(6 * c1 + i) * n + 6 * c2 + j] -= BD[3 * i] * B2[3 * j] + BD[3 * i + 1] * B2[3 * j + 1] + BD[3 * i + 2] * B2[3 * j + 2];
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) bs[i] -= coeff[i];
+    x.assign((size_t)n + 3 * pb.P, 0.0);
+    bool ok = true;
+    if (n > 0) ok = ldlt_solve(Sm, n, bs);
+    if (!ok) return false;
+    for (int i = 0; i < n; ++i) x[i] = bs[i];
+    // xl = Dinv * (bl - Bt * xp)
+    for (int p = 0; p < pb.P; ++p) {
+        double cl[3] = {S.bl[3 * p], S.bl[3 * p + 1], S.bl[3 * p + 2]};
+        const std::vector<int>& es = pt_edges[p];
+        for (size_t a = 0; a < es.size(); ++a) {
+            const int e = es[a], c = pb.pose_col[pb.edges[e].kf];
+            if (c < 0) continue;
+            const double* B = &S.Hpl[18 * (size_t)e];
+            for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 6; ++i) cl[j] -= B[3 * i + j] * x[6 * c + i];
+        }
+        const double* Di = &Dinv[9 * (size_t)p];
+        for (int i = 0; i < 3; ++i) x[n + 3 * p + i] = Di[3 * i] * cl[0] + Di[3 * i + 1] * cl[1] + Di[3 * i + 2] * cl[2];
+    }
+    return true;
+}
+
+// SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
+int optimize(Problem& pb, int iterations, int stage, slamit_ba_stats* st) {
+    // index mapping: free poses in id order (every free pose keeps a column even without active
+    // edges: it then has a zero Hessian and a zero update, equivalent to g2o leaving it out)
+    pb.pose_col.assign(pb.K, -1);
+    pb.nfree = 0;
+    for (int k = 0; k < pb.K; ++k) if (!pb.fixed[k]) pb.pose_col[k] = pb.nfree++;
+    std::vector<std::vector<int> > pt_edges(pb.P);
+    for (int e = 0; e < pb.E; ++e) if (pb.edges[e].active) pt_edges[pb.edges[e].pt].push_back(e);
+    bool any_active = false;
+    for (int e = 0; e < pb.E; ++e) any_active |= pb.edges[e].active;
+    if (!any_active) return 0;  // g2o: "0 vertices to optimize" -> optimize() returns without iterating
+    const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
+    const int maxTrials = 10;
+    double lambda = -1, ni = 2;
+    int nBad = 0, done = 0;
+    System S;
+    std::vector<double> x;
+    bool ok = true;
+    for (int it = 0; it < iterations && !stopped(pb) && ok; ++it) {
+        double currentChi = compute_errors(pb);
+        double tempChi = currentChi;
+        const double iniChi = currentChi;
+        build_system(pb, S);
+        if (it == 0) {
+            double maxDiag = 0;
+            for (int k = 0; k < S.np; ++k) for (int j = 0; j < 6; ++j) maxDiag = std::max(fabs(S.Hpp[36 * k + 7 * j]), maxDiag);
+            for (int p = 0; p < pb.P; ++p) for (int j = 0; j < 3; ++j) maxDiag = std::max(fabs(S.Hll[9 * p + 4 * j]), maxDiag);
+            lambda = tau * maxDiag;
+            ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            std::vector<Pose> backupPoses = pb.poses;  // push()
+            std::vector<double> backupPts = pb.pts;
+            bool ok2 = solve_schur(pb, S, lambda, pt_edges, x);
+            if (ok2 || !x.empty()) {  // update(_solver->x())
+                if (x.size() == (size_t)6 * S.np + 3 * pb.P) {
+                    for (int k = 0; k < pb.K; ++k) if (pb.pose_col[k] >= 0) pose_oplus(pb.poses[k], &x[6 * pb.pose_col[k]]);
+                    for (int i = 0; i < 3 * pb.P; ++i) pb.pts[i] += x[6 * S.np + i];
+                }
+            }
+            tempChi = compute_errors(pb);
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            double scale = 0;  // computeScale
+            for (int k = 0; k < 6 * S.np; ++k) scale += x[k] * (lambda * x[k] + S.bp[k]);
+            for (int k = 0; k < 3 * pb.P; ++k) scale += x[6 * S.np + k] * (lambda * x[6 * S.np + k] + S.bl[k]);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, upper);
+                double scaleFactor = std::max(lower, alpha);
+                lambda *= scaleFactor;
+                ni = 2;
+                currentChi = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                pb.poses = backupPoses;  // pop()
+                pb.pts = backupPts;
+            }
+            ++qmax;
+        } while (rho < 0 && qmax < maxTrials && !stopped(pb));
+        ++done;
+        if (st && it < SLAMIT_BA_MAX_ITS) {
+            // robust cost of the last evaluated trial (what activeRobustChi2() returns afterwards)
+            st->chi2[stage][it] = tempChi;
+            st->lambda[stage][it] = lambda;
+            st->trials[stage][it] = qmax;
+        }
+        if (qmax == maxTrials || rho == 0) { ok = false; continue; }  // Terminate
+        if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
+        if (nBad >= 3) ok = false;
+    }
+    return done;
+}
+
+}  // namespace
+
+extern "C" int ba_oracle_solve(const slamit_ba_problem* in, const slamit_ba_opts* op, slamit_ba_result* res) {
+    Problem pb;
+    pb.K = in->n_kf; pb.P = in->n_pt; pb.E = in->n_edge;
+    pb.delta = op->huber_delta; pb.gate = op->chi2_gate; pb.stop = op->stop;
+    pb.poses.resize(pb.K);
+    pb.fixed.assign(in->kf_fixed, in->kf_fixed + pb.K);
+    pb.intr.assign(in->kf_intr, in->kf_intr + 4 * (size_t)pb.K);
+    pb.pts.assign(in->pt_xyz, in->pt_xyz + 3 * (size_t)pb.P);
+    for (int k = 0; k < pb.K; ++k) {  // Converter::toSE3Quat -> SE3Quat(R, t): Quaterniond(R), normalised
+        R_to_quat(in->kf_pose + 12 * (size_t)k, pb.poses[k].q);
+        quat_normalize(pb.poses[k].q);
+        for (int i = 0; i < 3; ++i) pb.poses[k].t[i] = in->kf_pose[12 * (size_t)k + 9 + i];
+    }
+    pb.edges.resize(pb.E);
+    for (int e = 0; e < pb.E; ++e) {
+        Edge& ed = pb.edges[e];
+        ed.kf = in->edge_kf[e]; ed.pt = in->edge_pt[e];
+        if (ed.kf < 0 || ed.kf >= pb.K || ed.pt < 0 || ed.pt >= pb.P) return -1;
+        ed.u = in->edge_uv[2 * (size_t)e]; ed.v = in->edge_uv[2 * (size_t)e + 1];
+        ed.w = in->edge_inv_sigma2[e];
+        ed.active = true; ed.robust = true;
+        ed.err[0] = ed.err[1] = 0; ed.chi2 = 0;
+    }
+    slamit_ba_stats* st = res->stats;
+    if (st) memset(st, 0, sizeof(*st));
+    for (int stage = 0; stage < 2; ++stage) {
+        if (stopped(pb)) break;  // S/Optimizer.cc:655-657, 664-666
+        if (stage == 1) {
+            for (int e = 0; e < pb.E; ++e) {
+                Edge& ed = pb.edges[e];
+                const Pose& T = pb.poses[ed.kf];
+                double Xc[3];
+                quat_rot(T.q, &pb.pts[3 * ed.pt], Xc);
+                bool out = ed.chi2 > pb.gate || !(Xc[2] + T.t[2] > 0.0);
+                if (out) ed.active = false;   // setLevel(1)
+                ed.robust = false;            // setRobustKernel(0)
+                if (res->edge_stage1_outlier) res->edge_stage1_outlier[e] = out;
+            }
+        }
+        if (st) {
+            // cost at the stage's starting point; per-edge errors are restored afterwards so the
+            // stale values of de-activated edges stay what the reference would read
+            std::vector<Edge> keep = pb.edges;
+            st->chi2_init[stage] = compute_errors(pb);
+            pb.edges = keep;
+        }
+        int n = optimize(pb, stage == 0 ? op->its_robust : op->its_final, stage, st);
+        if (st) st->n_its[stage] = n;
+    }
+    for (int e = 0; e < pb.E; ++e) {
+        const Edge& ed = pb.edges[e];
+        const Pose& T = pb.poses[ed.kf];
+        double Xc[3];
+        quat_rot(T.q, &pb.pts[3 * ed.pt], Xc);
+        if (res->edge_chi2) res->edge_chi2[e] = ed.chi2;
+        if (res->edge_outlier) res->edge_outlier[e] = ed.chi2 > pb.gate || !(Xc[2] + T.t[2] > 0.0);
+    }
+    for (int k = 0; k < pb.K; ++k) {
+        double R[9];
+        quat_to_R(pb.poses[k].q, R);
+        memcpy(res->kf_pose + 12 * (size_t)k, R, sizeof(R));
+        for (int i = 0; i < 3; ++i) res->kf_pose[12 * (size_t)k + 9 + i] = pb.poses[k].t[i];
+    }
+    memcpy(res->pt_xyz, pb.pts.data(), sizeof(double) * 3 * (size_t)pb.P);
+    return 0;
+}

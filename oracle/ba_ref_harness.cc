@@ -1,0 +1,153 @@
+// ba_ref_harness.cc — drives the REFERENCE's own g2o (compiled by oracle/Makefile.ref from
+// /root/reference, outputs in oracle/_ref/) exactly the way Optimizer::LocalBundleAdjustment
+// does, but from POD inputs.  TEST INFRASTRUCTURE ONLY: used in the authoring container to
+// validate oracle/ba_oracle.cc and to generate tests/golden/ba_*.npz (tools/gen_ba_golden.py).
+//
+// Follows ORB_SLAM2/src/Optimizer.cc ("S/Optimizer.cc"):
+//   solver stack         :507-515   BlockSolver_6_3 + LinearSolverEigen + Levenberg
+//   keyframe vertices    :523-546   id = index, fixed flag, estimate = Converter::toSE3Quat(pose)
+//   point vertices       :572-580   id = index + maxKFid + 1, marginalised
+//   mono edges           :596-619   obs, Omega = I*invSigma2, Huber(delta), fx fy cx cy
+//   schedule             :659-707   optimize(5) robust -> chi2 gate / depth -> level 1, kernels off
+//                                   -> initializeOptimization(0) -> optimize(10)
+//   erasure test         :715-728   chi2 > gate || !isDepthPositive on EVERY edge
+#include <vector>
+
+#include "Thirdparty/g2o/g2o/core/block_solver.h"
+#include "Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.h"
+#include "Thirdparty/g2o/g2o/core/robust_kernel_impl.h"
+#include "Thirdparty/g2o/g2o/core/sparse_optimizer.h"
+#include "Thirdparty/g2o/g2o/core/hyper_graph_action.h"
+#include "Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h"
+#include "Thirdparty/g2o/g2o/types/types_six_dof_expmap.h"
+
+#include "../include/slamit.h"
+
+namespace {
+
+// Post-iteration action: records lambda, the number of LM trials and the robust cost of the
+// LAST EVALUATED trial (no recomputation: batch statistics stay off like in the reference, so
+// the per-edge errors keep the values the reference's chi2 gate reads at S/Optimizer.cc:680).
+struct LambdaRecorder : public g2o::HyperGraphAction {
+    g2o::OptimizationAlgorithmLevenberg* alg;
+    g2o::SparseOptimizer* opt;
+    std::vector<double> lambdas, chi2;
+    std::vector<int> trials;
+    virtual g2o::HyperGraphAction* operator()(const g2o::HyperGraph*, Parameters* = 0) {
+        lambdas.push_back(alg->currentLambda());
+        trials.push_back(alg->levenbergIteration());
+        chi2.push_back(opt->activeRobustChi2());
+        return this;
+    }
+};
+
+}  // namespace
+
+extern "C" int ba_ref_solve(const slamit_ba_problem* pb, const slamit_ba_opts* op, slamit_ba_result* res) {
+    g2o::SparseOptimizer optimizer;
+    g2o::BlockSolver_6_3::LinearSolverType* linearSolver =
+        new g2o::LinearSolverEigen<g2o::BlockSolver_6_3::PoseMatrixType>();
+    g2o::BlockSolver_6_3* solver_ptr = new g2o::BlockSolver_6_3(linearSolver);
+    g2o::OptimizationAlgorithmLevenberg* solver = new g2o::OptimizationAlgorithmLevenberg(solver_ptr);
+    optimizer.setAlgorithm(solver);
+    bool stopflag = false;
+    if (op->stop) optimizer.setForceStopFlag(const_cast<bool*>(reinterpret_cast<const volatile bool*>(op->stop)));
+    (void)stopflag;
+
+    const int K = pb->n_kf, P = pb->n_pt, E = pb->n_edge;
+    for (int k = 0; k < K; ++k) {
+        Eigen::Matrix<double, 3, 3> R;
+        const double* p = pb->kf_pose + 12 * k;
+        R << p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8];
+        Eigen::Matrix<double, 3, 1> t(p[9], p[10], p[11]);
+        g2o::VertexSE3Expmap* v = new g2o::VertexSE3Expmap();
+        v->setEstimate(g2o::SE3Quat(R, t));
+        v->setId(k);
+        v->setFixed(pb->kf_fixed[k] != 0);
+        optimizer.addVertex(v);
+    }
+    const int maxKFid = K - 1;
+    std::vector<g2o::EdgeSE3ProjectXYZ*> edges(E, (g2o::EdgeSE3ProjectXYZ*)0);
+    for (int p = 0; p < P; ++p) {
+        g2o::VertexSBAPointXYZ* v = new g2o::VertexSBAPointXYZ();
+        v->setEstimate(Eigen::Vector3d(pb->pt_xyz[3 * p], pb->pt_xyz[3 * p + 1], pb->pt_xyz[3 * p + 2]));
+        v->setId(p + maxKFid + 1);
+        v->setMarginalized(true);
+        optimizer.addVertex(v);
+    }
+    for (int e = 0; e < E; ++e) {
+        const int id = pb->edge_pt[e] + maxKFid + 1, kf = pb->edge_kf[e];
+        Eigen::Matrix<double, 2, 1> obs;
+        obs << pb->edge_uv[2 * e], pb->edge_uv[2 * e + 1];
+        g2o::EdgeSE3ProjectXYZ* ed = new g2o::EdgeSE3ProjectXYZ();
+        ed->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(id)));
+        ed->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(kf)));
+        ed->setMeasurement(obs);
+        ed->setInformation(Eigen::Matrix2d::Identity() * pb->edge_inv_sigma2[e]);
+        g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber;
+        ed->setRobustKernel(rk);
+        rk->setDelta(op->huber_delta);
+        ed->fx = pb->kf_intr[4 * kf]; ed->fy = pb->kf_intr[4 * kf + 1];
+        ed->cx = pb->kf_intr[4 * kf + 2]; ed->cy = pb->kf_intr[4 * kf + 3];
+        optimizer.addEdge(ed);
+        edges[e] = ed;
+    }
+
+    slamit_ba_stats* st = res->stats;
+    if (st) memset(st, 0, sizeof(*st));
+    LambdaRecorder rec;
+    rec.alg = solver;
+    rec.opt = &optimizer;
+    optimizer.addPostIterationAction(&rec);
+
+    for (int stage = 0; stage < 2; ++stage) {
+        const int its = stage == 0 ? op->its_robust : op->its_final;
+        if (op->stop && *op->stop) break;  // S/Optimizer.cc:655-657, 664-666
+        if (stage == 1) {
+            for (int e = 0; e < E; ++e) {
+                g2o::EdgeSE3ProjectXYZ* ed = edges[e];
+                bool out = ed->chi2() > op->chi2_gate || !ed->isDepthPositive();
+                if (out) ed->setLevel(1);
+                if (res->edge_stage1_outlier) res->edge_stage1_outlier[e] = out;
+                ed->setRobustKernel(0);
+            }
+            optimizer.initializeOptimization(0);
+        } else {
+            optimizer.initializeOptimization();
+        }
+        rec.lambdas.clear(); rec.trials.clear(); rec.chi2.clear();
+        if (st) {
+            optimizer.computeActiveErrors();  // harmless: solve() recomputes them first thing
+            st->chi2_init[stage] = optimizer.activeRobustChi2();
+        }
+        int n = optimizer.optimize(its);
+        if (n < 0) n = 0;  // "0 vertices to optimize": every edge was de-activated
+        if (st) {
+            st->n_its[stage] = n;
+            for (int i = 0; i < n && i < SLAMIT_BA_MAX_ITS; ++i) {
+                st->chi2[stage][i] = i < (int)rec.chi2.size() ? rec.chi2[i] : 0;
+                st->lambda[stage][i] = i < (int)rec.lambdas.size() ? rec.lambdas[i] : 0;
+                st->trials[stage][i] = i < (int)rec.trials.size() ? rec.trials[i] : 0;
+            }
+        }
+    }
+
+    for (int e = 0; e < E; ++e) {
+        g2o::EdgeSE3ProjectXYZ* ed = edges[e];
+        if (res->edge_chi2) res->edge_chi2[e] = ed->chi2();
+        if (res->edge_outlier) res->edge_outlier[e] = ed->chi2() > op->chi2_gate || !ed->isDepthPositive();
+    }
+    for (int k = 0; k < K; ++k) {
+        g2o::VertexSE3Expmap* v = static_cast<g2o::VertexSE3Expmap*>(optimizer.vertex(k));
+        Eigen::Matrix<double, 4, 4> T = v->estimate().to_homogeneous_matrix();  // Converter::toCvMat(SE3Quat)
+        double* o = res->kf_pose + 12 * k;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) o[3 * r + c] = T(r, c);
+        for (int r = 0; r < 3; ++r) o[9 + r] = T(r, 3);
+    }
+    for (int p = 0; p < P; ++p) {
+        g2o::VertexSBAPointXYZ* v = static_cast<g2o::VertexSBAPointXYZ*>(optimizer.vertex(p + maxKFid + 1));
+        for (int c = 0; c < 3; ++c) res->pt_xyz[3 * p + c] = v->estimate()[c];
+    }
+    return 0;
+}

@@ -25,7 +25,7 @@ _f32p = C.POINTER(C.c_float)
 def build(force=False):
     """Compile the oracle libraries with the committed Makefile (g++, seconds)."""
     need = force or not all(
-        os.path.exists(os.path.join(HERE, n)) for n in ("liborb_oracle.so",)
+        os.path.exists(os.path.join(HERE, n)) for n in ("liborb_oracle.so", "libba_oracle.so")
     )
     if need:
         subprocess.check_call(["make", "-s", "-C", HERE, "-f", os.path.join(HERE, "Makefile"), "all"])
@@ -212,3 +212,89 @@ def matrix(q, t):
     out = np.zeros((len(q), len(t)), np.uint16)
     orb_lib().orb_oracle_matrix(_ptr(q), len(q), _ptr(t), len(t), out.ctypes.data_as(C.POINTER(C.c_uint16)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Local bundle adjustment: the restatement (libba_oracle.so) and, where it was built in the
+# authoring container, the reference's own g2o (oracle/_ref/libba_ref.so).
+# ---------------------------------------------------------------------------------------------
+MAX_ITS = 32
+
+
+class _BaProblem(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("n_pt", C.c_int32), ("n_edge", C.c_int32),
+                ("kf_pose", C.c_void_p), ("kf_fixed", C.c_void_p), ("kf_intr", C.c_void_p),
+                ("pt_xyz", C.c_void_p), ("edge_kf", C.c_void_p), ("edge_pt", C.c_void_p),
+                ("edge_uv", C.c_void_p), ("edge_inv_sigma2", C.c_void_p)]
+
+
+class _BaOpts(C.Structure):
+    _fields_ = [("its_robust", C.c_int32), ("its_final", C.c_int32), ("huber_delta", C.c_double),
+                ("chi2_gate", C.c_double), ("stop", C.c_void_p)]
+
+
+class _BaStats(C.Structure):
+    _fields_ = [("n_its", C.c_int32 * 2), ("chi2", (C.c_double * MAX_ITS) * 2),
+                ("lambda_", (C.c_double * MAX_ITS) * 2), ("trials", (C.c_int32 * MAX_ITS) * 2),
+                ("chi2_init", C.c_double * 2)]
+
+
+class _BaResult(C.Structure):
+    _fields_ = [("kf_pose", C.c_void_p), ("pt_xyz", C.c_void_p), ("edge_chi2", C.c_void_p),
+                ("edge_outlier", C.c_void_p), ("edge_stage1_outlier", C.c_void_p), ("stats", C.c_void_p)]
+
+
+HUBER_MONO = float(np.float32(np.sqrt(5.991)))  # Optimizer.cc:569: sqrt(5.991) stored in a float
+
+_ba = {}
+
+
+def ba_ref_available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libba_ref.so"))
+
+
+def _ba_fn(which):
+    if which not in _ba:
+        if which == "oracle":
+            build()
+            L = C.CDLL(os.path.join(HERE, "libba_oracle.so"))
+            fn = L.ba_oracle_solve
+        else:
+            L = C.CDLL(os.path.join(HERE, "_ref", "libba_ref.so"))
+            fn = L.ba_ref_solve
+        fn.argtypes = [C.POINTER(_BaProblem), C.POINTER(_BaOpts), C.POINTER(_BaResult)]
+        _ba[which] = fn
+    return _ba[which]
+
+
+def _ba_call(which, prob, its_robust, its_final, huber_delta, chi2_gate, stop):
+    keep = {}
+    for k, dt in (("kf_pose", np.float64), ("kf_fixed", np.uint8), ("kf_intr", np.float64), ("pt_xyz", np.float64),
+                  ("edge_kf", np.int32), ("edge_pt", np.int32), ("edge_uv", np.float64), ("edge_inv_sigma2", np.float64)):
+        keep[k] = np.ascontiguousarray(prob[k], dtype=dt)
+    nk, npt, ne = len(keep["kf_fixed"]), len(keep["pt_xyz"]), len(keep["edge_kf"])
+    p = _BaProblem(nk, npt, ne, *[keep[k].ctypes.data for k in (
+        "kf_pose", "kf_fixed", "kf_intr", "pt_xyz", "edge_kf", "edge_pt", "edge_uv", "edge_inv_sigma2")])
+    o = _BaOpts(its_robust, its_final, huber_delta, chi2_gate, stop.ctypes.data if stop is not None else None)
+    out = {"kf_pose": np.zeros((nk, 12)), "pt_xyz": np.zeros((npt, 3)), "edge_chi2": np.zeros(ne),
+           "edge_outlier": np.zeros(ne, np.uint8), "edge_stage1_outlier": np.zeros(ne, np.uint8)}
+    st = _BaStats()
+    r = _BaResult(out["kf_pose"].ctypes.data, out["pt_xyz"].ctypes.data, out["edge_chi2"].ctypes.data,
+                  out["edge_outlier"].ctypes.data, out["edge_stage1_outlier"].ctypes.data, C.addressof(st))
+    rc = _ba_fn(which)(C.byref(p), C.byref(o), C.byref(r))
+    assert rc == 0, "BA %s failed" % which
+    n = list(st.n_its)
+    out["stats"] = {"n_its": n, "chi2": [list(st.chi2[s])[:n[s]] for s in range(2)],
+                    "lambda": [list(st.lambda_[s])[:n[s]] for s in range(2)],
+                    "trials": [list(st.trials[s])[:n[s]] for s in range(2)], "chi2_init": list(st.chi2_init)}
+    return out
+
+
+def ba_solve(prob, its_robust=5, its_final=10, huber_delta=HUBER_MONO, chi2_gate=5.991, stop=None):
+    """The CPU restatement (oracle/ba_oracle.cc)."""
+    return _ba_call("oracle", prob, its_robust, its_final, huber_delta, chi2_gate, stop)
+
+
+def ba_ref_solve(prob, its_robust=5, its_final=10, huber_delta=HUBER_MONO, chi2_gate=5.991, stop=None):
+    """The reference's own g2o (authoring container only)."""
+    return _ba_call("ref", prob, its_robust, its_final, huber_delta, chi2_gate, stop)

@@ -14,3 +14,20 @@ def pattern_pairs():
     nums = [int(v) for v in re.findall(r"-?\d+", body)]
     assert len(nums) == 1024
     return np.array(nums, np.int32).reshape(256, 4)
+
+
+def load_ba_golden(path):
+    """-> (problem dict as include/slamit.h wants it, reference-g2o result dict)."""
+    z = np.load(path)
+    prob = {k: z[k].astype(np.float64) for k in ("kf_pose", "kf_intr", "pt_xyz", "edge_uv", "edge_inv_sigma2")}
+    prob["kf_fixed"] = z["kf_fixed"].astype(np.uint8)
+    prob["edge_kf"] = z["edge_kf"].astype(np.int32)
+    prob["edge_pt"] = z["edge_pt"].astype(np.int32)
+    n = [int(v) for v in z["ref_n_its"]]
+    ref = {"kf_pose": z["ref_kf_pose"], "pt_xyz": z["ref_pt_xyz"], "edge_chi2": z["ref_edge_chi2"],
+           "edge_outlier": z["ref_edge_outlier"], "edge_stage1_outlier": z["ref_edge_stage1_outlier"],
+           "stats": {"n_its": n, "chi2": [list(z["ref_chi2"][s][:n[s]]) for s in range(2)],
+                     "lambda": [list(z["ref_lambda"][s][:n[s]]) for s in range(2)],
+                     "trials": [[int(v) for v in z["ref_trials"][s][:n[s]]] for s in range(2)],
+                     "chi2_init": list(z["ref_chi2_init"])}}
+    return prob, ref

@@ -1,0 +1,81 @@
+"""Pins the BA oracle (oracle/ba_oracle.cc) to the REFERENCE's own g2o.
+
+tests/golden/ba_*.npz were produced by tools/gen_ba_golden.py from g2o + Eigen compiled out of
+/root/reference (oracle/Makefile.ref); where that build exists (authoring container) the oracle
+is also compared with it live on fresh problems.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bindings as ob
+from tests.helpers import ROOT, load_ba_golden
+from weiner_slamit_v2_amd import synth
+
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ba_*.npz")))
+
+
+def _compare(res, ref, tol=1e-9, counts=True):
+    scale = max(np.abs(ref["kf_pose"]).max(), 1.0)
+    assert np.abs(res["kf_pose"] - ref["kf_pose"]).max() <= tol * scale
+    assert np.abs(res["pt_xyz"] - ref["pt_xyz"]).max() <= tol * max(np.abs(ref["pt_xyz"]).max(), 1.0)
+    assert np.array_equal(res["edge_stage1_outlier"], ref["edge_stage1_outlier"])
+    assert np.array_equal(res["edge_outlier"], ref["edge_outlier"])
+    assert np.allclose(res["edge_chi2"], ref["edge_chi2"], rtol=1e-6, atol=1e-9)
+    if counts:
+        s, r = res["stats"], ref["stats"]
+        assert s["n_its"] == r["n_its"] and s["trials"] == r["trials"]
+        for st in range(2):
+            assert np.allclose(s["chi2"][st], r["chi2"][st], rtol=1e-7, atol=1e-12)
+            assert np.allclose(s["lambda"][st], r["lambda"][st], rtol=1e-7)
+        assert np.allclose(s["chi2_init"], r["chi2_init"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[3:-4] for p in GOLDEN])
+def test_oracle_vs_golden(path):
+    prob, ref = load_ba_golden(path)
+    _compare(ob.ba_solve(prob), ref)
+
+
+def test_golden_set_is_complete():
+    names = {os.path.basename(p)[3:-4] for p in GOLDEN}
+    assert {"tiny", "small", "fixed3", "rough", "rejects", "allout", "window8"} <= names
+    _, ref = load_ba_golden(os.path.join(ROOT, "tests", "golden", "ba_rejects.npz"))
+    assert max(ref["stats"]["trials"][0]) >= 3      # exercises the reject / lambda*=ni path
+    _, ref = load_ba_golden(os.path.join(ROOT, "tests", "golden", "ba_allout.npz"))
+    assert ref["stats"]["n_its"][1] == 0 and ref["edge_outlier"].all()
+    _, ref = load_ba_golden(os.path.join(ROOT, "tests", "golden", "ba_window8.npz"))
+    assert ref["stats"]["n_its"][1] < 10            # Raul's stop rule fired (levenberg.cpp:155-161)
+
+
+@pytest.mark.skipif(not ob.ba_ref_available(), reason="reference g2o build (oracle/_ref) not present")
+@pytest.mark.parametrize("k,p,o,seed,nfix", [(6, 80, 3, 21, 1), (9, 120, 5, 22, 2), (20, 400, 6, 23, 1), (15, 250, None, 24, 1)])
+def test_vs_reference_g2o(k, p, o, seed, nfix):
+    prob = synth.synth_ba(k, p, o, seed=seed, n_fixed=nfix)
+    _compare(ob.ba_solve(prob), ob.ba_ref_solve(prob))
+
+
+def test_schedule_options_and_stop_flag():
+    prob, _ = load_ba_golden(os.path.join(ROOT, "tests", "golden", "ba_small.npz"))
+    full = ob.ba_solve(prob)
+    # stop flag raised before the call: nothing moves (Optimizer.cc:655-657)
+    stop = np.ones(1, np.uint8)
+    r = ob.ba_solve(prob, stop=stop)
+    assert np.allclose(r["pt_xyz"], prob["pt_xyz"]) and r["stats"]["n_its"] == [0, 0]
+    # fewer iterations: a prefix of the full run
+    r = ob.ba_solve(prob, its_robust=2, its_final=0)
+    assert r["stats"]["n_its"] == [2, 0]
+    assert np.allclose(r["stats"]["chi2"][0], full["stats"]["chi2"][0][:2])
+
+
+def test_cost_decreases():
+    prob = synth.synth_ba(10, 300, 5, seed=5, n_fixed=2)
+    r = ob.ba_solve(prob)
+    for st in range(2):
+        c = [r["stats"]["chi2_init"][st]] + r["stats"]["chi2"][st]
+        assert all(b <= a for a, b in zip(c, c[1:]))
+    # inliers end near the noise floor (1 px, 2 dof per edge)
+    inl = r["edge_outlier"] == 0
+    assert r["edge_chi2"][inl].mean() < 2.5
