@@ -1,0 +1,843 @@
+// ba_kernels.hip — hand-written gfx950 kernels of the local bundle adjustment (fp64).
+//
+// What they replace (reference: ORB_SLAM2/src/Optimizer.cc:453-778 driving g2o; "G/" =
+// Thirdparty/g2o/g2o/):
+//   k_linearize        EdgeSE3ProjectXYZ::computeError/linearizeOplus  G/types/types_six_dof_expmap.{h:90-95,cpp:103-139}
+//                      + Huber weight                                   G/core/robust_kernel_impl.cpp:77-90
+//   k_point_reduce     constructQuadraticForm, landmark side            G/core/base_binary_edge.hpp:55-120
+//   k_pose_reduce      constructQuadraticForm, pose side
+//   k_iter_begin       computeLambdaInit                                G/core/optimization_algorithm_levenberg.cpp:93-97,166-180
+//   k_prepare          setLambda + Dinv + Hpl, B*Dinv                    G/core/block_solver.hpp:564-589,381-400
+//   k_schur / _reduce  Schur complement  S = Hpp - sum_p B Dinv B^T      G/core/block_solver.hpp:401-439
+//                      as ONE dense split-K product GA * GB^T on v_mfma_f64_16x16x4_f64
+//   k_ldlt_solve       LinearSolverEigen::solve (dense blocked LDLt)     G/solvers/linear_solver_eigen.h:94-124
+//   k_backsub_update   landmark back-substitution + oplus + push()       G/core/block_solver.hpp:459-485, sparse_optimizer.cpp:422-435
+//   k_errors           computeActiveErrors + activeRobustChi2            G/core/sparse_optimizer.cpp:61-114
+//   k_decide           gain ratio, lambda update, pop()/discardTop(), stop rules   ...levenberg.cpp:102-161
+//   k_gate / k_final   chi2 gate + depth test between / after the stages  Optimizer.cc:672-743
+//
+// The whole Levenberg-Marquardt control flow lives in a device-resident BaState per window, so
+// an LM trial is a fixed sequence of launches ("slot") with no host round trip; kernels of a
+// finished window exit at once.  blockIdx.y is the window of a batch.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "ba_types.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ---- small fp64 helpers (same formulas as Eigen / g2o) ---------------------------------------
+__device__ __forceinline__ void quat_rot(const double* q, const double* v, double* r) {
+    double uvx = 2 * (q[1] * v[2] - q[2] * v[1]), uvy = 2 * (q[2] * v[0] - q[0] * v[2]), uvz = 2 * (q[0] * v[1] - q[1] * v[0]);
+    r[0] = v[0] + q[3] * uvx + (q[1] * uvz - q[2] * uvy);
+    r[1] = v[1] + q[3] * uvy + (q[2] * uvx - q[0] * uvz);
+    r[2] = v[2] + q[3] * uvz + (q[0] * uvy - q[1] * uvx);
+}
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+__device__ void R_to_quat(const double* m, double* q) {
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        double qq[4];
+        qq[i] = 0.5 * t;
+        t = 0.5 / t;
+        qq[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        qq[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        qq[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+    }
+}
+__device__ __forceinline__ void quat_normalize(double* q) {
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+// T <- exp(u) * T   (SE3Quat::exp, g2o/types/se3quat.h:218-253; u = [omega, upsilon])
+__device__ void pose_oplus(double* T, const double* u) {
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+    double R[9], V[9];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 9; ++i) {
+            const double I = (i % 4 == 0 ? 1.0 : 0.0);
+            R[i] = I + a * O[i] + b * O2[i];
+            V[i] = I + b * O[i] + c * O2[i];
+        }
+    }
+    double qe[4], te[3], rt[3], nq[4];
+    R_to_quat(R, qe);
+    quat_normalize(qe);
+    for (int i = 0; i < 3; ++i) te[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+    quat_rot(qe, T + 4, rt);
+    const double* b4 = T;
+    nq[3] = qe[3] * b4[3] - qe[0] * b4[0] - qe[1] * b4[1] - qe[2] * b4[2];
+    nq[0] = qe[3] * b4[0] + qe[0] * b4[3] + qe[1] * b4[2] - qe[2] * b4[1];
+    nq[1] = qe[3] * b4[1] + qe[1] * b4[3] + qe[2] * b4[0] - qe[0] * b4[2];
+    nq[2] = qe[3] * b4[2] + qe[2] * b4[3] + qe[0] * b4[1] - qe[1] * b4[0];
+    quat_normalize(nq);
+    T[0] = nq[0]; T[1] = nq[1]; T[2] = nq[2]; T[3] = nq[3];
+    T[4] = te[0] + rt[0]; T[5] = te[1] + rt[1]; T[6] = te[2] + rt[2];
+}
+
+// value of lane `l` (compile-time constant) as a wave-uniform scalar: v_readlane_b32 x2, no LDS
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// deterministic block sum for 256-thread blocks; result valid in thread 0
+__device__ double block_sum_256(double v, double* sh /*[4]*/) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+// ---- per-edge geometry -----------------------------------------------------------------------
+struct EdgeGeom { double err0, err1, chi2, x, y, z; };
+
+__device__ __forceinline__ EdgeGeom edge_eval(const BaWin& W, int e) {
+    const int kf = W.e_kf[e], pt = W.e_pt[e];
+    const double* T = W.pose + 7 * kf;
+    double Xc[3];
+    quat_rot(T, W.pt + 3 * pt, Xc);
+    Xc[0] += T[4]; Xc[1] += T[5]; Xc[2] += T[6];
+    const double* in = W.intr + 4 * kf;
+    EdgeGeom g;
+    g.x = Xc[0]; g.y = Xc[1]; g.z = Xc[2];
+    g.err0 = W.e_uv[2 * e] - (Xc[0] / Xc[2] * in[0] + in[2]);
+    g.err1 = W.e_uv[2 * e + 1] - (Xc[1] / Xc[2] * in[1] + in[3]);
+    const double w = W.e_w[e];
+    g.chi2 = g.err0 * w * g.err0 + g.err1 * w * g.err1;
+    return g;
+}
+
+// ---- S1: Jacobians + weights of every active edge --------------------------------------------
+__global__ __launch_bounds__(256) void k_linearize(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done || !st->need_linearize) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e == 0 && st->it == 0) st->maxdiag_bits = 0ull;
+    if (e >= W.n_edge || !W.e_active[e]) return;
+    const EdgeGeom g = edge_eval(W, e);
+    const int kf = W.e_kf[e];
+    const double* in = W.intr + 4 * kf;
+    const double fx = in[0], fy = in[1];
+    double R[9];
+    quat_to_R(W.pose + 7 * kf, R);
+    const double x = g.x, y = g.y, z = g.z, z_2 = z * z;
+    const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+    double* J = W.e_jac + 21 * (size_t)e;
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c)
+            J[3 * r + c] = -1. / z * (tmp[3 * r] * R[c] + tmp[3 * r + 1] * R[3 + c] + tmp[3 * r + 2] * R[6 + c]);
+    J[6] = x * y / z_2 * fx; J[7] = -(1 + (x * x / z_2)) * fx; J[8] = y / z * fx;
+    J[9] = -1. / z * fx; J[10] = 0; J[11] = x / z_2 * fx;
+    J[12] = (1 + y * y / z_2) * fy; J[13] = -x * y / z_2 * fy; J[14] = -x / z * fy;
+    J[15] = 0; J[16] = -1. / z * fy; J[17] = y / z_2 * fy;
+    const double dsqr = W.huber_delta * W.huber_delta;
+    double rho1 = 1.0;
+    if (st->robust && g.chi2 > dsqr) rho1 = W.huber_delta / sqrt(g.chi2);
+    const double w = W.e_w[e];
+    J[18] = rho1 * w;                 // weightedOmega
+    J[19] = -w * g.err0 * rho1;       // omega_r
+    J[20] = -w * g.err1 * rho1;
+}
+
+__device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v) {
+    atomicMax(p, (unsigned long long)__double_as_longlong(fabs(v)));
+}
+
+// ---- S2: landmark blocks Hll, bl (thread per point, fixed edge order) ---------------------------
+__global__ __launch_bounds__(256) void k_point_reduce(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done || !st->need_linearize) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= W.n_pt) return;
+    double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int i = W.pt_ptr[p]; i < W.pt_ptr[p + 1]; ++i) {
+        const int e = W.pt_edges[i];
+        if (!W.e_active[e]) continue;
+        const double* J = W.e_jac + 21 * (size_t)e;
+        const double wO = J[18], r0 = J[19], r1 = J[20];
+        b[0] += J[0] * r0 + J[3] * r1; b[1] += J[1] * r0 + J[4] * r1; b[2] += J[2] * r0 + J[5] * r1;
+        h[0] += (J[0] * J[0] + J[3] * J[3]) * wO; h[1] += (J[0] * J[1] + J[3] * J[4]) * wO; h[2] += (J[0] * J[2] + J[3] * J[5]) * wO;
+        h[3] += (J[1] * J[1] + J[4] * J[4]) * wO; h[4] += (J[1] * J[2] + J[4] * J[5]) * wO; h[5] += (J[2] * J[2] + J[5] * J[5]) * wO;
+    }
+    for (int i = 0; i < 6; ++i) W.Hll[6 * (size_t)p + i] = h[i];
+    for (int i = 0; i < 3; ++i) W.bl[3 * (size_t)p + i] = b[i];
+    if (st->it == 0) {
+        double m = fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5])));
+        atomic_max_bits(&st->maxdiag_bits, m);
+    }
+}
+
+// ---- S3: pose blocks Hpp, bp (one wavefront per keyframe, lane-strided + shuffle tree) ----------
+__global__ __launch_bounds__(64) void k_pose_reduce(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done || !st->need_linearize) return;
+    const int kf = blockIdx.x;
+    if (kf >= W.n_kf) return;
+    const int col = W.pose_col[kf];
+    if (col < 0) return;
+    double h[21], b[6];
+    for (int i = 0; i < 21; ++i) h[i] = 0;
+    for (int i = 0; i < 6; ++i) b[i] = 0;
+    for (int i = W.kf_ptr[kf] + (int)threadIdx.x; i < W.kf_ptr[kf + 1]; i += 64) {
+        const int e = W.kf_edges[i];
+        if (!W.e_active[e]) continue;
+        const double* J = W.e_jac + 21 * (size_t)e;
+        const double wO = J[18], r0 = J[19], r1 = J[20];
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            b[a] += J[6 + a] * r0 + J[12 + a] * r1;
+#pragma unroll
+            for (int c = a; c < 6; ++c) h[k++] += (J[6 + a] * J[6 + c] + J[12 + a] * J[12 + c]) * wO;
+        }
+    }
+    for (int i = 0; i < 21; ++i) h[i] = wave_sum(h[i]);
+    for (int i = 0; i < 6; ++i) b[i] = wave_sum(b[i]);
+    if (threadIdx.x == 0) {
+        double* H = W.Hpp + 36 * (size_t)col;
+        int k = 0;
+        double m = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int c = a; c < 6; ++c) { H[6 * a + c] = h[k]; H[6 * c + a] = h[k]; if (a == c) m = fmax(m, fabs(h[k])); ++k; }
+        for (int a = 0; a < 6; ++a) W.bp[6 * (size_t)col + a] = b[a];
+        if (st->it == 0) atomic_max_bits(&st->maxdiag_bits, m);
+    }
+}
+
+// ---- S4: iteration bookkeeping (one thread per window) -----------------------------------------
+__global__ void k_iter_begin(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (threadIdx.x != 0 || st->done || !st->need_linearize) return;
+    if (st->it == 0) {  // computeLambdaInit: tau * max |H_jj|
+        st->lambda = 1e-5 * __longlong_as_double((long long)st->maxdiag_bits);
+        st->ni = 2;
+        st->nBad = 0;
+    }
+    st->iniChi = st->currentChi;
+    st->qmax = 0;
+    st->need_linearize = 0;
+}
+
+// ---- S5: damped landmark blocks, Dinv, and the two dense operands of the Schur product ----------
+__device__ __forceinline__ void hpl_of(const double* J, double* H /*6x3*/) {
+    const double wO = J[18];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) H[3 * i + j] = (J[6 + i] * J[j] + J[12 + i] * J[3 + j]) * wO;
+}
+
+__global__ __launch_bounds__(128) void k_prepare(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done) return;
+    const int p = blockIdx.x * 128 + threadIdx.x;
+    if (p >= W.n_pt) return;
+    const double lambda = st->lambda;
+    const double* h = W.Hll + 6 * (size_t)p;
+    const double a = h[0] + lambda, b = h[1], c = h[2], d = h[3] + lambda, e_ = h[4], f = h[5] + lambda;
+    // symmetric 3x3 inverse by cofactors
+    const double c0 = d * f - e_ * e_, c1 = e_ * c - b * f, c2 = b * e_ - d * c;
+    const double det = a * c0 + b * c1 + c * c2;
+    const double id = 1.0 / det;
+    double Di[6];
+    Di[0] = c0 * id; Di[1] = c1 * id; Di[2] = c2 * id;
+    Di[3] = (a * f - c * c) * id; Di[4] = (b * c - a * e_) * id; Di[5] = (a * d - b * b) * id;
+    for (int i = 0; i < 6; ++i) W.Dinv[6 * (size_t)p + i] = Di[i];
+    const double* bl = W.bl + 3 * (size_t)p;
+    const size_t K = (size_t)W.Kpad;
+    for (int j = 0; j < 3; ++j) W.GB[(size_t)W.nS * K + 3 * (size_t)p + j] = bl[j];
+    for (int i = W.pt_ptr[p]; i < W.pt_ptr[p + 1]; ++i) {
+        const int e = W.pt_edges[i];
+        if (!W.e_active[e]) continue;
+        const int col = W.pose_col[W.e_kf[e]];
+        if (col < 0) continue;
+        double H[18];
+        hpl_of(W.e_jac + 21 * (size_t)e, H);
+        for (int r = 0; r < 6; ++r) {
+            const double h0 = H[3 * r], h1 = H[3 * r + 1], h2 = H[3 * r + 2];
+            const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)p;
+            W.GB[o] = h0; W.GB[o + 1] = h1; W.GB[o + 2] = h2;
+            W.GA[o] = h0 * Di[0] + h1 * Di[1] + h2 * Di[2];
+            W.GA[o + 1] = h0 * Di[1] + h1 * Di[3] + h2 * Di[4];
+            W.GA[o + 2] = h0 * Di[2] + h1 * Di[4] + h2 * Di[5];
+        }
+    }
+}
+
+// ---- S6: split-K dense product  part[s] = GA[:, ks] * GB[:, ks]^T  on fp64 MFMA ------------------
+// Workgroup = 4 wavefronts, one 64x64 macro tile (I <= J) of one k split.  Wave w owns rows
+// 16w..16w+15 and all four 16-wide column tiles (4 x double4 accumulators).  Slabs of 64 rows x
+// 32 k of both operands are staged in LDS (pitch 34 doubles: conflict-free ds_read_b64 for the
+// MFMA operand pattern lane -> [row = lane&15][k = lane>>4]).
+#define LDS_PITCH 34
+
+__global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.z];
+    if (W.st->done) return;
+    const int T = W.Npad / BA_TILE;
+    // blockIdx.x enumerates upper-triangular macro tiles
+    int I = 0, rem = blockIdx.x;
+    while (I < T && rem >= T - I) { rem -= T - I; ++I; }
+    const int J = I + rem;
+    if (I >= T) return;
+    const int s = blockIdx.y;
+    const int kchunk = W.Kpad / BA_SPLITS;
+    const int k0 = s * kchunk;
+    __shared__ double As[BA_TILE * LDS_PITCH];
+    __shared__ double Bs[BA_TILE * LDS_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t K = (size_t)W.Kpad;
+    const double* A = W.GA + (size_t)(I * BA_TILE) * K;
+    const double* B = W.GB + (size_t)(J * BA_TILE) * K;
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0, 0, 0, 0};
+    for (int kk = k0; kk < k0 + kchunk; kk += BA_KC) {
+        __syncthreads();
+        for (int i = tid; i < BA_TILE * BA_KC; i += 256) {
+            const int r = i >> 5, c = i & 31;
+            As[r * LDS_PITCH + c] = A[(size_t)r * K + kk + c];
+            Bs[r * LDS_PITCH + c] = B[(size_t)r * K + kk + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BA_KC; ks += 4) {
+            const double a = As[(16 * wv + (lane & 15)) * LDS_PITCH + ks + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double b = Bs[(16 * j + (lane & 15)) * LDS_PITCH + ks + (lane >> 4)];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double* P = W.part + (size_t)s * W.Npad * W.Npad;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = I * BA_TILE + 16 * wv + (lane >> 4) + 4 * r;
+            const int col = J * BA_TILE + 16 * j + (lane & 15);
+            P[(size_t)row * W.Npad + col] = acc[j][r];
+        }
+}
+
+// ---- S7: S = Hpp + lambda*I - sum_s part[s],  b_s = bp - coeff --------------------------------------
+__global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done) return;
+    const int n = W.nS, N = W.Npad;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int r = idx / N, c = idx - r * N;
+    if (r >= n || c > n || c < r) return;
+    double v = 0;
+    for (int s = 0; s < BA_SPLITS; ++s) v += W.part[(size_t)s * N * N + (size_t)r * N + c];
+    if (c == n) {
+        W.rhs[r] = W.bp[r] - v;  // _bschur = _b - coefficients
+        return;
+    }
+    double hv = 0;
+    if (r / 6 == c / 6) {
+        hv = W.Hpp[36 * (size_t)(r / 6) + 6 * (r % 6) + (c % 6)];
+        if (r == c) hv += st->lambda;
+    }
+    const double sv = hv - v;
+    W.S[(size_t)r * N + c] = sv;
+    W.S[(size_t)c * N + r] = sv;
+}
+
+// ---- S8: dense blocked LDLt (no pivoting) of the reduced system + solve, one workgroup -------------
+// In place on the lower triangle of S (row-major, pitch Npad).  The right-hand side rides along as
+// row n of the matrix, so the forward substitution is part of the factorisation: after the last
+// panel, row n holds y = D^-1 L^-1 b; a blocked backward substitution with L^T finishes.
+// Per 32-column panel: (1) diagonal block + panel rows are staged in LDS with coalesced loads,
+// (2) wavefront 0 factors the diagonal block (one (r,c) pair per lane per step, pair table in LDS),
+// (3) every row below solves its 32 entries out of LDS, (4) the trailing matrix takes the rank-32
+// update A22 -= (L21 D) D^-1 (L21 D)^T on v_mfma_f64_16x16x4_f64, 16x16 tiles spread over 8 waves.
+// A pivot that is exactly zero fails the solve like SimplicialLDLT's NumericalIssue.
+#define LD_NB 32
+#define LD_P (LD_NB + 1)
+#define LD_THREADS 512
+#define LD_PAIRS (LD_NB * (LD_NB - 1) / 2)
+
+__global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done) return;
+    const int n = W.nS, N = W.Npad;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    extern __shared__ double sm[];
+    double* Dg = sm;                      // LD_NB x LD_P: diagonal block (unit L below, D on the diagonal)
+    double* Wd = Dg + LD_NB * LD_P;       // (rows below + rhs row, padded to 16) x LD_P: L21 * D
+    __shared__ int s_fail;
+    __shared__ double s_invd[LD_NB];
+    __shared__ unsigned char s_pr[LD_PAIRS], s_pc[LD_PAIRS];
+    __shared__ short s_off[LD_NB + 1];
+    if (tid == 0) {
+        s_fail = 0;
+        int p = 0;
+        for (int c = 1; c < LD_NB; ++c) {   // pairs (r, c), 1 <= c <= r < 32, ordered by c
+            s_off[c] = (short)p;
+            for (int r = c; r < LD_NB; ++r) { s_pr[p] = (unsigned char)r; s_pc[p] = (unsigned char)c; ++p; }
+        }
+        s_off[LD_NB] = (short)p;
+    }
+    if (n == 0) { if (tid == 0) st->ok2 = 1; return; }
+    double* S = W.S;
+    for (int i = tid; i < n; i += LD_THREADS) S[(size_t)n * N + i] = W.rhs[i];  // rhs as row n
+    __syncthreads();
+    for (int jb = 0; jb < n; jb += LD_NB) {
+        const int nb = min(LD_NB, n - jb);
+        const int base = jb + nb;
+        const int below = n - base;          // matrix rows under the panel
+        const int rows = below + 1;          // + the rhs row
+        const int rows16 = (rows + 15) & ~15;
+        for (int i = tid; i < nb * LD_NB; i += LD_THREADS) {
+            const int r = i >> 5, c = i & 31;
+            if (c < nb) Dg[r * LD_P + c] = S[(size_t)(jb + r) * N + jb + c];
+        }
+        if (nb < LD_NB)
+            for (int i = tid; i < LD_NB * LD_NB; i += LD_THREADS) {
+                const int r = i >> 5, c = i & 31;
+                if (r >= nb || c >= nb) Dg[r * LD_P + c] = 0.0;
+            }
+        for (int i = tid; i < rows16 * LD_NB; i += LD_THREADS) {
+            const int r = i >> 5, c = i & 31;
+            Wd[r * LD_P + c] = (r < rows && c < nb) ? S[(size_t)(base + r) * N + jb + c] : 0.0;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            // factor the diagonal block with lane r holding row r in registers: at step k the pivot
+            // and the column entries a[c][k] of the other rows arrive by cross-lane shuffles.
+            // Rows/cols >= nb are padded with the identity.
+            const int r = lane & 31;
+            double row[LD_NB];
+#pragma unroll
+            for (int c = 0; c < LD_NB; ++c) row[c] = (r < nb && c < nb) ? Dg[r * LD_P + c] : (r == c ? 1.0 : 0.0);
+            int fail = 0;
+#pragma unroll
+            for (int k = 0; k < LD_NB; ++k) {
+                const double d = readlane_d(row[k], k);
+                const bool bad = (d == 0.0 || !(fabs(d) <= DBL_MAX));
+                fail |= bad;
+                const double invd = bad ? 0.0 : 1.0 / d;
+                const double lrk = row[k] * invd;          // L[r][k] (meaningful for r > k)
+#pragma unroll
+                for (int c = k + 1; c < LD_NB; ++c) {
+                    const double ack = readlane_d(row[k], c);   // a[c][k], unscaled
+                    if (r >= c) row[c] -= lrk * ack;
+                }
+                if (r > k) row[k] = lrk;
+                if (lane == 0) s_invd[k] = (k < nb) ? invd : 0.0;
+            }
+            if (lane < 32 && r < nb) {
+#pragma unroll
+                for (int c = 0; c < LD_NB; ++c) if (c < nb) Dg[r * LD_P + c] = row[c];
+            }
+            if (lane == 0 && fail) s_fail = 1;
+        }
+        __syncthreads();
+        if (s_fail) break;
+        // rows below (and the rhs row): w_k = a_k - sum_{m<k} w_m L11[k][m]   (w = L*d), row in registers
+        for (int r = tid; r < rows; r += LD_THREADS) {
+            double* wrow = Wd + r * LD_P;
+            double w[LD_NB];
+#pragma unroll
+            for (int k = 0; k < LD_NB; ++k) w[k] = wrow[k];
+#pragma unroll
+            for (int k = 1; k < LD_NB; ++k) {
+                double a = w[k];
+#pragma unroll
+                for (int m = 0; m < k; ++m) a -= w[m] * Dg[k * LD_P + m];
+                w[k] = a;
+                __builtin_amdgcn_sched_barrier(0);  // keep the 496 LDS reads from being hoisted (spills)
+            }
+#pragma unroll
+            for (int k = 1; k < LD_NB; ++k) wrow[k] = w[k];
+        }
+        __syncthreads();
+        // write back the factored panel: L11 / D, and L21 = (L*d) / d
+        for (int i = tid; i < nb * LD_NB; i += LD_THREADS) {
+            const int r = i >> 5, c = i & 31;
+            if (c <= r) S[(size_t)(jb + r) * N + jb + c] = Dg[r * LD_P + c];
+        }
+        for (int i = tid; i < rows * LD_NB; i += LD_THREADS) {
+            const int r = i >> 5, c = i & 31;
+            if (c < nb) S[(size_t)(base + r) * N + jb + c] = Wd[r * LD_P + c] * s_invd[c];
+        }
+        // trailing update on MFMA: C[r][c] -= sum_k (w[r][k] invd[k]) w[c][k],  c <= r
+        const int RT = rows16 >> 4, CT = (below + 15) >> 4;
+        // lower-triangular tile list: t -> (rt, ct), ct <= min(rt, CT-1); waves take 4 tiles at a time
+        int ntile = 0;
+        for (int rt = 0; rt < RT; ++rt) ntile += min(rt + 1, CT);
+        for (int t0 = 4 * wv; t0 < ntile; t0 += 4 * (LD_THREADS / 64)) {
+            double4_t acc[4];
+            int trt[4], tct[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int t = t0 + q, rt = 0;
+                if (t >= ntile) { trt[q] = -1; tct[q] = 0; acc[q] = (double4_t){0, 0, 0, 0}; continue; }
+                while (t >= min(rt + 1, CT)) { t -= min(rt + 1, CT); ++rt; }
+                trt[q] = rt; tct[q] = t;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = 16 * rt + (lane >> 4) + 4 * g, c = 16 * t + (lane & 15);
+                    acc[q][g] = (r < rows && c < below && c <= r) ? S[(size_t)(base + r) * N + base + c] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rt = trt[q] < 0 ? 0 : trt[q], ct = tct[q];
+#pragma unroll
+                for (int ks = 0; ks < LD_NB; ks += 4) {
+                    const int kk = ks + (lane >> 4);
+                    const double a = -Wd[(16 * rt + (lane & 15)) * LD_P + kk] * s_invd[kk];
+                    const double b = Wd[(16 * ct + (lane & 15)) * LD_P + kk];
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (trt[q] < 0) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = 16 * trt[q] + (lane >> 4) + 4 * g, c = 16 * tct[q] + (lane & 15);
+                    if (r < rows && c < below && c <= r) S[(size_t)(base + r) * N + base + c] = acc[q][g];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (s_fail) {
+        if (tid == 0) st->ok2 = 0;
+        return;
+    }
+    // ---- backward substitution x = L^-T y, y = row n of S ----
+    double* xs = Wd;                 // n doubles
+    double* red = Wd + N;            // 16 x 32 partial sums
+    for (int i = tid; i < n; i += LD_THREADS) xs[i] = S[(size_t)n * N + i];
+    __syncthreads();
+    for (int jb = ((n - 1) / LD_NB) * LD_NB; jb >= 0; jb -= LD_NB) {
+        const int nb = min(LD_NB, n - jb);
+        {
+            const int k = tid & (LD_NB - 1), part = tid >> 5;
+            double acc = 0;
+            if (k < nb)
+                for (int r = jb + nb + part; r < n; r += LD_THREADS / LD_NB) acc += S[(size_t)r * N + jb + k] * xs[r];
+            red[part * LD_NB + k] = acc;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const int k = lane;
+            double v = 0;
+            double col[LD_NB];
+            if (k < nb) {
+                double t = 0;
+                for (int p2 = 0; p2 < LD_THREADS / LD_NB; ++p2) t += red[p2 * LD_NB + k];
+                v = xs[jb + k] - t;
+            }
+#pragma unroll
+            for (int m = 0; m < LD_NB; ++m) col[m] = (k < nb && m < nb && m > k) ? S[(size_t)(jb + m) * N + jb + k] : 0.0;
+#pragma unroll
+            for (int m = LD_NB - 1; m >= 0; --m) {
+                const double xm = readlane_d(v, m);   // final once every higher index has been applied
+                if (m < nb && k < m) v -= col[m] * xm;
+            }
+            if (k < nb) xs[jb + k] = v;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += LD_THREADS) W.rhs[i] = xs[i];
+    if (tid == 0) st->ok2 = 1;
+}
+
+// ---- S9: landmark back-substitution, push(), oplus ------------------------------------------------
+__global__ __launch_bounds__(256) void k_backsub_update(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done) return;
+    __shared__ double sh[4];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = st->ok2 != 0;
+    const double lambda = st->lambda;
+    double scale = 0;
+    if (p < W.n_pt) {
+        const double* bl = W.bl + 3 * (size_t)p;
+        double cl[3] = {bl[0], bl[1], bl[2]};
+        double xl[3] = {0, 0, 0};
+        if (ok) {
+            for (int i = W.pt_ptr[p]; i < W.pt_ptr[p + 1]; ++i) {
+                const int e = W.pt_edges[i];
+                if (!W.e_active[e]) continue;
+                const int col = W.pose_col[W.e_kf[e]];
+                if (col < 0) continue;
+                double H[18];
+                hpl_of(W.e_jac + 21 * (size_t)e, H);
+                const double* xp = W.rhs + 6 * col;
+                for (int j = 0; j < 3; ++j)
+                    for (int r = 0; r < 6; ++r) cl[j] -= H[3 * r + j] * xp[r];
+            }
+            const double* Di = W.Dinv + 6 * (size_t)p;
+            xl[0] = Di[0] * cl[0] + Di[1] * cl[1] + Di[2] * cl[2];
+            xl[1] = Di[1] * cl[0] + Di[3] * cl[1] + Di[4] * cl[2];
+            xl[2] = Di[2] * cl[0] + Di[4] * cl[1] + Di[5] * cl[2];
+        }
+        for (int j = 0; j < 3; ++j) {
+            W.x_l[3 * (size_t)p + j] = xl[j];
+            scale += xl[j] * (lambda * xl[j] + bl[j]);
+            const double v = W.pt[3 * (size_t)p + j];
+            W.pt_bak[3 * (size_t)p + j] = v;
+            W.pt[3 * (size_t)p + j] = v + xl[j];
+        }
+    }
+    if (p < W.n_kf) {
+        double T[7];
+        for (int i = 0; i < 7; ++i) { T[i] = W.pose[7 * (size_t)p + i]; W.pose_bak[7 * (size_t)p + i] = T[i]; }
+        const int col = W.pose_col[p];
+        if (col >= 0 && ok) {
+            pose_oplus(T, W.rhs + 6 * col);
+            for (int i = 0; i < 7; ++i) W.pose[7 * (size_t)p + i] = T[i];
+        }
+    }
+    const double tot = block_sum_256(scale, sh);
+    if (threadIdx.x == 0) W.scale_part[blockIdx.x] = tot;
+}
+
+// ---- S10: residuals at the tentative state, robust cost partial sums ------------------------------------
+__global__ __launch_bounds__(256) void k_errors(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done) return;
+    __shared__ double sh[4];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double rho = 0;
+    if (e < W.n_edge && W.e_active[e]) {
+        const EdgeGeom g = edge_eval(W, e);
+        W.e_chi2[e] = g.chi2;
+        const double dsqr = W.huber_delta * W.huber_delta;
+        if (st->robust && g.chi2 > dsqr) rho = 2 * sqrt(g.chi2) * W.huber_delta - dsqr;
+        else rho = g.chi2;
+    }
+    const double tot = block_sum_256(rho, sh);
+    if (threadIdx.x == 0) W.chi_part[blockIdx.x] = tot;
+}
+
+__device__ double sum_parts(const double* part, int n, double* sh) {
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += part[i];
+    return block_sum_256(v, sh);
+}
+
+// ---- S11: accept / reject, lambda update, stop rules (one workgroup per window) ----------------------------
+__global__ __launch_bounds__(256) void k_decide(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done) return;
+    __shared__ double sh[4];
+    __shared__ int s_reject;
+    const int tid = threadIdx.x;
+    const int ne_blocks = (W.n_edge + 255) / 256, np_blocks = (W.n_pt + 255) / 256;
+    double tempChi = sum_parts(W.chi_part, ne_blocks, sh);
+    double scale = sum_parts(W.scale_part, np_blocks, sh);
+    double ps = 0;
+    for (int i = tid; i < W.nS; i += 256) { const double x = st->ok2 ? W.rhs[i] : 0.0; ps += x * (st->lambda * x + W.bp[i]); }
+    scale += block_sum_256(ps, sh);
+    if (tid == 0) {
+        if (!st->ok2) tempChi = DBL_MAX;
+        st->tempChi = tempChi;
+        double rho = (st->currentChi - tempChi) / (scale + 1e-3);
+        const bool good = rho > 0 && fabs(tempChi) <= DBL_MAX;
+        if (good) {
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            const double sf = fmax(1. / 3., alpha);
+            st->lambda *= sf;
+            st->ni = 2;
+            st->currentChi = tempChi;
+        } else {
+            st->lambda *= st->ni;
+            st->ni *= 2;
+        }
+        s_reject = !good;
+        st->qmax += 1;
+        const bool again = rho < 0 && st->qmax < 10;
+        if (!again) {  // the iteration is over
+            const int s = st->stage, it = st->it;
+            if (it < BA_MAX_ITS) { st->chi2[s][it] = tempChi; st->lam[s][it] = st->lambda; st->trials[s][it] = st->qmax; }
+            st->n_its[s] = it + 1;
+            bool terminate = st->qmax == 10 || rho == 0;
+            if (!terminate) {
+                if ((st->iniChi - st->currentChi) * 1e3 < st->iniChi) st->nBad += 1; else st->nBad = 0;
+                if (st->nBad >= 3) terminate = true;
+            }
+            st->it = it + 1;
+            st->need_linearize = 1;
+            if (terminate || st->it >= st->max_it) st->done = 1;
+        }
+    }
+    __syncthreads();
+    if (s_reject) {  // pop(): restore the vertices
+        for (int i = tid; i < 3 * W.n_pt; i += 256) W.pt[i] = W.pt_bak[i];
+        for (int i = tid; i < 7 * W.n_kf; i += 256) W.pose[i] = W.pose_bak[i];
+    }
+}
+
+// ---- stage control ---------------------------------------------------------------------------------------
+// gate between the stages (Optimizer.cc:672-686): chi2 > gate || depth <= 0 -> level 1; kernels off
+__global__ __launch_bounds__(256) void k_gate(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= W.n_edge) return;
+    const EdgeGeom g = edge_eval(W, e);
+    const bool out = W.e_chi2[e] > W.chi2_gate || !(g.z > 0.0);
+    W.e_out1[e] = out;
+    if (out) W.e_active[e] = 0;
+}
+
+// stage entry: counts the active edges; the following k_errors + k_stage_begin2 set the start cost
+__global__ __launch_bounds__(256) void k_stage_begin(BaWin* wins, int stage, int max_it, int robust) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int c = 0;
+    for (int e = threadIdx.x; e < W.n_edge; e += 256) c += W.e_active[e] != 0;
+    if (c) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->stage = stage; st->max_it = max_it; st->robust = robust;
+        st->it = 0; st->qmax = 0; st->nBad = 0; st->need_linearize = 1; st->ok2 = 1;
+        st->n_active = cnt;
+        st->n_its[stage] = 0;
+        st->lambda = -1; st->ni = 2;
+        st->done = (cnt == 0 || max_it <= 0) ? 1 : 0;  // "0 vertices to optimize" / no iterations
+    }
+}
+__global__ __launch_bounds__(256) void k_stage_begin2(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done) return;
+    __shared__ double sh[4];
+    const double chi = sum_parts(W.chi_part, (W.n_edge + 255) / 256, sh);
+    if (threadIdx.x == 0) { st->currentChi = chi; st->chi2_init[st->stage] = chi; }
+}
+
+// final erasure test on every edge (Optimizer.cc:715-728) and pose export as R|t
+__global__ __launch_bounds__(256) void k_final(BaWin* wins, double* const* out_pose, uint8_t* const* out_flag) {
+    const BaWin& W = wins[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < W.n_edge) {
+        const EdgeGeom g = edge_eval(W, e);
+        out_flag[blockIdx.y][e] = W.e_chi2[e] > W.chi2_gate || !(g.z > 0.0);
+    }
+    if (e < W.n_kf) {
+        double R[9];
+        quat_to_R(W.pose + 7 * (size_t)e, R);
+        double* o = out_pose[blockIdx.y] + 12 * (size_t)e;
+        for (int i = 0; i < 9; ++i) o[i] = R[i];
+        for (int i = 0; i < 3; ++i) o[9 + i] = W.pose[7 * (size_t)e + 4 + i];
+    }
+}
+
+// input poses R|t -> normalised quaternion (Converter::toSE3Quat -> SE3Quat(R,t))
+__global__ void k_import_poses(BaWin* wins, const double* const* in_pose) {
+    const BaWin& W = wins[blockIdx.y];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= W.n_kf) return;
+    const double* p = in_pose[blockIdx.y] + 12 * (size_t)k;
+    double R[9], q[4];
+    for (int i = 0; i < 9; ++i) R[i] = p[i];
+    R_to_quat(R, q);
+    quat_normalize(q);
+    double* T = W.pose + 7 * (size_t)k;
+    T[0] = q[0]; T[1] = q[1]; T[2] = q[2]; T[3] = q[3]; T[4] = p[9]; T[5] = p[10]; T[6] = p[11];
+}
+
+// ---- launch wrappers -----------------------------------------------------------------------------------------
+size_t bak_ldlt_smem(int Npad) { return sizeof(double) * ((size_t)LD_NB * LD_P + ((size_t)Npad + 16) * LD_P); }
+
+hipError_t bak_prepare(int Npad) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bak_ldlt_smem(Npad));
+}
+
+void bak_import(hipStream_t st, BaWin* wins, const double* const* in_pose, int max_kf, int nwin) {
+    hipLaunchKernelGGL(k_import_poses, dim3((max_kf + 63) / 64, nwin), dim3(64), 0, st, wins, in_pose);
+}
+
+void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int stage, int max_it, int robust, bool gate) {
+    const dim3 ge((max_edge + 255) / 256, nwin);
+    if (gate) hipLaunchKernelGGL(k_gate, ge, dim3(256), 0, st, wins);
+    hipLaunchKernelGGL(k_stage_begin, dim3(1, nwin), dim3(256), 0, st, wins, stage, max_it, robust);
+    hipLaunchKernelGGL(k_errors, ge, dim3(256), 0, st, wins);
+    hipLaunchKernelGGL(k_stage_begin2, dim3(1, nwin), dim3(256), 0, st, wins);
+}
+
+// one LM trial slot for every window of the batch
+void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad) {
+    const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt + 255) / 256, nwin);
+    hipLaunchKernelGGL(k_linearize, ge, dim3(256), 0, st, wins);
+    hipLaunchKernelGGL(k_point_reduce, gp, dim3(256), 0, st, wins);
+    hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(64), 0, st, wins);
+    hipLaunchKernelGGL(k_iter_begin, dim3(1, nwin), dim3(64), 0, st, wins);
+    hipLaunchKernelGGL(k_prepare, dim3((max_pt + 127) / 128, nwin), dim3(128), 0, st, wins);
+    const int T = Npad / BA_TILE;
+    hipLaunchKernelGGL(k_schur, dim3(T * (T + 1) / 2, BA_SPLITS, nwin), dim3(256), 0, st, wins);
+    hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins);
+    hipLaunchKernelGGL(k_ldlt_solve, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);
+    const int nb = (max_pt > max_kf ? max_pt : max_kf);
+    hipLaunchKernelGGL(k_backsub_update, dim3((nb + 255) / 256, nwin), dim3(256), 0, st, wins);
+    hipLaunchKernelGGL(k_errors, ge, dim3(256), 0, st, wins);
+    hipLaunchKernelGGL(k_decide, dim3(1, nwin), dim3(256), 0, st, wins);
+}
+
+void bak_final(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_edge, double* const* out_pose,
+               uint8_t* const* out_flag) {
+    const int nb = max_edge > max_kf ? max_edge : max_kf;
+    hipLaunchKernelGGL(k_final, dim3((nb + 255) / 256, nwin), dim3(256), 0, st, wins, out_pose, out_flag);
+}

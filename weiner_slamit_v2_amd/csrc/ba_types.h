@@ -1,0 +1,79 @@
+// ba_types.h — host/device shared layout of one local-BA window in HBM.
+#ifndef SLAMIT_BA_TYPES_H
+#define SLAMIT_BA_TYPES_H
+
+#include <stdint.h>
+
+#define BA_MAX_ITS 32       // == SLAMIT_BA_MAX_ITS
+#define BA_TILE 64          // Schur macro tile (rows/cols of S per workgroup)
+#define BA_KC 32            // k-depth of one staged slab
+#define BA_SPLITS 16        // split-K factor of the Schur GEMM
+
+// LM control block of one window (device resident; the host only reads it back between chunks
+// of enqueued trial slots).  Mirrors the locals of OptimizationAlgorithmLevenberg::solve
+// (g2o/core/optimization_algorithm_levenberg.cpp:61-164).
+struct BaState {
+    int32_t done;            // stage finished (iterations exhausted / Terminate / nothing active)
+    int32_t need_linearize;  // next slot starts a new iteration: Jacobians + normal equations
+    int32_t it;              // iteration index inside the stage
+    int32_t max_it;
+    int32_t qmax;            // LM trials used so far in this iteration
+    int32_t nBad;
+    int32_t robust;          // Huber kernel on (stage 1) / off (stage 2)
+    int32_t ok2;             // last factorisation succeeded
+    int32_t n_active;        // active edges of the stage
+    int32_t stage;
+    double lambda, ni;
+    double currentChi, iniChi, tempChi;
+    unsigned long long maxdiag_bits;  // max |H_jj| as ordered bits (non-negative doubles)
+    // per-stage statistics (slamit_ba_stats)
+    int32_t n_its[2];
+    double chi2[2][BA_MAX_ITS];
+    double lam[2][BA_MAX_ITS];
+    int32_t trials[2][BA_MAX_ITS];
+    double chi2_init[2];
+};
+
+// One window.  All pointers are device addresses inside the handle's slabs.
+struct BaWin {
+    int32_t n_kf, n_pt, n_edge, n_free;
+    int32_t nS;        // 6 * n_free
+    int32_t Npad;      // rows/cols of the padded reduced system, multiple of BA_TILE, >= nS + 1
+    int32_t Kpad;      // padded k extent (3 * n_pt rounded up to BA_KC * BA_SPLITS)
+    int32_t n_part;    // partial-sum slots of the chi2 reduction
+    double huber_delta, chi2_gate;
+    // vertices
+    double* pose;      // n_kf x 7: q(x,y,z,w), t
+    double* pose_bak;
+    double* intr;      // n_kf x 4
+    int32_t* pose_col; // n_kf: column block among free poses or -1
+    double* pt;        // n_pt x 3
+    double* pt_bak;
+    // edges (caller order) + CSR by point and by free pose
+    int32_t* e_kf; int32_t* e_pt;
+    double* e_uv;      // n_edge x 2
+    double* e_w;       // n_edge
+    uint8_t* e_active;
+    uint8_t* e_out1;   // stage-1 outlier flag
+    double* e_chi2;    // chi2 of the last evaluated trial
+    double* e_jac;     // n_edge x 21: A(2x3) B(2x6) wO r0 r1
+    int32_t* pt_ptr; int32_t* pt_edges;     // CSR: edges of each point
+    int32_t* kf_ptr; int32_t* kf_edges;     // CSR: edges of each keyframe
+    // normal equations
+    double* Hll;       // n_pt x 6 (xx xy xz yy yz zz)
+    double* bl;        // n_pt x 3
+    double* Dinv;      // n_pt x 6
+    double* Hpp;       // n_free x 36
+    double* bp;        // n_free x 6
+    double* GA;        // Npad x Kpad : (Hpl * Dinv) scattered, row = pose dof, col = 3*pt + j
+    double* GB;        // Npad x Kpad : Hpl scattered; row nS holds bl
+    double* part;      // BA_SPLITS x Npad x Npad partial products
+    double* S;         // Npad x Npad reduced system (symmetric, full)
+    double* rhs;       // Npad : b_schur in, x_pose out
+    double* x_l;       // n_pt x 3 landmark increments
+    double* chi_part;  // n_part partial robust-cost sums
+    double* scale_part;// n_part partial sums of x(lambda x + b) over landmarks
+    BaState* st;
+};
+
+#endif
