@@ -1,0 +1,100 @@
+// ORBmatcher.cc — see ORBmatcher.h.  Distances and selection run in libslamit_hip.so; the
+// acceptance thresholds and the rotation histogram are host logic as in the reference.
+#include "ORBmatcher.h"
+
+#include <math.h>
+
+#include "../../include/slamit.h"
+
+namespace ORB_SLAM2 {
+
+const int ORBmatcher::TH_HIGH = 100;     // ORBmatcher.cc:37
+const int ORBmatcher::TH_LOW = 50;       // :38
+const int ORBmatcher::HISTO_LENGTH = 30; // :39
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+namespace {
+// descriptor tables may be row-padded cv::Mat views; the C-ABI wants 32-byte rows
+const uint8_t* packed_rows(const cv::Mat& m, std::vector<uint8_t>& tmp) {
+    if (m.rows == 0) return 0;
+    if (m.isContinuous() && m.cols == SLAMIT_DESC_BYTES) return m.ptr<uint8_t>(0);
+    tmp.resize((size_t)m.rows * SLAMIT_DESC_BYTES);
+    for (int r = 0; r < m.rows; ++r) memcpy(&tmp[(size_t)r * SLAMIT_DESC_BYTES], m.ptr<uint8_t>(r), SLAMIT_DESC_BYTES);
+    return tmp.data();
+}
+}  // namespace
+
+int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
+    unsigned short d = 0;
+    if (slamit_hamming_matrix(a.ptr<uint8_t>(0), 1, b.ptr<uint8_t>(0), 1, &d) != SLAMIT_OK) return 256;
+    return d;
+}
+
+bool ORBmatcher::DistanceMatrix(const cv::Mat& query, const cv::Mat& train, std::vector<unsigned short>& dist) {
+    std::vector<uint8_t> tq, tt;
+    dist.assign((size_t)query.rows * train.rows, 0);
+    return slamit_hamming_matrix(packed_rows(query, tq), query.rows, packed_rows(train, tt), train.rows, dist.data()) == SLAMIT_OK;
+}
+
+bool ORBmatcher::BestTwo(const cv::Mat& query, const cv::Mat& train, std::vector<int>& bestIdx,
+                         std::vector<int>& bestDist, std::vector<int>& secondDist) {
+    std::vector<uint8_t> tq, tt;
+    bestIdx.assign(query.rows, -1); bestDist.assign(query.rows, 256); secondDist.assign(query.rows, 256);
+    if (query.rows == 0) return true;
+    return slamit_hamming_best2(packed_rows(query, tq), query.rows, packed_rows(train, tt), train.rows, bestIdx.data(),
+                                bestDist.data(), secondDist.data()) == SLAMIT_OK;
+}
+
+int ORBmatcher::SearchBruteForce(const std::vector<cv::KeyPoint>& keys1, const cv::Mat& desc1,
+                                 const std::vector<cv::KeyPoint>& keys2, const cv::Mat& desc2,
+                                 std::vector<int>& vnMatches12, int th) {
+    if (th < 0) th = TH_LOW;
+    std::vector<int> idx, best, second;
+    vnMatches12.assign(desc1.rows, -1);
+    if (!BestTwo(desc1, desc2, idx, best, second)) return 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int i = 0; i < desc1.rows; ++i) {
+        if (best[i] <= th && (float)best[i] < mfNNratio * (float)second[i]) {
+            vnMatches12[i] = idx[i];
+            ++nmatches;
+            if (mbCheckOrientation && i < (int)keys1.size() && idx[i] < (int)keys2.size()) {
+                float rot = keys1[i].angle - keys2[idx[i]].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(i);
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; ++b) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (size_t j = 0; j < rotHist[b].size(); ++j) {
+                if (vnMatches12[rotHist[b][j]] >= 0) { vnMatches12[rotHist[b][j]] = -1; --nmatches; }
+            }
+        }
+    }
+    return nmatches;
+}
+
+// three most populated bins; the 2nd/3rd are dropped when below 10 % of the first (ORBmatcher.cc:1605-1646)
+void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+    int top[3] = {0, 0, 0};
+    int at[3] = {-1, -1, -1};
+    for (int i = 0; i < L; ++i) {
+        const int s = (int)histo[i].size();
+        int pos = s > top[0] ? 0 : s > top[1] ? 1 : s > top[2] ? 2 : 3;
+        for (int k = 2; k > pos; --k) { top[k] = top[k - 1]; at[k] = at[k - 1]; }
+        if (pos < 3) { top[pos] = s; at[pos] = i; }
+    }
+    if (top[1] < 0.1f * (float)top[0]) { at[1] = -1; at[2] = -1; }
+    else if (top[2] < 0.1f * (float)top[0]) at[2] = -1;
+    ind1 = at[0]; ind2 = at[1]; ind3 = at[2];
+}
+
+}  // namespace ORB_SLAM2

@@ -1,0 +1,203 @@
+// Optimizer.h — ORB_SLAM2::Optimizer::LocalBundleAdjustment backed by libslamit_hip.so.
+//
+// The reference's function (ORB_SLAM2/src/Optimizer.cc:453-778, declared include/Optimizer.h:45)
+// does three things: (1) walks the covisibility graph to pick local keyframes, their map points
+// and the fixed keyframes (:456-504), (2) builds a g2o graph and runs the 5 + 10 iteration
+// schedule (:507-743), (3) erases outlier observations and writes poses / points back under
+// Map::mMutexMapUpdate (:746-777).  Here (1) and (3) are host code written against whatever
+// KeyFrame / MapPoint / Map types the caller has (a template, so LocalMapping.cc:84's call
+//      Optimizer::LocalBundleAdjustment(mpCurrentKeyFrame, &mbAbortBA, mpMap);
+// compiles unchanged against the reference's own classes), and (2) is one slamit_ba_solve call.
+//
+// Members used on the caller's types, all from the reference's headers:
+//   KeyFrame : mnId, mnBALocalForKF, mnBAFixedForKF, GetVectorCovisibleKeyFrames(), isBad(),
+//              GetMapPointMatches(), GetPose(), SetPose(), mvKeysUn, mvuRight, mvInvLevelSigma2,
+//              fx, fy, cx, cy, EraseMapPointMatch(MapPoint*)
+//   MapPoint : mnId, mnBALocalForKF, isBad(), GetObservations(), GetWorldPos(), SetWorldPos(),
+//              UpdateNormalAndDepth(), EraseObservation(KeyFrame*)
+//   Map      : mMutexMapUpdate
+// Stereo observations (mvuRight >= 0, :621-650) are not handled by the HIP path yet; a window that
+// contains one is left untouched and LastStatus() reports SLAMIT_ERR_ARG.
+#ifndef SLAMIT_SHIM_OPTIMIZER_H
+#define SLAMIT_SHIM_OPTIMIZER_H
+
+#include <math.h>
+#include <stdint.h>
+
+#include <list>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#ifdef SLAMIT_USE_OPENCV
+#include <opencv2/core/core.hpp>
+#else
+#include "cvlite.h"
+#endif
+
+#include "../../include/slamit.h"
+
+namespace ORB_SLAM2 {
+
+class Optimizer {
+public:
+    template <class KeyFrameT, class MapT>
+    static void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap);
+
+    // POD form: the window already flattened (what the template above produces).
+    static int LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, const volatile bool* stop, slamit_ba_result& res);
+
+    static int LastStatus() { return lastStatus(); }
+    static void SetDevice(int device) { deviceRef() = device; }
+
+private:
+    static int& lastStatus() { static int s = 0; return s; }
+    static int& deviceRef() { static int d = 0; return d; }
+    static slamit_ba*& handleRef() { static slamit_ba* h = 0; return h; }
+    static int* capRef() { static int c[3] = {0, 0, 0}; return c; }
+    static std::mutex& solveMutex() { static std::mutex m; return m; }
+};
+
+inline int Optimizer::LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, const volatile bool* stop, slamit_ba_result& res) {
+    std::lock_guard<std::mutex> guard(solveMutex());  // one LocalMapping thread in the reference; be safe anyway
+    int* cap = capRef();
+    if (!handleRef() || prob.n_kf > cap[0] || prob.n_pt > cap[1] || prob.n_edge > cap[2]) {
+        slamit_ba_destroy(handleRef());
+        handleRef() = 0;
+        cap[0] = prob.n_kf > 64 ? 2 * prob.n_kf : 64;
+        cap[1] = prob.n_pt > 4096 ? 2 * prob.n_pt : 4096;
+        cap[2] = prob.n_edge > 65536 ? 2 * prob.n_edge : 65536;
+        int rc = slamit_ba_create(cap[0], cap[1], cap[2], 1, deviceRef(), &handleRef());
+        if (rc != SLAMIT_OK) { handleRef() = 0; cap[0] = cap[1] = cap[2] = 0; return lastStatus() = rc; }
+    }
+    slamit_ba_opts o;
+    o.its_robust = 5;                              // Optimizer.cc:660
+    o.its_final = 10;                              // :707
+    o.huber_delta = (double)(float)sqrt(5.991);    // :569 (a float in the reference)
+    o.chi2_gate = 5.991;                           // :680,723
+    o.stop = reinterpret_cast<const volatile uint8_t*>(stop);
+    return lastStatus() = slamit_ba_solve(handleRef(), &prob, &o, &res);
+}
+
+template <class KeyFrameT, class MapT>
+void Optimizer::LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap) {
+    typedef decltype(pKF->GetMapPointMatches()) MapPointVec;
+    typedef typename MapPointVec::value_type MapPointPtr;
+
+    // ---- (1) local keyframes, their map points, fixed keyframes (Optimizer.cc:456-504) ----
+    std::list<KeyFrameT*> lLocalKeyFrames;
+    lLocalKeyFrames.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    const std::vector<KeyFrameT*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
+    for (size_t i = 0; i < vNeighKFs.size(); ++i) {
+        KeyFrameT* pKFi = vNeighKFs[i];
+        pKFi->mnBALocalForKF = pKF->mnId;
+        if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi);
+    }
+    std::list<MapPointPtr> lLocalMapPoints;
+    for (typename std::list<KeyFrameT*>::iterator lit = lLocalKeyFrames.begin(); lit != lLocalKeyFrames.end(); ++lit) {
+        MapPointVec vpMPs = (*lit)->GetMapPointMatches();
+        for (size_t i = 0; i < vpMPs.size(); ++i) {
+            MapPointPtr pMP = vpMPs[i];
+            if (pMP && !pMP->isBad() && pMP->mnBALocalForKF != pKF->mnId) {
+                lLocalMapPoints.push_back(pMP);
+                pMP->mnBALocalForKF = pKF->mnId;
+            }
+        }
+    }
+    std::list<KeyFrameT*> lFixedCameras;
+    for (typename std::list<MapPointPtr>::iterator lit = lLocalMapPoints.begin(); lit != lLocalMapPoints.end(); ++lit) {
+        std::map<KeyFrameT*, size_t> observations = (*lit)->GetObservations();
+        for (typename std::map<KeyFrameT*, size_t>::iterator mit = observations.begin(); mit != observations.end(); ++mit) {
+            KeyFrameT* pKFi = mit->first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+                pKFi->mnBAFixedForKF = pKF->mnId;
+                if (!pKFi->isBad()) lFixedCameras.push_back(pKFi);
+            }
+        }
+    }
+
+    // ---- flatten into the C-ABI's arrays (vertices :522-546, edges :572-653) ----
+    std::vector<KeyFrameT*> kfs;
+    std::map<KeyFrameT*, int> kfIndex;
+    std::vector<double> pose, intr, pts, uv, invSigma2;
+    std::vector<uint8_t> fixed;
+    std::vector<int32_t> ekf, ept;
+    for (int pass = 0; pass < 2; ++pass) {
+        std::list<KeyFrameT*>& src = pass == 0 ? lLocalKeyFrames : lFixedCameras;
+        for (typename std::list<KeyFrameT*>::iterator lit = src.begin(); lit != src.end(); ++lit) {
+            KeyFrameT* k = *lit;
+            kfIndex[k] = (int)kfs.size();
+            kfs.push_back(k);
+            cv::Mat T = k->GetPose();  // 4x4 CV_32F, widened like Converter::toSE3Quat
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) pose.push_back((double)T.template at<float>(r, c));
+            for (int r = 0; r < 3; ++r) pose.push_back((double)T.template at<float>(r, 3));
+            fixed.push_back(pass == 1 || k->mnId == 0);
+            intr.push_back(k->fx); intr.push_back(k->fy); intr.push_back(k->cx); intr.push_back(k->cy);
+        }
+    }
+    std::vector<MapPointPtr> mps(lLocalMapPoints.begin(), lLocalMapPoints.end());
+    std::vector<std::pair<KeyFrameT*, MapPointPtr> > edgeOwner;
+    bool hasStereo = false;
+    for (size_t p = 0; p < mps.size(); ++p) {
+        cv::Mat X = mps[p]->GetWorldPos();
+        for (int r = 0; r < 3; ++r) pts.push_back((double)X.template at<float>(r, 0));
+        const std::map<KeyFrameT*, size_t> observations = mps[p]->GetObservations();
+        for (typename std::map<KeyFrameT*, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) {
+            KeyFrameT* pKFi = mit->first;
+            if (pKFi->isBad()) continue;
+            typename std::map<KeyFrameT*, int>::iterator where = kfIndex.find(pKFi);
+            if (where == kfIndex.end()) continue;
+            if (pKFi->mvuRight[mit->second] >= 0) { hasStereo = true; continue; }
+            const cv::KeyPoint& kpUn = pKFi->mvKeysUn[mit->second];
+            ekf.push_back(where->second); ept.push_back((int32_t)p);
+            uv.push_back(kpUn.pt.x); uv.push_back(kpUn.pt.y);
+            invSigma2.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
+            edgeOwner.push_back(std::make_pair(pKFi, mps[p]));
+        }
+    }
+    if (hasStereo) { lastStatus() = SLAMIT_ERR_ARG; return; }
+    if (pbStopFlag && *pbStopFlag) return;  // :655-657
+
+    // ---- (2) the optimisation itself ----
+    slamit_ba_problem prob;
+    prob.n_kf = (int32_t)kfs.size(); prob.n_pt = (int32_t)mps.size(); prob.n_edge = (int32_t)ekf.size();
+    prob.kf_pose = pose.data(); prob.kf_fixed = fixed.data(); prob.kf_intr = intr.data(); prob.pt_xyz = pts.data();
+    prob.edge_kf = ekf.data(); prob.edge_pt = ept.data(); prob.edge_uv = uv.data(); prob.edge_inv_sigma2 = invSigma2.data();
+    std::vector<double> outPose(pose.size()), outPts(pts.size()), chi2(ekf.size());
+    std::vector<uint8_t> outlier(ekf.size()), outlier1(ekf.size());
+    slamit_ba_result res;
+    res.kf_pose = outPose.data(); res.pt_xyz = outPts.data(); res.edge_chi2 = chi2.data();
+    res.edge_outlier = outlier.data(); res.edge_stage1_outlier = outlier1.data(); res.stats = 0;
+    if (LocalBundleAdjustmentPOD(prob, pbStopFlag, res) != SLAMIT_OK) return;
+
+    // ---- (3) erase outlier observations, write back (:711-777) ----
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+    for (size_t e = 0; e < edgeOwner.size(); ++e) {
+        if (!outlier[e] || edgeOwner[e].second->isBad()) continue;
+        edgeOwner[e].first->EraseMapPointMatch(edgeOwner[e].second);
+        edgeOwner[e].second->EraseObservation(edgeOwner[e].first);
+    }
+    size_t k = 0;
+    for (typename std::list<KeyFrameT*>::iterator lit = lLocalKeyFrames.begin(); lit != lLocalKeyFrames.end(); ++lit, ++k) {
+        cv::Mat T(4, 4, CV_32F);
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) T.template at<float>(r, c) = (float)outPose[12 * k + 3 * r + c];
+            T.template at<float>(r, 3) = (float)outPose[12 * k + 9 + r];
+            T.template at<float>(3, r) = 0.f;
+        }
+        T.template at<float>(3, 3) = 1.f;
+        (*lit)->SetPose(T);
+    }
+    for (size_t p = 0; p < mps.size(); ++p) {
+        cv::Mat X(3, 1, CV_32F);
+        for (int r = 0; r < 3; ++r) X.template at<float>(r, 0) = (float)outPts[3 * p + r];
+        mps[p]->SetWorldPos(X);
+        mps[p]->UpdateNormalAndDepth();
+    }
+}
+
+}  // namespace ORB_SLAM2
+
+#endif
