@@ -105,7 +105,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
-    from weiner_slamit_v2_amd import api, synth
+    from weiner_slamit_v2_amd import api, shard, synth
 
     B = args.batch
     # each rank owns its own B streams (different seeds per rank); two consecutive frames per stream
@@ -124,8 +124,7 @@ def main():
     d_idx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_best = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_second = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    summary = torch.zeros((B, 2), dtype=torch.int32, device=dev)
-    gathered = torch.zeros((world * B, 2), dtype=torch.int32, device=dev) if world > 1 else None
+    gather = shard.SummaryGather(B, 2, dev, world)  # per-frame (keypoints, matches) to every rank
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step(k):
@@ -134,8 +133,8 @@ def main():
         api.ORBmatcher.best2_batch_dev(d_desc[cur], d_n[cur], d_desc[prv], d_n[prv], d_idx, d_best, d_second,
                                        cap, device=dev.index, stream=stream)
         if world > 1:  # result summary to every rank (the only cross-GPU traffic of the path)
-            summary[:, 0] = d_n[cur]
-            dist.all_gather_into_tensor(gathered, summary)
+            gather.local[:, 0] = d_n[cur]
+            gather.step()
 
     for k in range(args.warmup):
         step(k)
@@ -166,10 +165,7 @@ def main():
     torch.cuda.synchronize(dev)
     match_ms = m0.elapsed_time(m1) / 5
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = shard.max_over_ranks(elapsed, dev, world)
 
     # sanity of the timed work: every frame produced its keypoints and matches
     n_last = d_n[(args.warmup + args.steps - 1) & 1].cpu().numpy()

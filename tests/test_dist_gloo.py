@@ -1,0 +1,68 @@
+"""The N>1 path on CPU: world_size 2, gloo.  Covers what bench.py does across ranks — stream
+sharding, the per-step summary all_gather, barrier + max-over-ranks timing — without a GPU."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from weiner_slamit_v2_amd import shard
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert shard.env_rank() == (rank, rank, world)
+        per_rank = 4
+        mine = shard.weak_streams(per_rank, world, rank)
+        g = shard.SummaryGather(per_rank, 2, torch.device("cpu"), world)
+        for step in range(3):
+            for i, s in enumerate(mine):  # pretend: stream s produced 1000+s keypoints, s matches at this step
+                g.local[i, 0] = 1000 + s
+                g.local[i, 1] = s * 10 + step
+            allv = g.step()
+            assert allv.shape == (world * per_rank, 2)
+            assert allv[:, 0].tolist() == [1000 + s for s in range(world * per_rank)]
+            assert allv[:, 1].tolist() == [s * 10 + step for s in range(world * per_rank)]
+        dist.barrier()
+        t = shard.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
+        assert t == float(world)
+        strong = shard.stream_assignment(8, world, rank)
+        assert strong == list(range(rank, 8, world))
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_assignments_cover_every_stream_once():
+    sys.path.insert(0, ROOT)
+    from weiner_slamit_v2_amd import shard
+
+    for world in (1, 2, 4, 8):
+        seen = sorted(s for r in range(world) for s in shard.stream_assignment(8, world, r))
+        assert seen == list(range(8))
+        seen = sorted(s for r in range(world) for s in shard.weak_streams(64, world, r))
+        assert seen == list(range(64 * world))
