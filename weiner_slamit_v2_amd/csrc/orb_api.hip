@@ -21,9 +21,15 @@ hipError_t orbk_upload_pattern(hipStream_t st);
 void orbk_resize(hipStream_t st, const uint8_t* src, int sw, int sh, size_t sstride, size_t sframe,
                  uint8_t* dst, int dw, int dh, size_t dstride, size_t dframe, const int* xofs,
                  const short* ialpha, const int* yofs, const short* ibeta, int nframes);
+hipError_t orbk_pyramid_prepare(int smem_bytes);
+void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const PyrBox* boxes, const PyrTabs* tabs,
+                  int nregions, const uint8_t* img0, size_t img0_stride, size_t img0_frame, uint8_t* pyr, int bufA_bytes,
+                  int smem_bytes, int nframes);
+size_t orbk_fast_smem(int max_wcell, int max_hcell);
+hipError_t orbk_fast_prepare(int max_wcell, int max_hcell);
 void orbk_fast(hipStream_t st, const OrbLevel* levels, int nlevels, int cells_per_frame, const uint8_t* img0,
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, unsigned long long* cand,
-               size_t cand_frame_stride, int* cand_count, int iniTh, int minTh, int nframes);
+               size_t cand_frame_stride, int* cand_count, int iniTh, int minTh, int max_wcell, int max_hcell, int nframes);
 size_t orbk_octree_smem(int node_cap);
 hipError_t orbk_octree_prepare(int node_cap);
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
@@ -33,8 +39,8 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0, size_t img0_stride,
                    size_t img0_frame, const uint8_t* pyr, OrbLevelKp* lkp, size_t kp_frame_stride,
                    const int* kp_count, int max_kp, int nframes);
-void orbk_blur(hipStream_t st, const uint8_t* src, int w, int h, size_t sstride, size_t sframe, uint8_t* dst,
-               size_t dstride, size_t dframe, int nframes);
+void orbk_blur(hipStream_t st, const OrbLevel* levels, int nlevels, int total_tiles, const uint8_t* img0,
+               size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes);
 void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,
                    const OrbLevelKp* lkp, size_t kp_frame_stride, const int* kp_count, slamit_kp* out_kps,
                    uint8_t* out_desc, int out_cap, int* out_n, int max_kp, int nframes);
@@ -83,7 +89,7 @@ struct slamit_orb {
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
     std::vector<int> per_level;
     std::vector<OrbLevel> levels;
-    int cells_per_frame, node_cap, max_kp_level, max_out;
+    int cells_per_frame, blur_tiles, node_cap, max_kp_level, max_out, max_wcell, max_hcell;
     size_t pyr_frame_total, blur_frame_total;
     size_t cand_frame_stride, kp_frame_stride;
     // device memory
@@ -97,6 +103,9 @@ struct slamit_orb {
     OrbLevelKp* d_lkp;
     int* d_tab_i[ORB_MAX_LEVELS][2];      // xofs, yofs per level (level >= 1)
     short* d_tab_s[ORB_MAX_LEVELS][2];    // ialpha, ibeta
+    PyrBox* d_boxes;                      // fused pyramid: [nregions][nlevels]
+    PyrTabs* d_tabs;                      // [nlevels]
+    int pyr_regions, pyr_bufA, pyr_smem;
     // staging for the host-pointer entry points
     uint8_t* d_in;
     size_t d_in_stride, d_in_frame;
@@ -120,7 +129,7 @@ static void orb_free(slamit_orb* h) {
     hipSetDevice(h->device);
     hipFree(h->d_levels); hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cand); hipFree(h->d_ws_xy);
     hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
-    hipFree(h->d_out_desc); hipFree(h->d_out_n); hipFree(h->d_scratch);
+    hipFree(h->d_out_desc); hipFree(h->d_out_n); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
@@ -170,7 +179,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
     // ---- level geometry (ORBextractor.cc:1143-1147, 789-803, 556-571) ----
     h->levels.assign(nl, OrbLevel());
     size_t pyr_off = 0, blur_off = 0, cand_off = 0;
-    int kp_off = 0, cell_base = 0;
+    int kp_off = 0, cell_base = 0, blur_tiles = 0;
     h->node_cap = 8; h->max_kp_level = 1;
     int sum_cap = 0;
     const bool empty = p->width == 0 || p->height == 0;
@@ -195,6 +204,8 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         }
         L.wCell = (int)ceil(width / L.nCols); L.hCell = (int)ceil(height / L.nRows);
         L.cell_base = cell_base; L.ncells = L.nCols * L.nRows; cell_base += L.ncells;
+        h->max_wcell = std::max(h->max_wcell, L.wCell); h->max_hcell = std::max(h->max_hcell, L.hCell);
+        L.blur_tile_base = blur_tiles; blur_tiles += ((L.w + 63) / 64) * ((L.h + 63) / 64);  // 64x64 strips, four 16-row steps each
         L.cand_cap = L.ncells * ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);  // NMS: <= 1 per 2x2 in a cell
         L.cand_off = cand_off; cand_off += round_up((size_t)L.cand_cap, 64);
         const int bw = L.maxBorderX - ORB_MIN_BORDER, bh = L.maxBorderY - ORB_MIN_BORDER;
@@ -219,6 +230,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
     }
     h->max_out = std::max(h->max_out, sum_cap);
     h->cells_per_frame = cell_base;
+    h->blur_tiles = blur_tiles;
     h->pyr_frame_total = pyr_off; h->blur_frame_total = blur_off;
     h->cand_frame_stride = cand_off; h->kp_frame_stride = (size_t)kp_off;
     // frames are the outer dimension of every per-frame array: plane(level, f) = base + level_off + f*frame_total
@@ -265,9 +277,66 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         if (e == hipSuccess) e = hipMemcpy(h->d_tab_s[l][0], xa.data(), xa.size() * 2, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(h->d_tab_s[l][1], ya.data(), ya.size() * 2, hipMemcpyHostToDevice);
     }
+    // ---- fused pyramid: per-region boxes (own / need) for every level ----
+    if (e == hipSuccess && !empty && nl > 1) {
+        std::vector<std::vector<int> > XO(nl), YO(nl);
+        for (int l = 1; l < nl; ++l) {
+            std::vector<short> dummy;
+            resize_axis(h->levels[l].w, h->levels[l - 1].w, true, XO[l], dummy);
+            resize_axis(h->levels[l].h, h->levels[l - 1].h, false, YO[l], dummy);
+        }
+        const int GX = std::max(1, (p->width + 127) / 128), GY = std::max(1, (p->height + 95) / 96);
+        std::vector<PyrBox> boxes((size_t)GX * GY * nl);
+        size_t capA = 16, capB = 16;
+        bool okb = true;
+        for (int gy = 0; gy < GY && okb; ++gy)
+            for (int gx = 0; gx < GX && okb; ++gx) {
+                PyrBox* B = &boxes[((size_t)gy * GX + gx) * nl];
+                for (int l = 0; l < nl; ++l) {
+                    const OrbLevel& L = h->levels[l];
+                    B[l].ox0 = (int16_t)((long)gx * L.w / GX); B[l].ox1 = (int16_t)((long)(gx + 1) * L.w / GX);
+                    B[l].oy0 = (int16_t)((long)gy * L.h / GY); B[l].oy1 = (int16_t)((long)(gy + 1) * L.h / GY);
+                    if (l == 0) { B[l].ox0 = B[l].ox1 = B[l].oy0 = B[l].oy1 = 0; }  // level 0 is only read
+                    else if (B[l].ox1 <= B[l].ox0 || B[l].oy1 <= B[l].oy0) okb = false;
+                }
+                B[nl - 1].nx0 = B[nl - 1].ox0; B[nl - 1].nx1 = B[nl - 1].ox1;
+                B[nl - 1].ny0 = B[nl - 1].oy0; B[nl - 1].ny1 = B[nl - 1].oy1;
+                for (int l = nl - 1; l >= 1 && okb; --l) {
+                    const int sw = h->levels[l - 1].w, sh = h->levels[l - 1].h;
+                    int sx0 = XO[l][B[l].nx0], sx1 = std::min(XO[l][B[l].nx1 - 1] + 1, sw - 1) + 1;
+                    int sy0 = std::min(std::max(YO[l][B[l].ny0], 0), sh - 1);
+                    int sy1 = std::min(std::max(YO[l][B[l].ny1 - 1] + 1, 0), sh - 1) + 1;
+                    if (l - 1 >= 1) {
+                        sx0 = std::min(sx0, (int)B[l - 1].ox0); sx1 = std::max(sx1, (int)B[l - 1].ox1);
+                        sy0 = std::min(sy0, (int)B[l - 1].oy0); sy1 = std::max(sy1, (int)B[l - 1].oy1);
+                    }
+                    if (l - 1 == 0) sx0 &= ~3;  // dword-aligned level-0 patch
+                    B[l - 1].nx0 = (int16_t)sx0; B[l - 1].nx1 = (int16_t)sx1; B[l - 1].ny0 = (int16_t)sy0; B[l - 1].ny1 = (int16_t)sy1;
+                }
+                for (int l = 0; l < nl; ++l) {
+                    if (l >= 1 && B[l].nx1 - B[l].nx0 > 256) okb = false;  // kernel keeps <= 4 columns per lane
+                    size_t bytes = (size_t)(((B[l].nx1 - B[l].nx0) + 3) & ~3) * (B[l].ny1 - B[l].ny0);
+                    if (l & 1) capB = std::max(capB, bytes); else capA = std::max(capA, bytes);
+                }
+            }
+        h->pyr_regions = okb ? GX * GY : 0;
+        h->pyr_bufA = (int)round_up(capA, 16);
+        h->pyr_smem = h->pyr_bufA + (int)round_up(capB, 16);
+        if (h->pyr_smem > 150 * 1024) h->pyr_regions = 0;  // fall back to the per-level kernel
+        if (h->pyr_regions) {
+            std::vector<PyrTabs> tabs(nl);
+            for (int l = 0; l < nl; ++l) { tabs[l].xofs = h->d_tab_i[l][0]; tabs[l].ialpha = h->d_tab_s[l][0]; tabs[l].yofs = h->d_tab_i[l][1]; tabs[l].ibeta = h->d_tab_s[l][1]; }
+            ALLOC(h->d_boxes, sizeof(PyrBox) * boxes.size());
+            ALLOC(h->d_tabs, sizeof(PyrTabs) * nl);
+            if (e == hipSuccess) e = hipMemcpy(h->d_boxes, boxes.data(), sizeof(PyrBox) * boxes.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(h->d_tabs, tabs.data(), sizeof(PyrTabs) * nl, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = orbk_pyramid_prepare(h->pyr_smem);
+        }
+    }
 #undef ALLOC
     if (e == hipSuccess) e = orbk_upload_pattern(h->stream);
     if (e == hipSuccess) e = orbk_octree_prepare(h->node_cap);
+    if (e == hipSuccess && !empty) e = orbk_fast_prepare(h->max_wcell, h->max_hcell);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         orb_free(h);
@@ -329,20 +398,25 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     HIP_TRY(hipMemsetAsync(cand_count, 0, sizeof(int) * nframes * nl, st));
     // K1: pyramid, level l from level l-1
     prof_mark(h, st, ST_RESIZE, true);
-    for (int l = 1; l < nl; ++l) {
-        const OrbLevel& S = h->levels[l - 1];
-        const OrbLevel& D = h->levels[l];
-        const uint8_t* src = l == 1 ? d_gray : h->d_pyr + S.plane_off;
-        size_t sstride = l == 1 ? stride : (size_t)S.stride;
-        size_t sframe = l == 1 ? frame_stride : h->pyr_frame_total;
-        orbk_resize(st, src, S.w, S.h, sstride, sframe, h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride,
-                    h->pyr_frame_total, h->d_tab_i[l][0], h->d_tab_s[l][0], h->d_tab_i[l][1], h->d_tab_s[l][1], nframes);
+    if (h->pyr_regions) {
+        orbk_pyramid(st, h->d_levels, nl, h->d_boxes, h->d_tabs, h->pyr_regions, d_gray, stride, frame_stride, h->d_pyr,
+                     h->pyr_bufA, h->pyr_smem, nframes);
+    } else {
+        for (int l = 1; l < nl; ++l) {
+            const OrbLevel& S = h->levels[l - 1];
+            const OrbLevel& D = h->levels[l];
+            const uint8_t* src = l == 1 ? d_gray : h->d_pyr + S.plane_off;
+            size_t sstride = l == 1 ? stride : (size_t)S.stride;
+            size_t sframe = l == 1 ? frame_stride : h->pyr_frame_total;
+            orbk_resize(st, src, S.w, S.h, sstride, sframe, h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride,
+                        h->pyr_frame_total, h->d_tab_i[l][0], h->d_tab_s[l][0], h->d_tab_i[l][1], h->d_tab_s[l][1], nframes);
+        }
     }
     prof_mark(h, st, ST_RESIZE, false);
     // K2: FAST + NMS + per-cell threshold fallback -> candidate lists
     prof_mark(h, st, ST_FAST, true);
     orbk_fast(st, h->d_levels, nl, h->cells_per_frame, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
-              h->cand_frame_stride, cand_count, h->p.ini_th_fast, h->p.min_th_fast, nframes);
+              h->cand_frame_stride, cand_count, h->p.ini_th_fast, h->p.min_th_fast, h->max_wcell, h->max_hcell, nframes);
     prof_mark(h, st, ST_FAST, false);
     // K4: octree
     prof_mark(h, st, ST_OCTREE, true);
@@ -356,12 +430,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     prof_mark(h, st, ST_ANGLE, false);
     // K6: blur every level
     prof_mark(h, st, ST_BLUR, true);
-    for (int l = 0; l < nl; ++l) {
-        const OrbLevel& L = h->levels[l];
-        const uint8_t* src = l == 0 ? d_gray : h->d_pyr + L.plane_off;
-        orbk_blur(st, src, L.w, L.h, l == 0 ? stride : (size_t)L.stride, l == 0 ? frame_stride : h->pyr_frame_total,
-                  h->d_blur + L.blur_off, (size_t)L.stride, h->blur_frame_total, nframes);
-    }
+    orbk_blur(st, h->d_levels, nl, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
     prof_mark(h, st, ST_BLUR, false);
     // K7: descriptors + output records
     prof_mark(h, st, ST_DESCRIBE, true);

@@ -61,6 +61,100 @@ __global__ __launch_bounds__(256) void resize_level_kernel(
 }
 
 // --------------------------------------------------------------------------------------------
+// K1 (fused): the whole pyramid in ONE launch.  Workgroup (region, frame) loads its level-0 patch
+// once, then produces level 1, 2, ... each from the previous level kept in LDS (two ping-pong
+// buffers), storing only the pixels it owns.  The chain of integer roundings is exactly the
+// reference's (level l is always computed from level l-1), but no level is ever re-read from HBM
+// and six dependent launches disappear.  Boxes come from the host (orb_api.hip: build_pyr_boxes).
+// --------------------------------------------------------------------------------------------
+#define PYR_THREADS 512
+#define PYR_ROWS (PYR_THREADS / 64)
+
+__global__ __launch_bounds__(PYR_THREADS) void pyramid_fused_kernel(
+    const OrbLevel* __restrict__ levels, int nlevels, const PyrBox* __restrict__ boxes,
+    const PyrTabs* __restrict__ tabs, const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
+    uint8_t* __restrict__ pyr, int bufA_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pbuf[];
+    uint8_t* buf[2] = {pbuf, pbuf + bufA_bytes};
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int frame = blockIdx.y;
+    const PyrBox* B = boxes + (size_t)blockIdx.x * nlevels;
+    // level-0 patch (its x0 is a multiple of 4: whole dwords when the caller's image is 4-byte aligned)
+    {
+        const PyrBox b = B[0];
+        const int nw = b.nx1 - b.nx0, pitch = (nw + 3) & ~3;
+        const uint8_t* S = img0 + (size_t)frame * img0_frame;
+        const bool aligned = ((((uintptr_t)S) | img0_stride) & 3) == 0;
+        const int w0 = levels[0].w;
+        if (aligned) {
+            const int nd = pitch >> 2;
+            for (int y = b.ny0 + ty; y < b.ny1; y += PYR_ROWS)
+                for (int d = tx; d < nd; d += 64) {
+                    const int x = b.nx0 + 4 * d;
+                    uint32_t v;
+                    if (x + 4 <= w0) v = *reinterpret_cast<const uint32_t*>(S + (size_t)y * img0_stride + x);
+                    else { v = 0; for (int j = 0; j < 4; ++j) if (x + j < w0) v |= (uint32_t)S[(size_t)y * img0_stride + x + j] << (8 * j); }
+                    *reinterpret_cast<uint32_t*>(&buf[0][(y - b.ny0) * pitch + 4 * d]) = v;
+                }
+        } else {
+            for (int y = b.ny0 + ty; y < b.ny1; y += PYR_ROWS)
+                for (int x = b.nx0 + tx; x < b.nx1; x += 64)
+                    buf[0][(y - b.ny0) * pitch + (x - b.nx0)] = S[(size_t)y * img0_stride + x];
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l < nlevels; ++l) {
+        const PyrBox b = B[l], pb = B[l - 1];
+        const OrbLevel& L = levels[l];
+        const int sw = levels[l - 1].w, sh = levels[l - 1].h;
+        const PyrTabs T = tabs[l];
+        const uint8_t* src = buf[(l - 1) & 1];
+        uint8_t* dst = buf[l & 1];
+        const int spitch = ((pb.nx1 - pb.nx0) + 3) & ~3, dpitch = ((b.nx1 - b.nx0) + 3) & ~3;
+        uint8_t* plane = pyr + L.plane_off + (size_t)frame * L.plane_bytes;
+        // a lane keeps the coefficients of its (<= 4) columns in registers; rows are wave-uniform, so
+        // their tables come through the scalar unit
+        const int nw = b.nx1 - b.nx0;
+        int cx0[4], cx1[4], ca0[4], ca1[4];
+        unsigned ownmask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = b.nx0 + tx + 64 * j;
+            if (tx + 64 * j < nw) {
+                const int sx = T.xofs[x];
+                cx0[j] = sx - pb.nx0;
+                cx1[j] = min(sx + 1, sw - 1) - pb.nx0;
+                ca0[j] = T.ialpha[2 * x];
+                ca1[j] = T.ialpha[2 * x + 1];
+                if (x >= b.ox0 && x < b.ox1) ownmask |= 1u << j;
+            } else { cx0[j] = cx1[j] = 0; ca0[j] = ca1[j] = 0; }
+        }
+        const int wy = __builtin_amdgcn_readfirstlane(ty);
+        for (int y = b.ny0 + wy; y < b.ny1; y += PYR_ROWS) {
+            const int sy = T.yofs[y];
+            const int sy0 = min(max(sy, 0), sh - 1) - pb.ny0, sy1 = min(max(sy + 1, 0), sh - 1) - pb.ny0;
+            const int b0 = T.ibeta[2 * y], b1 = T.ibeta[2 * y + 1];
+            const uint8_t* S0 = src + sy0 * spitch;
+            const uint8_t* S1 = src + sy1 * spitch;
+            const bool own_y = y >= b.oy0 && y < b.oy1;
+            uint8_t* drow = dst + (y - b.ny0) * dpitch + tx;
+            uint8_t* prow = plane + (size_t)y * L.stride + b.nx0 + tx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (tx + 64 * j < nw) {
+                    const int r0 = S0[cx0[j]] * ca0[j] + S0[cx1[j]] * ca1[j];
+                    const int r1 = S1[cx0[j]] * ca0[j] + S1[cx1[j]] * ca1[j];
+                    const int v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+                    drow[64 * j] = (uint8_t)v;
+                    if (own_y && ((ownmask >> j) & 1)) prow[64 * j] = (uint8_t)v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // K2: FAST-9/16 per cell.  One 256-thread workgroup = one cell of one level of one frame.
 //
 // The cell's window (<= 65x65 bytes) is staged in LDS once; every pixel of the scan area gets its
@@ -106,19 +200,34 @@ __device__ __forceinline__ int fast_score(const uint8_t* t) {
     return max(v - dm, bm - v) - 1;
 }
 
+// One WAVEFRONT per cell (4 cells per workgroup): every step below is wave-synchronous, so there is
+// no s_barrier anywhere; list appends use ballot + popcount with the running count in a
+// wave-uniform register, so there are no LDS atomics either.
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(256) void fast_cells_kernel(
-    const OrbLevel* __restrict__ levels, int nlevels,
+    const OrbLevel* __restrict__ levels, int nlevels, int cells_per_frame,
     const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr,
     unsigned long long* __restrict__ cand, size_t cand_frame_stride,
-    int* __restrict__ cand_count, int iniTh, int minTh) {
-    __shared__ uint8_t tile[ORB_TILE_MAX * TILE_PITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[(ORB_CELL_MAX + 2) * SC_PITCH];
-    __shared__ int s_cnt_ini, s_cnt_min, s_base;
-
-    const int tid = threadIdx.x;
+    int* __restrict__ cand_count, int iniTh, int minTh, int tile_rows, int sc_rows, int list_cap, int kp_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int frame = blockIdx.y;
-    const int cell = blockIdx.x;
+    const int cell = blockIdx.x * 4 + wv;
+    if (cell >= cells_per_frame) return;
+    // per-wave LDS carve
+    const int tile_bytes = tile_rows * TILE_PITCH, sc_bytes = sc_rows * SC_PITCH;
+    const int per_wave = (tile_bytes + sc_bytes + 2 * list_cap + 2 * kp_cap + 15) & ~15;
+    uint8_t* tile = fsm + (size_t)wv * per_wave;
+    uint8_t* sc = tile + tile_bytes;
+    unsigned short* s_list = reinterpret_cast<unsigned short*>(sc + sc_bytes);
+    unsigned short* s_kp = s_list + list_cap;
+
     int level = 0;
     while (level + 1 < nlevels && cell >= levels[level + 1].cell_base) ++level;
     const OrbLevel& L = levels[level];
@@ -142,70 +251,95 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     }
     src += (size_t)iniY * stride + iniX;
 
-    // stage the window; rows are <= 65 contiguous bytes, neighbouring cells share L2 lines
+    // stage the window (rows of <= 65 contiguous bytes; neighbouring cells share L2 lines)
     const int npx = cw * ch;
     const unsigned inv_cw = (1u << 20) / (unsigned)cw + 1;  // exact p / cw for p*cw < 2^20
-    for (int p = tid; p < npx; p += 256) {
+    for (int p = lane; p < npx; p += WAVE) {
         int r = (int)(((unsigned)p * inv_cw) >> 20);
         int cc = p - r * cw;
         tile[r * TILE_PITCH + cc] = src[(size_t)r * stride + cc];
     }
-    for (int i = tid; i < (ORB_CELL_MAX + 2) * SC_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
-    if (tid == 0) { s_cnt_ini = 0; s_cnt_min = 0; }
-    __syncthreads();
-
-    const int floorTh = max(min(iniTh, minTh), 1);
+    for (int i = lane; i < sc_bytes / 4; i += WAVE) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    wave_sync_lds();
     const int nscan = sw * sh;
     const unsigned inv_sw = (1u << 20) / (unsigned)sw + 1;
-    for (int p = tid; p < nscan; p += 256) {
-        int y = (int)(((unsigned)p * inv_sw) >> 20);
-        int x = p - y * sw;
-        int S = fast_score(&tile[(y + 3) * TILE_PITCH + x + 3]);
-        sc[(y + 1) * SC_PITCH + x + 1] = (uint8_t)(S >= floorTh ? S : 0);
-    }
-    __syncthreads();
 
-    // NMS (strict >, 8 neighbours, zeros outside the scan area); remember per-thread results
-    uint32_t m_ini = 0, m_min = 0;
-    int it = 0;
-    for (int p = tid; p < nscan; p += 256, ++it) {
-        int y = (int)(((unsigned)p * inv_sw) >> 20);
-        int x = p - y * sw;
-        const uint8_t* s = &sc[(y + 1) * SC_PITCH + x + 1];
-        int v = s[0];
-        if (v) {
-            int nb = imax3(s[-SC_PITCH - 1], s[-SC_PITCH], s[-SC_PITCH + 1]);
-            nb = imax3(nb, s[-1], s[1]);
-            nb = max(nb, imax3(s[SC_PITCH - 1], s[SC_PITCH], s[SC_PITCH + 1]));
-            if (v > nb) {
-                if (v >= iniTh) m_ini |= 1u << it;
-                if (v >= minTh) m_min |= 1u << it;
+    // Two attempts like the reference: FAST at iniThFAST, and only if the cell stays empty, again at
+    // minThFAST (ORBextractor.cc:827-833).  Per attempt:
+    //  A. compass pre-test (necessary condition: a 9-arc of the 16-ring always holds two adjacent
+    //     compass pixels, so two adjacent ones must both be brighter than v+t or both darker than v-t);
+    //     survivors are compacted into a list so that
+    //  B. the exact score is computed with every lane busy, stored if >= t,
+    //  C. NMS over the survivors (strict >, 8 neighbours, zeros outside the scan area / below t).
+    int th = iniTh;
+    int nkp = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int nlist = 0;
+        for (int p0 = 0; p0 < nscan; p0 += WAVE) {
+            const int p = p0 + lane;
+            int pass = 0;
+            if (p < nscan) {
+                const int y = (int)(((unsigned)p * inv_sw) >> 20);
+                const int x = p - y * sw;
+                const uint8_t* t = &tile[(y + 3) * TILE_PITCH + x + 3];
+                const int v = t[0];
+                const int s0 = t[3 * TILE_PITCH], e0 = t[3], n0 = t[-3 * TILE_PITCH], w0 = t[-3];
+                const int hi = v + th, lo = v - th;
+                const int bs = s0 > hi, be = e0 > hi, bn = n0 > hi, bw = w0 > hi;
+                const int ds = s0 < lo, de = e0 < lo, dn = n0 < lo, dw = w0 < lo;
+                pass = (bs & be) | (be & bn) | (bn & bw) | (bw & bs) | (ds & de) | (de & dn) | (dn & dw) | (dw & ds);
             }
+            const unsigned long long m = __ballot(pass);
+            if (pass) s_list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+            nlist += __popcll(m);
         }
+        wave_sync_lds();
+        for (int i = lane; i < nlist; i += WAVE) {
+            const int p = s_list[i];
+            const int y = (int)(((unsigned)p * inv_sw) >> 20);
+            const int x = p - y * sw;
+            const int S = fast_score(&tile[(y + 3) * TILE_PITCH + x + 3]);
+            sc[(y + 1) * SC_PITCH + x + 1] = (uint8_t)(S >= th ? S : 0);
+        }
+        wave_sync_lds();
+        nkp = 0;
+        for (int i0 = 0; i0 < nlist; i0 += WAVE) {
+            const int i = i0 + lane;
+            int keep = 0, p = 0;
+            if (i < nlist) {
+                p = s_list[i];
+                const int y = (int)(((unsigned)p * inv_sw) >> 20);
+                const int x = p - y * sw;
+                const uint8_t* s = &sc[(y + 1) * SC_PITCH + x + 1];
+                const int v = s[0];
+                if (v) {
+                    int nb = imax3(s[-SC_PITCH - 1], s[-SC_PITCH], s[-SC_PITCH + 1]);
+                    nb = imax3(nb, s[-1], s[1]);
+                    nb = max(nb, imax3(s[SC_PITCH - 1], s[SC_PITCH], s[SC_PITCH + 1]));
+                    keep = v > nb;
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) s_kp[nkp + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+            nkp += __popcll(m);
+        }
+        wave_sync_lds();
+        if (nkp > 0 || minTh >= th) break;  // found corners, or the retry cannot find more
+        th = minTh;
     }
-    int n_ini = __popc(m_ini), n_min = __popc(m_min);
-    int off_ini = 0, off_min = 0;
-    if (n_ini) off_ini = atomicAdd(&s_cnt_ini, n_ini);
-    if (n_min) off_min = atomicAdd(&s_cnt_min, n_min);
-    __syncthreads();
-    const bool use_ini = s_cnt_ini > 0;  // ORBextractor.cc:829-833: retry at minThFAST if empty
-    const int total = use_ini ? s_cnt_ini : s_cnt_min;
-    if (total == 0) return;
-    if (tid == 0) s_base = atomicAdd(&cand_count[frame * nlevels + level], total);
-    __syncthreads();
-    uint32_t m = use_ini ? m_ini : m_min;
-    int o = s_base + (use_ini ? off_ini : off_min);
+    if (nkp == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cand_count[frame * nlevels + level], nkp);
+    base = __shfl(base, 0, WAVE);
     unsigned long long* out = cand + L.cand_off + (size_t)frame * cand_frame_stride;
-    while (m) {
-        int b = __ffs(m) - 1;
-        m &= m - 1;
-        int p = tid + 256 * b;
-        int y = (int)(((unsigned)p * inv_sw) >> 20);
-        int x = p - y * sw;
-        unsigned S = sc[(y + 1) * SC_PITCH + x + 1];
-        unsigned order = ((unsigned)c << 12) | ((unsigned)(y + 3) << 6) | (unsigned)(x + 3);
+    for (int i = lane; i < nkp; i += WAVE) {
+        const int p = s_kp[i];
+        const int y = (int)(((unsigned)p * inv_sw) >> 20);
+        const int x = p - y * sw;
+        const unsigned S = sc[(y + 1) * SC_PITCH + x + 1];
+        const unsigned order = ((unsigned)c << 12) | ((unsigned)(y + 3) << 6) | (unsigned)(x + 3);
+        const int o = base + i;
         if (o < L.cand_cap) out[o] = ((unsigned long long)S << 32) | order;
-        ++o;
     }
 }
 
@@ -505,7 +639,19 @@ __global__ __launch_bounds__(256) void octree_kernel(
 // K5: IC_Angle — intensity centroid over the radius-15 disc on the un-blurred level.
 // One wavefront per keypoint; integer moments reduced with cross-lane shuffles.
 // --------------------------------------------------------------------------------------------
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// offsets (u, v) of the 749 pixels of the radius-15 disc, rows v = -15..15, |u| <= umax[|v|]
+struct DiscTable { signed char u[768], v[768]; int n; };
+__constant__ DiscTable c_disc;
+
+static DiscTable make_disc() {
+    static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    DiscTable t;
+    t.n = 0;
+    for (int v = -15; v <= 15; ++v)
+        for (int u = -umax[v < 0 ? -v : v]; u <= umax[v < 0 ? -v : v]; ++u) { t.u[t.n] = (signed char)u; t.v[t.n] = (signed char)v; ++t.n; }
+    for (int i = t.n; i < 768; ++i) { t.u[i] = 0; t.v[i] = 0; }
+    return t;
+}
 
 __global__ __launch_bounds__(256) void ic_angle_kernel(
     const OrbLevel* __restrict__ levels, int nlevels,
@@ -519,19 +665,17 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
     if (i >= kp_count[frame * nlevels + level]) return;
     OrbLevelKp* kp = lkp + L.kp_off + (size_t)frame * kp_frame_stride + i;
     const uint8_t* src;
-    size_t stride;
-    if (level == 0) { src = img0 + (size_t)frame * img0_frame; stride = img0_stride; }
-    else { src = pyr + L.plane_off + (size_t)frame * L.plane_bytes; stride = (size_t)L.stride; }
+    int stride;
+    if (level == 0) { src = img0 + (size_t)frame * img0_frame; stride = (int)img0_stride; }
+    else { src = pyr + L.plane_off + (size_t)frame * L.plane_bytes; stride = L.stride; }
     const uint8_t* center = src + (size_t)kp->y * stride + kp->x;
     int m10 = 0, m01 = 0;
-    for (int idx = lane; idx < 31 * 31; idx += WAVE) {
-        int v = idx / 31 - 15, u = idx % 31 - 15;
-        int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        if (au <= c_umax[av]) {
-            int val = center[(ptrdiff_t)v * (ptrdiff_t)stride + u];
-            m10 += u * val;
-            m01 += v * val;
-        }
+    const int n = c_disc.n;
+    for (int idx = lane; idx < n; idx += WAVE) {
+        const int u = c_disc.u[idx], v = c_disc.v[idx];
+        const int val = center[v * stride + u];
+        m10 += u * val;
+        m01 += v * val;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -551,40 +695,103 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-__global__ __launch_bounds__(256) void blur_level_kernel(
-    const uint8_t* __restrict__ src, int w, int h, size_t sstride, size_t sframe,
-    uint8_t* __restrict__ dst, size_t dstride, size_t dframe) {
-    __shared__ uint8_t in[22][72];
-    __shared__ uint16_t rows[22][64];
-    const int tid = threadIdx.x;
-    const int bx = blockIdx.x * 64, by = blockIdx.y * 16, f = blockIdx.z;
-    const uint8_t* S = src + (size_t)f * sframe;
-    for (int i = tid; i < 22 * 70; i += 256) {
-        int r = i / 70, c = i - r * 70;
-        int gy = reflect101(by + r - 3, h), gx = reflect101(bx + c - 3, w);
-        in[r][c] = S[(size_t)gy * sstride + gx];
-    }
-    __syncthreads();
-    for (int i = tid; i < 22 * 64; i += 256) {
-        int r = i >> 6, c = i & 63;
-        const uint8_t* p = &in[r][c];
-        int acc = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        rows[r][c] = (uint16_t)acc;
-    }
-    __syncthreads();
-    const int x4 = (tid & 15) * 4, y = tid >> 4;
-    if (bx + x4 >= w || by + y >= h) return;
-    uint32_t out = 0;
+// One launch covers every level of every frame: blockIdx.x walks the per-level tile lists
+// (OrbLevel::blur_tile_base), blockIdx.y is the frame.  A workgroup owns a 64-wide, 64-tall strip
+// and walks it in four 16-row steps; the input rows of step s+1 are fetched into registers while
+// step s is being filtered, so the HBM/L2 latency is paid once per strip.  Dwords that lie fully
+// inside an image row are loaded whole (planes are 4-byte aligned); edge dwords go byte by byte
+// through the REFLECT_101 map.
+#define BLUR_STEPS 4
+
+__device__ __forceinline__ uint32_t blur_fetch(const uint8_t* S, size_t sstride, bool aligned, int w, int h, int bx, int by,
+                                               int i) {
+    const int r = i / 18, c4 = i - r * 18;
+    const int gy = reflect101(by + r - 3, h);
+    const int gx0 = bx - 4 + 4 * c4;
+    const uint8_t* rowp = S + (size_t)gy * sstride;
+    if (aligned && gx0 >= 0 && gx0 + 4 <= w) return *reinterpret_cast<const uint32_t*>(rowp + gx0);
+    uint32_t v = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = x4 + i;
-        int acc = 18 * (rows[y][c] + rows[y + 6][c]) + 34 * (rows[y + 1][c] + rows[y + 5][c]) +
-                  49 * (rows[y + 2][c] + rows[y + 4][c]) + 55 * rows[y + 3][c];
-        int v = (acc + (1 << 15)) >> 16;
-        v = min(v, 255);
-        out |= (uint32_t)v << (8 * i);
+    for (int j = 0; j < 4; ++j) v |= (uint32_t)rowp[reflect101(gx0 + j, w)] << (8 * j);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void blur_all_kernel(
+    const OrbLevel* __restrict__ levels, int nlevels,
+    const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
+    const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+    __shared__ __attribute__((aligned(16))) uint8_t in[22][72];
+    __shared__ __attribute__((aligned(16))) uint16_t rows[22][64];
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.y;
+    int level = 0;
+    while (level + 1 < nlevels && (int)blockIdx.x >= levels[level + 1].blur_tile_base) ++level;
+    const OrbLevel& L = levels[level];
+    const int t = blockIdx.x - L.blur_tile_base;
+    const int tx = (L.w + 63) >> 6;
+    const int ty = t / tx;
+    const int bx = (t - ty * tx) * 64, by0 = ty * (16 * BLUR_STEPS);
+    const int w = L.w, h = L.h;
+    if (by0 >= h) return;
+    const uint8_t* S;
+    size_t sstride;
+    if (level == 0) { S = img0 + (size_t)frame * img0_frame; sstride = img0_stride; }
+    else { S = pyr + L.plane_off + (size_t)frame * L.plane_bytes; sstride = (size_t)L.stride; }
+    const bool aligned = ((((uintptr_t)S) | sstride) & 3) == 0;
+    uint8_t* D = blur + L.blur_off + (size_t)frame * L.blur_bytes;
+    // in[r][k] holds column bx - 4 + k of row by - 3 + r
+    const int i0 = tid, i1 = tid + 256;  // 22 * 18 = 396 dwords per step
+    uint32_t v0 = blur_fetch(S, sstride, aligned, w, h, bx, by0, i0);
+    uint32_t v1 = i1 < 22 * 18 ? blur_fetch(S, sstride, aligned, w, h, bx, by0, i1) : 0;
+    *reinterpret_cast<uint32_t*>(&in[i0 / 18][4 * (i0 % 18)]) = v0;
+    if (i1 < 22 * 18) *reinterpret_cast<uint32_t*>(&in[i1 / 18][4 * (i1 % 18)]) = v1;
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < BLUR_STEPS; ++s) {
+        const int by = by0 + 16 * s;
+        const bool more = s + 1 < BLUR_STEPS && by + 16 < h;
+        if (more) {
+            v0 = blur_fetch(S, sstride, aligned, w, h, bx, by + 16, i0);
+            if (i1 < 22 * 18) v1 = blur_fetch(S, sstride, aligned, w, h, bx, by + 16, i1);
+        }
+        // row pass: thread -> 4 adjacent outputs of one of the 22 rows (taps sum to 257: fits u16)
+        for (int i = tid; i < 22 * 16; i += 256) {
+            const int r = i >> 4, c = (i & 15) * 4;
+            // three ALIGNED dwords (columns bx+c-4 .. bx+c+7); q[k] = column bx + c - 3 + k.
+            // (Byte-wise reads at the odd offset get merged into unaligned ds_read_b64, which costs
+            //  ~30 LDS cycles per instruction on gfx950: measured with SQ_LDS_IDX_ACTIVE.)
+            const uint32_t* pw = reinterpret_cast<const uint32_t*>(&in[r][c]);
+            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+            int q[10];
+            q[0] = (w0 >> 8) & 0xFF; q[1] = (w0 >> 16) & 0xFF; q[2] = w0 >> 24;
+            q[3] = w1 & 0xFF; q[4] = (w1 >> 8) & 0xFF; q[5] = (w1 >> 16) & 0xFF; q[6] = w1 >> 24;
+            q[7] = w2 & 0xFF; q[8] = (w2 >> 8) & 0xFF; q[9] = (w2 >> 16) & 0xFF;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                rows[r][c + o] = (uint16_t)(18 * (q[o] + q[o + 6]) + 34 * (q[o + 1] + q[o + 5]) + 49 * (q[o + 2] + q[o + 4]) + 55 * q[o + 3]);
+        }
+        __syncthreads();
+        if (more) {
+            *reinterpret_cast<uint32_t*>(&in[i0 / 18][4 * (i0 % 18)]) = v0;
+            if (i1 < 22 * 18) *reinterpret_cast<uint32_t*>(&in[i1 / 18][4 * (i1 % 18)]) = v1;
+        }
+        const int x4 = (tid & 15) * 4, y = tid >> 4;
+        if (bx + x4 < w && by + y < h) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = x4 + i;
+                int acc = 18 * (rows[y][c] + rows[y + 6][c]) + 34 * (rows[y + 1][c] + rows[y + 5][c]) +
+                          49 * (rows[y + 2][c] + rows[y + 4][c]) + 55 * rows[y + 3][c];
+                int v = (acc + (1 << 15)) >> 16;
+                v = min(v, 255);
+                out |= (uint32_t)v << (8 * i);
+            }
+            *reinterpret_cast<uint32_t*>(D + (size_t)(by + y) * L.stride + bx + x4) = out;
+        }
+        if (!more) break;
+        __syncthreads();
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)f * dframe + (size_t)(by + y) * dstride + bx + x4) = out;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -683,6 +890,9 @@ __global__ void decode_candidates_kernel(const OrbLevel* __restrict__ levels, in
 extern "C++" {
 
 hipError_t orbk_upload_pattern(hipStream_t st) {
+    static const DiscTable disc = make_disc();
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_disc), &disc, sizeof(disc), 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pattern), slamit_orb_pattern, SLAMIT_ORB_PATTERN_INTS, 0,
                                   hipMemcpyHostToDevice, st);
 }
@@ -695,12 +905,39 @@ void orbk_resize(hipStream_t st, const uint8_t* src, int sw, int sh, size_t sstr
                        dh, dstride, dframe, xofs, ialpha, yofs, ibeta);
 }
 
+hipError_t orbk_pyramid_prepare(int smem_bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_fused_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+}
+
+void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const PyrBox* boxes, const PyrTabs* tabs,
+                  int nregions, const uint8_t* img0, size_t img0_stride, size_t img0_frame, uint8_t* pyr, int bufA_bytes,
+                  int smem_bytes, int nframes) {
+    hipLaunchKernelGGL(pyramid_fused_kernel, dim3(nregions, nframes), dim3(PYR_THREADS), smem_bytes, st, levels, nlevels, boxes,
+                       tabs, img0, img0_stride, img0_frame, pyr, bufA_bytes);
+}
+
+size_t orbk_fast_smem(int max_wcell, int max_hcell) {
+    const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
+    const int list_cap = max_wcell * max_hcell, kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
+    const int per_wave = (tile_rows * TILE_PITCH + sc_rows * SC_PITCH + 2 * list_cap + 2 * kp_cap + 15) & ~15;
+    return (size_t)4 * per_wave;
+}
+
+hipError_t orbk_fast_prepare(int max_wcell, int max_hcell) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)orbk_fast_smem(max_wcell, max_hcell));
+}
+
 void orbk_fast(hipStream_t st, const OrbLevel* levels, int nlevels, int cells_per_frame,
                const uint8_t* img0, size_t img0_stride, size_t img0_frame, const uint8_t* pyr,
                unsigned long long* cand, size_t cand_frame_stride, int* cand_count, int iniTh, int minTh,
-               int nframes) {
-    hipLaunchKernelGGL(fast_cells_kernel, dim3(cells_per_frame, nframes), dim3(256), 0, st, levels, nlevels,
-                       img0, img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh);
+               int max_wcell, int max_hcell, int nframes) {
+    const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
+    const int list_cap = max_wcell * max_hcell, kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
+    hipLaunchKernelGGL(fast_cells_kernel, dim3((cells_per_frame + 3) / 4, nframes), dim3(256),
+                       orbk_fast_smem(max_wcell, max_hcell), st, levels, nlevels, cells_per_frame, img0, img0_stride,
+                       img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows, sc_rows, list_cap, kp_cap);
 }
 
 size_t orbk_octree_smem(int node_cap) {
@@ -729,10 +966,10 @@ void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const ui
                        nlevels, img0, img0_stride, img0_frame, pyr, lkp, kp_frame_stride, kp_count);
 }
 
-void orbk_blur(hipStream_t st, const uint8_t* src, int w, int h, size_t sstride, size_t sframe, uint8_t* dst,
-               size_t dstride, size_t dframe, int nframes) {
-    hipLaunchKernelGGL(blur_level_kernel, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(256), 0, st, src, w,
-                       h, sstride, sframe, dst, dstride, dframe);
+void orbk_blur(hipStream_t st, const OrbLevel* levels, int nlevels, int total_tiles, const uint8_t* img0,
+               size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes) {
+    hipLaunchKernelGGL(blur_all_kernel, dim3(total_tiles, nframes), dim3(256), 0, st, levels, nlevels, img0, img0_stride,
+                       img0_frame, pyr, blur);
 }
 
 void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,

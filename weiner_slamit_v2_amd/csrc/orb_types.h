@@ -28,6 +28,7 @@ struct OrbLevel {
     int32_t maxBorderX, maxBorderY;   // w - 16, h - 16
     int32_t cell_base;         // index of this level's first cell in the per-frame cell list
     int32_t ncells;
+    int32_t blur_tile_base;    // index of this level's first 64x16 blur tile in the per-frame tile list
     // candidate list of (frame, level): cand + cand_off + frame * cand_frame_stride  (elements)
     uint64_t cand_off;
     int32_t cand_cap;
@@ -40,6 +41,18 @@ struct OrbLevel {
     int32_t kp_off, kp_cap;    // kp_cap = node capacity = max(quota, 4*nIni) + 4
     float scale;               // mvScaleFactor[level]
     float patch_size;          // (float)(int)(31 * scale)
+};
+
+// Fused pyramid: one workgroup builds ALL levels of one image region, each level out of the
+// previous one held in LDS.  Per (block, level): the region whose pixels this block stores to HBM
+// ("own") and the superset it has to compute because deeper levels read it ("need").
+struct PyrBox {
+    int16_t ox0, oy0, ox1, oy1;
+    int16_t nx0, ny0, nx1, ny1;
+};
+struct PyrTabs {               // cv::resize coefficient tables of level l (from level l-1), device pointers
+    const int32_t* xofs; const int16_t* ialpha;
+    const int32_t* yofs; const int16_t* ibeta;
 };
 
 struct OrbLevelKp {            // a keypoint in level coordinates, after the octree
