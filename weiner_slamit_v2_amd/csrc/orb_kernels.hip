@@ -168,22 +168,22 @@ __global__ __launch_bounds__(PYR_THREADS) void pyramid_fused_kernel(
 // vToDistributeKeys order (cell row, cell col, y, x); the octree only needs that order to break
 // response ties, so the list itself may be unordered.
 // --------------------------------------------------------------------------------------------
-#define TILE_PITCH 72
-#define SC_PITCH 64
+#define SC_COL0 4   // scan pixel x sits at LDS column x + 4 in both the image tile and the score tile
 
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(min(a, b), c); }
 
+template <int PITCH>
 __device__ __forceinline__ int fast_score(const uint8_t* t) {
     // ring in the order of cv::FAST's 16-pattern: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
     // (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
     int r[16];
-    r[0] = t[3 * TILE_PITCH + 0];   r[1] = t[3 * TILE_PITCH + 1];   r[2] = t[2 * TILE_PITCH + 2];
-    r[3] = t[1 * TILE_PITCH + 3];   r[4] = t[3];                    r[5] = t[-1 * TILE_PITCH + 3];
-    r[6] = t[-2 * TILE_PITCH + 2];  r[7] = t[-3 * TILE_PITCH + 1];  r[8] = t[-3 * TILE_PITCH + 0];
-    r[9] = t[-3 * TILE_PITCH - 1];  r[10] = t[-2 * TILE_PITCH - 2]; r[11] = t[-1 * TILE_PITCH - 3];
-    r[12] = t[-3];                  r[13] = t[1 * TILE_PITCH - 3];  r[14] = t[2 * TILE_PITCH - 2];
-    r[15] = t[3 * TILE_PITCH - 1];
+    r[0] = t[3 * PITCH + 0];   r[1] = t[3 * PITCH + 1];   r[2] = t[2 * PITCH + 2];
+    r[3] = t[1 * PITCH + 3];   r[4] = t[3];               r[5] = t[-1 * PITCH + 3];
+    r[6] = t[-2 * PITCH + 2];  r[7] = t[-3 * PITCH + 1];  r[8] = t[-3 * PITCH + 0];
+    r[9] = t[-3 * PITCH - 1];  r[10] = t[-2 * PITCH - 2]; r[11] = t[-1 * PITCH - 3];
+    r[12] = t[-3];             r[13] = t[1 * PITCH - 3];  r[14] = t[2 * PITCH - 2];
+    r[15] = t[3 * PITCH - 1];
     const int v = t[0];
     int hi3[16], lo3[16];
 #pragma unroll
@@ -191,42 +191,52 @@ __device__ __forceinline__ int fast_score(const uint8_t* t) {
         hi3[k] = imax3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
         lo3[k] = imin3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
     }
-    int dm = 255, bm = 0;  // min over arcs of the arc's max; max over arcs of the arc's min
+    int h9[16], l9[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        dm = min(dm, imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
-        bm = max(bm, imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+        h9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+        l9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
     }
+    // min over arcs of the arc's max; max over arcs of the arc's min (3-input trees)
+    const int dm = imin3(imin3(imin3(h9[0], h9[1], h9[2]), imin3(h9[3], h9[4], h9[5]), imin3(h9[6], h9[7], h9[8])),
+                         imin3(imin3(h9[9], h9[10], h9[11]), imin3(h9[12], h9[13], h9[14]), h9[15]), 255);
+    const int bm = imax3(imax3(imax3(l9[0], l9[1], l9[2]), imax3(l9[3], l9[4], l9[5]), imax3(l9[6], l9[7], l9[8])),
+                         imax3(imax3(l9[9], l9[10], l9[11]), imax3(l9[12], l9[13], l9[14]), l9[15]), 0);
     return max(v - dm, bm - v) - 1;
 }
 
-// One WAVEFRONT per cell (4 cells per workgroup): every step below is wave-synchronous, so there is
-// no s_barrier anywhere; list appends use ballot + popcount with the running count in a
-// wave-uniform register, so there are no LDS atomics either.
+// One WAVEFRONT per cell (4 cells per workgroup): every step is wave-synchronous (no s_barrier), list
+// appends use ballot + popcount with the running count in a wave-uniform register (no LDS atomics),
+// and a wave needs < 5 KB of LDS for the usual <= 40-pixel cells so 8 waves fit per SIMD: on gfx950
+// this kernel is bound by instruction ISSUE (~1 instruction / 4 cycles / SIMD, measured with
+// SQ_ACTIVE_INST_ANY), so occupancy that lets SALU/LDS/VMEM issue beside VALU is what pays.
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
+#define FAST_LIST_CAP 448   // flushed to the scoring step whenever fewer than 256 slots are free
+
+template <int PITCH>
 __global__ __launch_bounds__(256) void fast_cells_kernel(
     const OrbLevel* __restrict__ levels, int nlevels, int cells_per_frame,
-    const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
+    const uint8_t* __restrict__ img0, unsigned img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr,
     unsigned long long* __restrict__ cand, size_t cand_frame_stride,
-    int* __restrict__ cand_count, int iniTh, int minTh, int tile_rows, int sc_rows, int list_cap, int kp_cap) {
+    int* __restrict__ cand_count, int iniTh, int minTh, int tile_rows, int sc_rows, int kp_cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int frame = blockIdx.y;
     const int cell = blockIdx.x * 4 + wv;
     if (cell >= cells_per_frame) return;
-    // per-wave LDS carve
-    const int tile_bytes = tile_rows * TILE_PITCH, sc_bytes = sc_rows * SC_PITCH;
-    const int per_wave = (tile_bytes + sc_bytes + 2 * list_cap + 2 * kp_cap + 15) & ~15;
-    uint8_t* tile = fsm + (size_t)wv * per_wave;
+    // per-wave LDS carve: image tile | score tile | survivor list | keypoint list
+    const int tile_bytes = tile_rows * PITCH + 16, sc_bytes = sc_rows * PITCH;
+    const int per_wave = (tile_bytes + sc_bytes + 2 * FAST_LIST_CAP + 2 * kp_cap + 15) & ~15;
+    uint8_t* tile = fsm + wv * per_wave;
     uint8_t* sc = tile + tile_bytes;
     unsigned short* s_list = reinterpret_cast<unsigned short*>(sc + sc_bytes);
-    unsigned short* s_kp = s_list + list_cap;
+    unsigned short* s_kp = s_list + FAST_LIST_CAP;
 
     int level = 0;
     while (level + 1 < nlevels && cell >= levels[level + 1].cell_base) ++level;
@@ -241,87 +251,143 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     if (sw <= 0 || sh <= 0) return;
 
     const uint8_t* src;
-    size_t stride;
-    if (level == 0) {
-        src = img0 + (size_t)frame * img0_frame;
-        stride = img0_stride;
-    } else {
-        src = pyr + L.plane_off + (size_t)frame * L.plane_bytes;
-        stride = (size_t)L.stride;
-    }
+    unsigned stride;
+    if (level == 0) { src = img0 + (size_t)frame * img0_frame; stride = img0_stride; }
+    else { src = pyr + L.plane_off + (size_t)frame * L.plane_bytes; stride = (unsigned)L.stride; }
     src += (size_t)iniY * stride + iniX;
 
-    // stage the window (rows of <= 65 contiguous bytes; neighbouring cells share L2 lines)
-    const int npx = cw * ch;
-    const unsigned inv_cw = (1u << 20) / (unsigned)cw + 1;  // exact p / cw for p*cw < 2^20
-    for (int p = lane; p < npx; p += WAVE) {
-        int r = (int)(((unsigned)p * inv_cw) >> 20);
-        int cc = p - r * cw;
-        tile[r * TILE_PITCH + cc] = src[(size_t)r * stride + cc];
+    // ---- stage the window: window column j -> LDS column j + 1 (so that scan pixel x is at x + 4) ----
+    // Each lane builds one aligned LDS dword from two aligned global dwords (v_alignbyte).  The window
+    // lies >= 15 px inside the image row, so the 8 bytes around it are always inside the row.
+    {
+        const unsigned shift = (unsigned)((uintptr_t)(src - 1) & 3);
+        const uint8_t* abase = src - 1 - shift;            // 4-byte aligned iff the row pitch is
+        const bool aligned = (stride & 3) == 0;
+        const int nd = (cw + 1 + 3) >> 2;                  // dwords per row (LDS cols 0 .. cw)
+        const int rows_per_it = 64 / nd > 0 ? 64 / nd : 1;
+        const int rsub = lane / nd, d = lane - rsub * nd;
+        if (aligned) {
+            for (int r0 = 0; r0 < ch; r0 += rows_per_it) {
+                const int r = r0 + rsub;
+                if (rsub < rows_per_it && r < ch) {
+                    const uint32_t* g = reinterpret_cast<const uint32_t*>(abase + __umul24(r, stride)) + d;
+                    const uint32_t lo = g[0], hi = g[1];
+                    *reinterpret_cast<uint32_t*>(&tile[r * PITCH + 4 * d]) = __builtin_amdgcn_alignbyte(hi, lo, shift);
+                }
+            }
+        } else {
+            const int npx = cw * ch;
+            const unsigned inv_cw = (1u << 20) / (unsigned)cw + 1;
+            for (int p = lane; p < npx; p += WAVE) {
+                const int r = (int)(__umul24(p, inv_cw) >> 20);
+                const int cc = p - r * cw;
+                tile[r * PITCH + cc + 1] = src[__umul24(r, stride) + cc];
+            }
+        }
     }
     for (int i = lane; i < sc_bytes / 4; i += WAVE) reinterpret_cast<uint32_t*>(sc)[i] = 0;
     wave_sync_lds();
-    const int nscan = sw * sh;
+
+    const int ngrp = (sw + 3) >> 2;          // groups of 4 scan pixels per row
+    const int nitems = ngrp * sh;
+    const unsigned inv_g = (1u << 20) / (unsigned)ngrp + 1;
     const unsigned inv_sw = (1u << 20) / (unsigned)sw + 1;
 
     // Two attempts like the reference: FAST at iniThFAST, and only if the cell stays empty, again at
     // minThFAST (ORBextractor.cc:827-833).  Per attempt:
-    //  A. compass pre-test (necessary condition: a 9-arc of the 16-ring always holds two adjacent
-    //     compass pixels, so two adjacent ones must both be brighter than v+t or both darker than v-t);
-    //     survivors are compacted into a list so that
-    //  B. the exact score is computed with every lane busy, stored if >= t,
-    //  C. NMS over the survivors (strict >, 8 neighbours, zeros outside the scan area / below t).
+    //  A. compass pre-test, 4 pixels per lane with byte-parallel arithmetic (necessary condition: a
+    //     9-arc of the 16-ring always holds two adjacent compass pixels, so two adjacent ones must
+    //     both be brighter than v+t or both darker than v-t); survivors are compacted into a list,
+    //  B. the exact score of every survivor, all lanes busy; stored if >= t,
+    //  C. NMS (strict >, 8 neighbours, zeros outside the scan area / below t) over the score tile.
     int th = iniTh;
     int nkp = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
+        // For bytes a (ring) and c (centre): a - c > t  <=>  a + (255 - c) >= t + 256.  v_lerp_u8 gives
+        // (a + ~c + r) >> 1 per byte with a 9-bit intermediate; with r = parity of t the test becomes
+        // d >= K on bytes, and a second lerp against 256 - K leaves the answer in each byte's MSB.
+        const int T = th + 256;
+        const unsigned rb = (T & 1) ? 0x01010101u : 0u;
+        const int Kv = (T + 1) >> 1;                       // 129..256
+        const unsigned kc = (unsigned)(256 - Kv) * 0x01010101u;
         int nlist = 0;
-        for (int p0 = 0; p0 < nscan; p0 += WAVE) {
-            const int p = p0 + lane;
-            int pass = 0;
-            if (p < nscan) {
-                const int y = (int)(((unsigned)p * inv_sw) >> 20);
-                const int x = p - y * sw;
-                const uint8_t* t = &tile[(y + 3) * TILE_PITCH + x + 3];
-                const int v = t[0];
-                const int s0 = t[3 * TILE_PITCH], e0 = t[3], n0 = t[-3 * TILE_PITCH], w0 = t[-3];
-                const int hi = v + th, lo = v - th;
-                const int bs = s0 > hi, be = e0 > hi, bn = n0 > hi, bw = w0 > hi;
-                const int ds = s0 < lo, de = e0 < lo, dn = n0 < lo, dw = w0 < lo;
-                pass = (bs & be) | (be & bn) | (bn & bw) | (bw & bs) | (ds & de) | (de & dn) | (dn & dw) | (dw & ds);
-            }
-            const unsigned long long m = __ballot(pass);
-            if (pass) s_list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
-            nlist += __popcll(m);
-        }
-        wave_sync_lds();
-        for (int i = lane; i < nlist; i += WAVE) {
-            const int p = s_list[i];
-            const int y = (int)(((unsigned)p * inv_sw) >> 20);
-            const int x = p - y * sw;
-            const int S = fast_score(&tile[(y + 3) * TILE_PITCH + x + 3]);
-            sc[(y + 1) * SC_PITCH + x + 1] = (uint8_t)(S >= th ? S : 0);
-        }
-        wave_sync_lds();
-        nkp = 0;
-        for (int i0 = 0; i0 < nlist; i0 += WAVE) {
-            const int i = i0 + lane;
-            int keep = 0, p = 0;
-            if (i < nlist) {
-                p = s_list[i];
-                const int y = (int)(((unsigned)p * inv_sw) >> 20);
-                const int x = p - y * sw;
-                const uint8_t* s = &sc[(y + 1) * SC_PITCH + x + 1];
-                const int v = s[0];
-                if (v) {
-                    int nb = imax3(s[-SC_PITCH - 1], s[-SC_PITCH], s[-SC_PITCH + 1]);
-                    nb = imax3(nb, s[-1], s[1]);
-                    nb = max(nb, imax3(s[SC_PITCH - 1], s[SC_PITCH], s[SC_PITCH + 1]));
-                    keep = v > nb;
+        for (int i0 = 0; i0 < nitems || nlist > 0; i0 += WAVE) {
+            if (i0 < nitems) {
+                const int it = i0 + lane;
+                unsigned flags = 0;
+                int y = 0, x0 = 0;
+                if (it < nitems) {
+                    y = (int)(__umul24(it, inv_g) >> 20);
+                    x0 = (it - y * ngrp) * 4;
+                    const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(y + 3) * PITCH + x0 + SC_COL0]);
+                    const unsigned C = rowc[0], Dm = rowc[-1], Dp = rowc[1];
+                    const unsigned N = *reinterpret_cast<const uint32_t*>(&tile[y * PITCH + x0 + SC_COL0]);
+                    const unsigned S = *reinterpret_cast<const uint32_t*>(&tile[(y + 6) * PITCH + x0 + SC_COL0]);
+                    const unsigned E = __builtin_amdgcn_alignbyte(Dp, C, 3);   // columns x0+3 .. x0+6
+                    const unsigned Wv = __builtin_amdgcn_alignbyte(C, Dm, 1);  // columns x0-3 .. x0
+                    const unsigned nC = ~C;
+#define BRIGHT(a) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp((a), nC, rb), kc, 0u)
+#define DARK(a) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~(a), rb), kc, 0u)
+                    const unsigned bN = BRIGHT(N), bE = BRIGHT(E), bS = BRIGHT(S), bW = BRIGHT(Wv);
+                    const unsigned dN = DARK(N), dE = DARK(E), dS = DARK(S), dW = DARK(Wv);
+#undef BRIGHT
+#undef DARK
+                    flags = ((bN & bE) | (bE & bS) | (bS & bW) | (bW & bN) | (dN & dE) | (dE & dS) | (dS & dW) | (dW & dN)) & 0x80808080u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pass = ((flags >> (8 * j + 7)) & 1u) && (x0 + j < sw);
+                    const unsigned long long m = __ballot(pass);
+                    if (pass) s_list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(y * sw + x0 + j);
+                    nlist += __popcll(m);
                 }
             }
-            const unsigned long long m = __ballot(keep);
-            if (keep) s_kp[nkp + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
-            nkp += __popcll(m);
+            // score the listed pixels once the list could overflow, and at the end
+            if (nlist > FAST_LIST_CAP - 256 || i0 + WAVE >= nitems) {
+                wave_sync_lds();
+                for (int i = lane; i < nlist; i += WAVE) {
+                    const int p = s_list[i];
+                    const int y = (int)(__umul24(p, inv_sw) >> 20);
+                    const int x = p - y * sw;
+                    const int S = fast_score<PITCH>(&tile[(y + 3) * PITCH + x + SC_COL0]);
+                    sc[(y + 1) * PITCH + x + SC_COL0] = (uint8_t)(S >= th ? S : 0);
+                }
+                wave_sync_lds();
+                nlist = 0;
+            }
+        }
+        // NMS straight off the score tile, 4 pixels per lane, zero dwords skipped
+        nkp = 0;
+        for (int i0 = 0; i0 < nitems; i0 += WAVE) {
+            const int it = i0 + lane;
+            unsigned keep = 0;
+            int y = 0, x0 = 0;
+            if (it < nitems) {
+                y = (int)(__umul24(it, inv_g) >> 20);
+                x0 = (it - y * ngrp) * 4;
+                const uint8_t* s = &sc[(y + 1) * PITCH + x0 + SC_COL0];
+                const unsigned cur = *reinterpret_cast<const uint32_t*>(s);
+                if (cur) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int v = (cur >> (8 * j)) & 0xFF;
+                        if (v) {
+                            const uint8_t* q = s + j;
+                            int nb = imax3(q[-PITCH - 1], q[-PITCH], q[-PITCH + 1]);
+                            nb = imax3(nb, q[-1], q[1]);
+                            nb = max(nb, imax3(q[PITCH - 1], q[PITCH], q[PITCH + 1]));
+                            if (v > nb) keep |= 1u << j;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = (keep >> j) & 1u;
+                const unsigned long long m = __ballot(k);
+                if (k) s_kp[nkp + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(y * sw + x0 + j);
+                nkp += __popcll(m);
+            }
         }
         wave_sync_lds();
         if (nkp > 0 || minTh >= th) break;  // found corners, or the retry cannot find more
@@ -334,9 +400,9 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     unsigned long long* out = cand + L.cand_off + (size_t)frame * cand_frame_stride;
     for (int i = lane; i < nkp; i += WAVE) {
         const int p = s_kp[i];
-        const int y = (int)(((unsigned)p * inv_sw) >> 20);
+        const int y = (int)(__umul24(p, inv_sw) >> 20);
         const int x = p - y * sw;
-        const unsigned S = sc[(y + 1) * SC_PITCH + x + 1];
+        const unsigned S = sc[(y + 1) * PITCH + x + SC_COL0];
         const unsigned order = ((unsigned)c << 12) | ((unsigned)(y + 3) << 6) | (unsigned)(x + 3);
         const int o = base + i;
         if (o < L.cand_cap) out[o] = ((unsigned long long)S << 32) | order;
@@ -917,16 +983,21 @@ void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const Pyr
                        tabs, img0, img0_stride, img0_frame, pyr, bufA_bytes);
 }
 
+static int fast_pitch(int max_wcell) { return max_wcell + 11 <= 48 ? 48 : 72; }  // LDS columns 0 .. sw + 10 are touched
+
 size_t orbk_fast_smem(int max_wcell, int max_hcell) {
+    const int P = fast_pitch(max_wcell);
     const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
-    const int list_cap = max_wcell * max_hcell, kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
-    const int per_wave = (tile_rows * TILE_PITCH + sc_rows * SC_PITCH + 2 * list_cap + 2 * kp_cap + 15) & ~15;
+    const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
+    const int per_wave = (tile_rows * P + 16 + sc_rows * P + 2 * FAST_LIST_CAP + 2 * kp_cap + 15) & ~15;
     return (size_t)4 * per_wave;
 }
 
 hipError_t orbk_fast_prepare(int max_wcell, int max_hcell) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)orbk_fast_smem(max_wcell, max_hcell));
+    const int smem = (int)orbk_fast_smem(max_wcell, max_hcell);
+    if (fast_pitch(max_wcell) == 48)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<72>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 void orbk_fast(hipStream_t st, const OrbLevel* levels, int nlevels, int cells_per_frame,
@@ -934,10 +1005,17 @@ void orbk_fast(hipStream_t st, const OrbLevel* levels, int nlevels, int cells_pe
                unsigned long long* cand, size_t cand_frame_stride, int* cand_count, int iniTh, int minTh,
                int max_wcell, int max_hcell, int nframes) {
     const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
-    const int list_cap = max_wcell * max_hcell, kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
-    hipLaunchKernelGGL(fast_cells_kernel, dim3((cells_per_frame + 3) / 4, nframes), dim3(256),
-                       orbk_fast_smem(max_wcell, max_hcell), st, levels, nlevels, cells_per_frame, img0, img0_stride,
-                       img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows, sc_rows, list_cap, kp_cap);
+    const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
+    const dim3 grid((cells_per_frame + 3) / 4, nframes);
+    const size_t smem = orbk_fast_smem(max_wcell, max_hcell);
+    if (fast_pitch(max_wcell) == 48)
+        hipLaunchKernelGGL(fast_cells_kernel<48>, grid, dim3(256), smem, st, levels, nlevels, cells_per_frame, img0,
+                           (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
+                           sc_rows, kp_cap);
+    else
+        hipLaunchKernelGGL(fast_cells_kernel<72>, grid, dim3(256), smem, st, levels, nlevels, cells_per_frame, img0,
+                           (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
+                           sc_rows, kp_cap);
 }
 
 size_t orbk_octree_smem(int node_cap) {
