@@ -33,6 +33,19 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
 
+def measured_traffic(batch):
+    """HBM bytes per launch of the FAST kernel from the committed rocprofv3 PMC summary
+    (profiles/r01_hbm_traffic.json, produced by tools/collect_profiles.sh on the same kernel);
+    FETCH_SIZE + WRITE_SIZE, scaled to this run's frames per launch.  None if absent."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        k = [v for n, v in doc["kernels"].items() if n.startswith("fast_cells_kernel")][0]
+        kb = k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]
+        return int(kb * 1024 * batch / doc["frames_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(frames_a, frames_b, budget_s=12.0, min_frames=16):
     """The CPU oracle (port of the reference path) on one host core over a bounded sample of the
     same workload: extract frame A_i, extract B_i, match B_i against A_i."""
@@ -193,7 +206,8 @@ def main():
                                    "%d independent streams per GPU per step" % B,
                        "frames_per_step_per_gpu": B, "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"kernel": "fast_cells_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(B),
+                         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)",
                          "avg_launch_ms": round(fast_avg_ms, 5), "launches": fast_calls,
                          "algorithmic_bytes_per_launch": FAST_BYTES_PER_FRAME * B},
             "stage_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in stages.items()},
