@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libslamit_hip.so")
+LIB_PATH = os.environ.get("SLAMIT_LIB", os.path.join(HERE, "libslamit_hip.so"))  # override only for diagnostic builds
 
 KP_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),

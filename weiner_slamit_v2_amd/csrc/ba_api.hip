@@ -5,6 +5,7 @@
 // ba_kernels.hip; there is no CPU solve path.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -265,6 +266,15 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
+    if (getenv("SLAMIT_BA_DIAG"))  // diagnostic builds only: in-kernel clock of the last LDLt launch
+        fprintf(stderr, "[ba diag] ldlt shader cycles %llu, realtime ticks (100 MHz) %llu -> %.0f MHz, %.1f us\n",
+                hs[0].dbg[2] - hs[0].dbg[0], hs[0].dbg[3] - hs[0].dbg[1],
+                100.0 * (double)(hs[0].dbg[2] - hs[0].dbg[0]) / (double)(hs[0].dbg[3] - hs[0].dbg[1] + 1),
+                (double)(hs[0].dbg[3] - hs[0].dbg[1]) / 100.0);
+    if (getenv("SLAMIT_BA_DIAG"))
+        fprintf(stderr, "[ba diag] ldlt phase cycles: load %llu factor %llu rows %llu writeback %llu trailing %llu backsub %llu\n",
+                hs[0].dbg[4] >> 32, hs[0].dbg[4] & 0xffffffffull, hs[0].dbg[5] >> 32, hs[0].dbg[5] & 0xffffffffull,
+                hs[0].dbg[6] >> 32, hs[0].dbg[6] & 0xffffffffull);
     for (int b = 0; b < nwin; ++b) {
         slamit_ba_stats* S = results[b].stats;
         if (!S) continue;

@@ -404,6 +404,77 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins) {
 #define LD_THREADS 512
 #define LD_PAIRS (LD_NB * (LD_NB - 1) / 2)
 
+// Factor one 32x32 diagonal block in LDS (unit L below, D on the diagonal) with the whole
+// workgroup: at step k thread p updates one (r, c) pair of the trailing triangle,
+// a[r][c] -= a[r][k] a[c][k] / d_k, one barrier per step.  (Register-resident variants of this
+// serial section — row per lane with v_readlane or ds_bpermute broadcasts — made hipcc spill
+// SGPRs/VGPRs to scratch, ~1 us per reload; the LDS form is the robust one.)
+__device__ __forceinline__ double fast_recip(double d) {
+    double x = __builtin_amdgcn_rcp(d);   // v_rcp_f64
+    x = x * (2.0 - d * x);                // one Newton step: ~1e-16 relative, no v_div_* sequence
+    return x;
+}
+
+__device__ __forceinline__ void ldlt_factor_diag(double* Dg, double* s_invd, const unsigned char* s_pr,
+                                                 const unsigned char* s_pc, const short* s_off, int nb, int tid,
+                                                 int* s_fail) {
+    // Column k is never written once step k starts (updates touch columns > k), so the unit-L entries
+    // are produced at the very end from the untouched (L*d) columns and a step needs ONE barrier.
+    for (int k = 0; k < nb; ++k) {
+        const double d = Dg[k * LD_P + k];
+        const bool bad = (d == 0.0 || !(fabs(d) <= DBL_MAX));
+        const double invd = bad ? 0.0 : fast_recip(d);
+        const int p = s_off[k + 1] + tid;
+        if (p < LD_PAIRS) {
+            const int r = s_pr[p], c = s_pc[p];
+            if (r < nb) Dg[r * LD_P + c] -= Dg[r * LD_P + k] * Dg[c * LD_P + k] * invd;
+        }
+        if (tid == 0) { s_invd[k] = invd; if (bad) *s_fail = 1; }
+        __syncthreads();
+    }
+    for (int k = nb + tid; k < LD_NB; k += LD_THREADS) s_invd[k] = 0.0;
+    // scale the strictly-lower part: L[r][c] = (L d)[r][c] / d_c
+    for (int i = tid; i < LD_NB * LD_NB; i += LD_THREADS) {
+        const int r = i >> 5, c = i & 31;
+        if (r < nb && c < r) Dg[r * LD_P + c] *= s_invd[c];
+    }
+}
+
+// rows below (and the rhs row): w_k = a_k - sum_{m<k} w_m L11[k][m]   (w = L*d), row in registers
+__device__ __forceinline__ void ldlt_rows(double* Wd, const double* Dg, int rows, int tid) {
+    for (int r = tid; r < rows; r += LD_THREADS) {
+        double* wrow = Wd + r * LD_P;
+        double w[LD_NB];
+#pragma unroll
+        for (int k = 0; k < LD_NB; ++k) w[k] = wrow[k];
+#pragma unroll
+        for (int k = 1; k < LD_NB; ++k) {
+            double a = w[k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) a -= w[m] * Dg[k * LD_P + m];
+            w[k] = a;
+            __builtin_amdgcn_sched_barrier(0);  // keep the 496 LDS reads from being hoisted (spills)
+        }
+#pragma unroll
+        for (int k = 1; k < LD_NB; ++k) wrow[k] = w[k];
+    }
+}
+
+// back-substitution inside one 32-row block: lane k owns x_k, the columns of L11 sit in registers
+__device__ __forceinline__ void ldlt_back_block(const double* S, int N, double* xs, int jb, int nb, int lane) {
+    const int k = lane;
+    double v = (k < nb) ? xs[jb + k] : 0.0;
+    double col[LD_NB];
+#pragma unroll
+    for (int m = 0; m < LD_NB; ++m) col[m] = (k < nb && m < nb && m > k) ? S[(size_t)(jb + m) * N + jb + k] : 0.0;
+#pragma unroll
+    for (int m = LD_NB - 1; m >= 0; --m) {
+        const double xm = readlane_d(v, m);   // final once every higher index has been applied
+        if (m < nb && k < m) v -= col[m] * xm;
+    }
+    if (k < nb) xs[jb + k] = v;
+}
+
 __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
     BaState* st = W.st;
@@ -427,6 +498,13 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
         s_off[LD_NB] = (short)p;
     }
     if (n == 0) { if (tid == 0) st->ok2 = 1; return; }
+#ifdef BA_DIAG_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[i] += tn - tprev; tprev = tn; } while (0)
+    if (tid == 0) { st->dbg[0] = tprev; st->dbg[1] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define STAMP(i)
+#endif
     double* S = W.S;
     for (int i = tid; i < n; i += LD_THREADS) S[(size_t)n * N + i] = W.rhs[i];  // rhs as row n
     __syncthreads();
@@ -445,61 +523,28 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
                 const int r = i >> 5, c = i & 31;
                 if (r >= nb || c >= nb) Dg[r * LD_P + c] = 0.0;
             }
-        for (int i = tid; i < rows16 * LD_NB; i += LD_THREADS) {
-            const int r = i >> 5, c = i & 31;
-            Wd[r * LD_P + c] = (r < rows && c < nb) ? S[(size_t)(base + r) * N + jb + c] : 0.0;
+        for (int i0 = tid; i0 < rows16 * LD_NB; i0 += 8 * LD_THREADS) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {   // issue all loads first: the L2 round trip is paid once per batch
+                const int i = i0 + u * LD_THREADS, r = i >> 5, c = i & 31;
+                v[u] = (i < rows16 * LD_NB && r < rows && c < nb) ? S[(size_t)(base + r) * N + jb + c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * LD_THREADS, r = i >> 5, c = i & 31;
+                if (i < rows16 * LD_NB) Wd[r * LD_P + c] = v[u];
+            }
         }
         __syncthreads();
-        if (wv == 0) {
-            // factor the diagonal block with lane r holding row r in registers: at step k the pivot
-            // and the column entries a[c][k] of the other rows arrive by cross-lane shuffles.
-            // Rows/cols >= nb are padded with the identity.
-            const int r = lane & 31;
-            double row[LD_NB];
-#pragma unroll
-            for (int c = 0; c < LD_NB; ++c) row[c] = (r < nb && c < nb) ? Dg[r * LD_P + c] : (r == c ? 1.0 : 0.0);
-            int fail = 0;
-#pragma unroll
-            for (int k = 0; k < LD_NB; ++k) {
-                const double d = readlane_d(row[k], k);
-                const bool bad = (d == 0.0 || !(fabs(d) <= DBL_MAX));
-                fail |= bad;
-                const double invd = bad ? 0.0 : 1.0 / d;
-                const double lrk = row[k] * invd;          // L[r][k] (meaningful for r > k)
-#pragma unroll
-                for (int c = k + 1; c < LD_NB; ++c) {
-                    const double ack = readlane_d(row[k], c);   // a[c][k], unscaled
-                    if (r >= c) row[c] -= lrk * ack;
-                }
-                if (r > k) row[k] = lrk;
-                if (lane == 0) s_invd[k] = (k < nb) ? invd : 0.0;
-            }
-            if (lane < 32 && r < nb) {
-#pragma unroll
-                for (int c = 0; c < LD_NB; ++c) if (c < nb) Dg[r * LD_P + c] = row[c];
-            }
-            if (lane == 0 && fail) s_fail = 1;
-        }
+        STAMP(0);
+        ldlt_factor_diag(Dg, s_invd, s_pr, s_pc, s_off, nb, tid, &s_fail);
+        STAMP(1);
         __syncthreads();
         if (s_fail) break;
-        // rows below (and the rhs row): w_k = a_k - sum_{m<k} w_m L11[k][m]   (w = L*d), row in registers
-        for (int r = tid; r < rows; r += LD_THREADS) {
-            double* wrow = Wd + r * LD_P;
-            double w[LD_NB];
-#pragma unroll
-            for (int k = 0; k < LD_NB; ++k) w[k] = wrow[k];
-#pragma unroll
-            for (int k = 1; k < LD_NB; ++k) {
-                double a = w[k];
-#pragma unroll
-                for (int m = 0; m < k; ++m) a -= w[m] * Dg[k * LD_P + m];
-                w[k] = a;
-                __builtin_amdgcn_sched_barrier(0);  // keep the 496 LDS reads from being hoisted (spills)
-            }
-#pragma unroll
-            for (int k = 1; k < LD_NB; ++k) wrow[k] = w[k];
-        }
+        ldlt_rows(Wd, Dg, rows, tid);
         __syncthreads();
+        STAMP(2);
         // write back the factored panel: L11 / D, and L21 = (L*d) / d
         for (int i = tid; i < nb * LD_NB; i += LD_THREADS) {
             const int r = i >> 5, c = i & 31;
@@ -510,6 +555,8 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
             if (c < nb) S[(size_t)(base + r) * N + jb + c] = Wd[r * LD_P + c] * s_invd[c];
         }
         // trailing update on MFMA: C[r][c] -= sum_k (w[r][k] invd[k]) w[c][k],  c <= r
+        STAMP(3);
+#ifndef LD_DIAG_SKIP_TRAIL
         const int RT = rows16 >> 4, CT = (below + 15) >> 4;
         // lower-triangular tile list: t -> (rt, ct), ct <= min(rt, CT-1); waves take 4 tiles at a time
         int ntile = 0;
@@ -550,48 +597,44 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
                 }
             }
         }
+#endif
         __syncthreads();
+        STAMP(4);
     }
     if (s_fail) {
         if (tid == 0) st->ok2 = 0;
         return;
     }
+#ifndef LD_DIAG_SKIP_BACK
     // ---- backward substitution x = L^-T y, y = row n of S ----
+    // Right-looking over 32-row blocks from the bottom: wavefront 0 solves the block's triangular
+    // system (lane k owns x_k, columns of L11 in registers, v_readlane broadcasts), then every
+    // earlier unknown i < jb takes y_i -= sum_m L[jb+m][i] * x_m, reading ROWS of L (coalesced).
     double* xs = Wd;                 // n doubles
-    double* red = Wd + N;            // 16 x 32 partial sums
     for (int i = tid; i < n; i += LD_THREADS) xs[i] = S[(size_t)n * N + i];
     __syncthreads();
     for (int jb = ((n - 1) / LD_NB) * LD_NB; jb >= 0; jb -= LD_NB) {
         const int nb = min(LD_NB, n - jb);
-        {
-            const int k = tid & (LD_NB - 1), part = tid >> 5;
-            double acc = 0;
-            if (k < nb)
-                for (int r = jb + nb + part; r < n; r += LD_THREADS / LD_NB) acc += S[(size_t)r * N + jb + k] * xs[r];
-            red[part * LD_NB + k] = acc;
-        }
+        if (wv == 0) ldlt_back_block(S, N, xs, jb, nb, lane);
         __syncthreads();
-        if (wv == 0) {
-            const int k = lane;
-            double v = 0;
-            double col[LD_NB];
-            if (k < nb) {
-                double t = 0;
-                for (int p2 = 0; p2 < LD_THREADS / LD_NB; ++p2) t += red[p2 * LD_NB + k];
-                v = xs[jb + k] - t;
-            }
+        for (int i = tid; i < jb; i += LD_THREADS) {
+            double acc = xs[i];
+            double lv[LD_NB];
 #pragma unroll
-            for (int m = 0; m < LD_NB; ++m) col[m] = (k < nb && m < nb && m > k) ? S[(size_t)(jb + m) * N + jb + k] : 0.0;
+            for (int m = 0; m < LD_NB; ++m) lv[m] = (m < nb) ? S[(size_t)(jb + m) * N + i] : 0.0;
 #pragma unroll
-            for (int m = LD_NB - 1; m >= 0; --m) {
-                const double xm = readlane_d(v, m);   // final once every higher index has been applied
-                if (m < nb && k < m) v -= col[m] * xm;
-            }
-            if (k < nb) xs[jb + k] = v;
+            for (int m = 0; m < LD_NB; ++m) acc -= lv[m] * xs[jb + m];
+            xs[i] = acc;
         }
         __syncthreads();
     }
     for (int i = tid; i < n; i += LD_THREADS) W.rhs[i] = xs[i];
+#endif
+#ifdef BA_DIAG_STAMPS
+    STAMP(5);
+    if (tid == 0) { st->dbg[2] = __builtin_amdgcn_s_memtime(); st->dbg[3] = __builtin_amdgcn_s_memrealtime();
+                    st->dbg[4] = (ph[0] << 32) | ph[1]; st->dbg[5] = (ph[2] << 32) | ph[3]; st->dbg[6] = (ph[4] << 32) | ph[5]; }
+#endif
     if (tid == 0) st->ok2 = 1;
 }
 

@@ -32,6 +32,7 @@ struct BaState {
     double lam[2][BA_MAX_ITS];
     int32_t trials[2][BA_MAX_ITS];
     double chi2_init[2];
+    unsigned long long dbg[8];  // diagnostic stamps (s_memtime / s_memrealtime); written only when BA_DIAG_STAMPS is defined
 };
 
 // One window.  All pointers are device addresses inside the handle's slabs.
