@@ -71,25 +71,45 @@ def cpu_baseline(frames_a, frames_b, budget_s=12.0, min_frames=16):
             "sample": "%d synthetic 640x480 frames, oracle extract (1000 feat, 8 lvl) + all-pairs best2 vs previous frame, %.1f s" % (n, el)}
 
 
-def ba_secondary(device, steps):
-    """local-BA LM iterations/sec, 50 KF x 2000 points (window-8 visibility, 16k edges)."""
+def ba_secondary(device, steps, with_cpu=True):
+    """local-BA LM iterations/sec on BASELINE config 4 (50 KF x 2000 points): window-8 visibility
+    (16,000 edges) and dense visibility (100,000 edges), single window and a batch of 8 windows,
+    next to the CPU oracle (port of the reference's g2o path, pinned to it) on one host core."""
     try:
         from weiner_slamit_v2_amd import api, synth
-        if not hasattr(api.lib(), "slamit_ba_create"):
-            return None
-        prob = synth.synth_ba(50, 2000, 8)
-        opt = api.Optimizer(64, 2048, len(prob["edge_kf"]) + 64, 1, device)
-        out = opt.LocalBundleAdjustment(prob)  # warm-up
-        t0 = time.perf_counter()
-        reps = max(3, min(steps, 10))
-        its = 0
-        for _ in range(reps):
-            out = opt.LocalBundleAdjustment(prob)
-            its += sum(out["stats"]["n_its"])
-        el = time.perf_counter() - t0
-        return {"metric": "local-BA LM iterations/sec (50 KF, 2000 pts, 16k edges, 5 robust + 10 plain)",
-                "value": round(its / el, 2), "unit": "iters/s", "dtype": "f64",
-                "ms_per_window": round(1e3 * el / reps, 3), "note": "end to end through the host-pointer C-ABI"}
+        out = {"metric": "local-BA LM iterations/sec (50 KF, 2000 pts; schedule 5 robust + 10 plain)", "unit": "iters/s",
+               "dtype": "f64", "note": "end to end through the host-pointer C-ABI (upload + solve + download)"}
+        for name, obs in (("window8", 8), ("dense", None)):
+            prob = synth.synth_ba(50, 2000, obs)
+            ne = len(prob["edge_kf"])
+            opt = api.Optimizer(64, 2048, ne + 64, 8, device)
+            opt.LocalBundleAdjustment(prob)  # warm-up
+            reps = max(3, min(steps, 10))
+            t0 = time.perf_counter()
+            its = 0
+            for _ in range(reps):
+                r = opt.LocalBundleAdjustment(prob)
+                its += sum(r["stats"]["n_its"])
+            el = time.perf_counter() - t0
+            opt.LocalBundleAdjustmentBatch([prob] * 8)
+            t1 = time.perf_counter()
+            rb = opt.LocalBundleAdjustmentBatch([prob] * 8)
+            elb = time.perf_counter() - t1
+            entry = {"edges": ne, "value": round(its / el, 1), "ms_per_window": round(1e3 * el / reps, 3),
+                     "batch8_value": round(sum(sum(x["stats"]["n_its"]) for x in rb) / elb, 1)}
+            # Schur product: one dense 2 * Npad^2/2 * Kpad flop MFMA launch per LM trial (DESIGN.md section 6)
+            if with_cpu:
+                from oracle import bindings as ob
+                t2 = time.perf_counter()
+                ro = ob.ba_solve(prob)
+                elc = time.perf_counter() - t2
+                entry["cpu_baseline"] = {"value": round(sum(ro["stats"]["n_its"]) / elc, 1), "unit": "iters/s", "cores": 1,
+                                         "kind": "port", "sample": "1 window, %.0f ms" % (1e3 * elc)}
+                entry["speedup_vs_cpu_1core"] = round(entry["value"] / entry["cpu_baseline"]["value"], 1)
+            out[name] = entry
+            opt.close()
+        out["value"] = out["window8"]["value"]
+        return out
     except Exception as e:  # the ORB line must still print
         return {"error": repr(e)}
 
@@ -217,7 +237,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(fa, fb)
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         if not args.no_ba:
-            out["secondary"] = ba_secondary(dev.index, args.steps)
+            out["secondary"] = ba_secondary(dev.index, args.steps, with_cpu=not args.no_cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

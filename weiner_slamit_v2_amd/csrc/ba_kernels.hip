@@ -335,14 +335,31 @@ __global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
     double4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0, 0, 0, 0};
+    // software pipeline: the next slab is fetched into registers while the current one feeds the MFMAs
+    double pa[8], pb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = tid + 256 * u, r = i >> 5, c = i & 31;
+        pa[u] = A[(size_t)r * K + k0 + c];
+        pb[u] = B[(size_t)r * K + k0 + c];
+    }
     for (int kk = k0; kk < k0 + kchunk; kk += BA_KC) {
         __syncthreads();
-        for (int i = tid; i < BA_TILE * BA_KC; i += 256) {
-            const int r = i >> 5, c = i & 31;
-            As[r * LDS_PITCH + c] = A[(size_t)r * K + kk + c];
-            Bs[r * LDS_PITCH + c] = B[(size_t)r * K + kk + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u, r = i >> 5, c = i & 31;
+            As[r * LDS_PITCH + c] = pa[u];
+            Bs[r * LDS_PITCH + c] = pb[u];
         }
         __syncthreads();
+        if (kk + BA_KC < k0 + kchunk) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = tid + 256 * u, r = i >> 5, c = i & 31;
+                pa[u] = A[(size_t)r * K + kk + BA_KC + c];
+                pb[u] = B[(size_t)r * K + kk + BA_KC + c];
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < BA_KC; ks += 4) {
             const double a = As[(16 * wv + (lane & 15)) * LDS_PITCH + ks + (lane >> 4)];
