@@ -71,6 +71,17 @@ def cpu_baseline(frames_a, frames_b, budget_s=12.0, min_frames=16):
             "sample": "%d synthetic 640x480 frames, oracle extract (1000 feat, 8 lvl) + all-pairs best2 vs previous frame, %.1f s" % (n, el)}
 
 
+def cpu_baseline_ba(prob):
+    """The BA oracle (CPU port pinned to the reference's g2o) on one host core, one window."""
+    from oracle import bindings as ob
+
+    t0 = time.perf_counter()
+    r = ob.ba_solve(prob)
+    el = time.perf_counter() - t0
+    return {"value": round(sum(r["stats"]["n_its"]) / el, 1), "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": "1 window, %.0f ms" % (1e3 * el)}
+
+
 def ba_secondary(device, steps, with_cpu=True):
     """local-BA LM iterations/sec on BASELINE config 4 (50 KF x 2000 points): window-8 visibility
     (16,000 edges) and dense visibility (100,000 edges), single window and a batch of 8 windows,
@@ -99,12 +110,7 @@ def ba_secondary(device, steps, with_cpu=True):
                      "batch8_value": round(sum(sum(x["stats"]["n_its"]) for x in rb) / elb, 1)}
             # Schur product: one dense 2 * Npad^2/2 * Kpad flop MFMA launch per LM trial
             if with_cpu:
-                from oracle import bindings as ob
-                t2 = time.perf_counter()
-                ro = ob.ba_solve(prob)
-                elc = time.perf_counter() - t2
-                entry["cpu_baseline"] = {"value": round(sum(ro["stats"]["n_its"]) / elc, 1), "unit": "iters/s", "cores": 1,
-                                         "kind": "port", "sample": "1 window, %.0f ms" % (1e3 * elc)}
+                entry["cpu_baseline"] = cpu_baseline_ba(prob)
                 entry["speedup_vs_cpu_1core"] = round(entry["value"] / entry["cpu_baseline"]["value"], 1)
             out[name] = entry
             opt.close()
