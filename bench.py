@@ -29,6 +29,10 @@ sys.path.insert(0, ROOT)
 
 W, H, NFEAT, NLEVELS = 640, 480, 1000, 8
 FAST_BYTES_PER_FRAME = 950532        # 1 B per pyramid pixel, 8 levels of 640x480
+CONFIGS = {  # name: (width, height, nfeatures, algorithmic FAST bytes per frame, BASELINE.json config)
+    "vga": (640, 480, 1000, 950532, "configs[1]"),
+    "720p": (1280, 720, 2000, 2853088, "configs[2]"),
+}
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
@@ -46,12 +50,12 @@ def measured_traffic(batch):
         return None
 
 
-def cpu_baseline(frames_a, frames_b, budget_s=12.0, min_frames=16):
+def cpu_baseline(frames_a, frames_b, nfeat=1000, budget_s=12.0, min_frames=16):
     """The CPU oracle (port of the reference path) on one host core over a bounded sample of the
     same workload: extract frame A_i, extract B_i, match B_i against A_i."""
     from oracle import bindings as ob
 
-    orc = ob.OrbOracle(NFEAT, 1.2, NLEVELS, 20, 7)
+    orc = ob.OrbOracle(nfeat, 1.2, NLEVELS, 20, 7)
     t0 = time.perf_counter()
     n = 0
     prev = None
@@ -68,7 +72,8 @@ def cpu_baseline(frames_a, frames_b, budget_s=12.0, min_frames=16):
         if el >= budget_s and n >= min_frames:
             break
     return {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic 640x480 frames, oracle extract (1000 feat, 8 lvl) + all-pairs best2 vs previous frame, %.1f s" % (n, el)}
+            "sample": "%d synthetic %dx%d frames, oracle extract (%d feat, 8 lvl) + all-pairs best2 vs previous frame, %.1f s" % (
+                n, frames_a[0].shape[1], frames_a[0].shape[0], nfeat, el)}
 
 
 def cpu_baseline_ba(prob):
@@ -128,7 +133,11 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent 640x480 streams per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="vga",
+                    help="vga = the headline metric's configuration; 720p = BASELINE configs[2] (profiling run)")
     args = ap.parse_args()
+    global W, H, NFEAT, FAST_BYTES_PER_FRAME
+    W, H, NFEAT, FAST_BYTES_PER_FRAME, cfg_name = CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
@@ -215,7 +224,7 @@ def main():
         fast_avg_ms = fast_ms / max(fast_calls, 1)
         achieved = FAST_BYTES_PER_FRAME * B / (fast_avg_ms * 1e-3) / 1e9 if fast_avg_ms > 0 else 0.0
         out = {
-            "metric": "frames/sec ORB extract+match @640x480x8lvl",
+            "metric": "frames/sec ORB extract+match @%dx%dx8lvl" % (W, H),
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "frames/s",
             "n_gpus": world,
@@ -227,12 +236,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 640x480 8-level ORB extract (1000 features, FAST 20/7) + "
+            "config": {"workload": "BASELINE %s: %dx%d 8-level ORB extract (%d features, FAST 20/7) + "
                                    "brute-force 256-bit Hamming best/second match vs the stream's previous frame; "
-                                   "%d independent streams per GPU per step" % B,
+                                   "%d independent streams per GPU per step" % (cfg_name, W, H, NFEAT, B),
                        "frames_per_step_per_gpu": B, "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"kernel": "fast_cells_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(B),
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(B) if args.config == "vga" else None,
                          "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)",
                          "avg_launch_ms": round(fast_avg_ms, 5), "launches": fast_calls,
                          "algorithmic_bytes_per_launch": FAST_BYTES_PER_FRAME * B},
@@ -240,7 +249,7 @@ def main():
             "match_ms_per_step": round(match_ms, 4),
         }
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(fa, fb)
+            out["cpu_baseline"] = cpu_baseline(fa, fb, NFEAT)
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         if not args.no_ba:
             out["secondary"] = ba_secondary(dev.index, args.steps, with_cpu=not args.no_cpu)
