@@ -198,6 +198,35 @@ int slamit_ba_solve(slamit_ba* h, const slamit_ba_problem* prob, const slamit_ba
 int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs,
                           const slamit_ba_opts* opts, slamit_ba_result* results);
 
+/* ---- Pose-only optimisation (SURVEY.md §8f "next" rank 1) ----------------------------------
+ * Optimizer::PoseOptimization (src/Optimizer.cc:239-451): one SE3 pose, n unary reprojection edges
+ * (g2o EdgeSE3ProjectXYZOnlyPose, Thirdparty/g2o/g2o/types/types_six_dof_expmap.{h:143-170,cpp:266-288}),
+ * four rounds of 10 Levenberg-Marquardt iterations, each restarted from the INPUT pose over the
+ * current inliers; after every round an edge is an outlier iff (float)chi2 > 5.991f; the Huber
+ * kernel is dropped after the third round.  Runs in one workgroup per frame, whole schedule on the
+ * device.  Returns through n_inliers what the reference returns (nInitialCorrespondences - nBad;
+ * 0 and an untouched pose when n < 3). */
+typedef struct slamit_pose_problem {
+    int32_t n;               /* correspondences (map point <-> undistorted keypoint) */
+    const double* pose;      /* 12: R row-major, t — pFrame->mTcw widened like Converter::toSE3Quat */
+    const double* intr;      /* 4: fx fy cx cy */
+    const double* xw;        /* n x 3 world points (float positions widened) */
+    const double* uv;        /* n x 2 */
+    const double* inv_sigma2;/* n */
+} slamit_pose_problem;
+
+typedef struct slamit_pose_result {
+    double* pose;            /* 12 out */
+    uint8_t* outlier;        /* n out: pFrame->mvbOutlier after the last round */
+    int32_t n_inliers;       /* out */
+    int32_t n_its[4];        /* out: LM iterations run in each round */
+    double chi2[4];          /* out: robust cost of the last evaluated trial of each round */
+} slamit_pose_result;
+
+/* nframes independent frames in one launch (host pointers, synchronous). */
+int slamit_pose_optimize_batch(int device, int nframes, const slamit_pose_problem* probs, slamit_pose_result* results);
+int slamit_pose_optimize(int device, const slamit_pose_problem* prob, slamit_pose_result* res);
+
 /* ---- misc -------------------------------------------------------------------------------- */
 
 const char* slamit_last_error(void);

@@ -463,3 +463,157 @@ extern "C" int ba_oracle_solve(const slamit_ba_problem* in, const slamit_ba_opts
     memcpy(res->pt_xyz, pb.pts.data(), sizeof(double) * 3 * (size_t)pb.P);
     return 0;
 }
+
+
+// =================================================================================================
+// Optimizer::PoseOptimization (S/Optimizer.cc:239-451): one pose vertex, unary
+// EdgeSE3ProjectXYZOnlyPose edges, BlockSolver_6_3 + LinearSolverDense + Levenberg; 4 rounds x 10
+// iterations, every round restarted from the input pose; (float)chi2 > 5.991f relabels outliers;
+// kernels dropped after round index 2.  Pinned to the reference's g2o the same way as the BA
+// (oracle/ba_ref_harness.cc:pose_ref_solve, tests/golden/pose_*.npz).
+// =================================================================================================
+namespace {
+
+struct PEdge { double X[3], u, v, w; bool active, robust; double err[2], chi2; };
+
+double pose_errors(const Pose& T, const double* in, std::vector<PEdge>& E, double delta) {
+    double total = 0;
+    const double dsqr = delta * delta;
+    for (size_t e = 0; e < E.size(); ++e) {
+        PEdge& ed = E[e];
+        if (!ed.active) continue;
+        double Xc[3];
+        quat_rot(T.q, ed.X, Xc);
+        for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
+        ed.err[0] = ed.u - (Xc[0] / Xc[2] * in[0] + in[2]);
+        ed.err[1] = ed.v - (Xc[1] / Xc[2] * in[1] + in[3]);
+        ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1];
+        if (ed.robust && ed.chi2 > dsqr) total += 2 * sqrt(ed.chi2) * delta - dsqr;
+        else total += ed.chi2;
+    }
+    return total;
+}
+
+int pose_optimize_round(Pose& T, const double* in, std::vector<PEdge>& E, double delta, int iterations, double* lastChi) {
+    bool any = false;
+    for (size_t e = 0; e < E.size(); ++e) any |= E[e].active;
+    if (!any) return 0;
+    const double dsqr = delta * delta;
+    double lambda = -1, ni = 2;
+    int nBad = 0, done = 0;
+    bool ok = true;
+    for (int it = 0; it < iterations && ok; ++it) {
+        double currentChi = pose_errors(T, in, E, delta), tempChi = currentChi;
+        const double iniChi = currentChi;
+        double H[36], b[6];
+        for (int i = 0; i < 36; ++i) H[i] = 0;
+        for (int i = 0; i < 6; ++i) b[i] = 0;
+        for (size_t e = 0; e < E.size(); ++e) {
+            const PEdge& ed = E[e];
+            if (!ed.active) continue;
+            double Xc[3];
+            quat_rot(T.q, ed.X, Xc);
+            for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
+            const double x = Xc[0], y = Xc[1], invz = 1.0 / Xc[2], invz_2 = invz * invz, fx = in[0], fy = in[1];
+            double J[12];
+            J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
+            J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+            J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy;
+            J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+            double rho1 = 1.0;
+            if (ed.robust && ed.chi2 > dsqr) rho1 = delta / sqrt(ed.chi2);
+            const double wO = rho1 * ed.w;
+            for (int i = 0; i < 6; ++i) {
+                b[i] -= rho1 * (J[i] * ed.w * ed.err[0] + J[6 + i] * ed.w * ed.err[1]);
+                for (int j = 0; j < 6; ++j) H[6 * i + j] += (J[i] * J[j] + J[6 + i] * J[6 + j]) * wO;
+            }
+        }
+        if (it == 0) {
+            double maxDiag = 0;
+            for (int j = 0; j < 6; ++j) maxDiag = std::max(fabs(H[7 * j]), maxDiag);
+            lambda = 1e-5 * maxDiag; ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            Pose backup = T;
+            std::vector<double> A(36), x(b, b + 6);
+            for (int i = 0; i < 36; ++i) A[i] = H[i] + (i % 7 == 0 ? lambda : 0.0);
+            bool ok2 = ldlt_solve(A, 6, x);
+            if (ok2) pose_oplus(T, x.data()); else x.assign(6, 0.0);
+            tempChi = pose_errors(T, in, E, delta);
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            double scale = 0;
+            for (int k = 0; k < 6; ++k) scale += x[k] * (lambda * x[k] + b[k]);
+            rho /= scale + 1e-3;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = std::min(1. - pow((2 * rho - 1), 3), 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2; T = backup;
+            }
+            ++qmax;
+        } while (rho < 0 && qmax < 10);
+        ++done;
+        *lastChi = tempChi;
+        if (qmax == 10 || rho == 0) { ok = false; continue; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
+        if (nBad >= 3) ok = false;
+    }
+    return done;
+}
+
+}  // namespace
+
+extern "C" int pose_oracle_solve(const slamit_pose_problem* pb, slamit_pose_result* res) {
+    const int n = pb->n;
+    Pose T0;
+    R_to_quat(pb->pose, T0.q);
+    quat_normalize(T0.q);
+    for (int i = 0; i < 3; ++i) T0.t[i] = pb->pose[9 + i];
+    for (int r = 0; r < 4; ++r) { res->n_its[r] = 0; res->chi2[r] = 0; }
+    if (n < 3) {  // S/Optimizer.cc:364-365
+        memcpy(res->pose, pb->pose, sizeof(double) * 12);
+        res->n_inliers = 0;
+        return 0;
+    }
+    const double delta = (double)(float)sqrt(5.991);
+    std::vector<PEdge> E(n);
+    for (int e = 0; e < n; ++e) {
+        for (int i = 0; i < 3; ++i) E[e].X[i] = pb->xw[3 * e + i];
+        E[e].u = pb->uv[2 * e]; E[e].v = pb->uv[2 * e + 1]; E[e].w = pb->inv_sigma2[e];
+        E[e].active = true; E[e].robust = true; E[e].err[0] = E[e].err[1] = 0; E[e].chi2 = 0;
+        res->outlier[e] = 0;
+    }
+    Pose T = T0;
+    int nBad = 0;
+    for (int round = 0; round < 4; ++round) {
+        T = T0;  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)) at the top of every round
+        res->n_its[round] = pose_optimize_round(T, pb->intr, E, delta, 10, &res->chi2[round]);
+        nBad = 0;
+        for (int e = 0; e < n; ++e) {
+            PEdge& ed = E[e];
+            if (res->outlier[e]) {  // inactive edges are re-evaluated at the new pose (:379-382)
+                double Xc[3];
+                quat_rot(T.q, ed.X, Xc);
+                for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
+                ed.err[0] = ed.u - (Xc[0] / Xc[2] * pb->intr[0] + pb->intr[2]);
+                ed.err[1] = ed.v - (Xc[1] / Xc[2] * pb->intr[1] + pb->intr[3]);
+                ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1];
+            }
+            const float chi2 = (float)ed.chi2;
+            if (chi2 > 5.991f) { res->outlier[e] = 1; ed.active = false; ++nBad; }
+            else { res->outlier[e] = 0; ed.active = true; }
+            if (round == 2) ed.robust = false;
+        }
+        if (n < 10) break;  // optimizer.edges().size() < 10
+    }
+    double R[9];
+    quat_to_R(T.q, R);
+    memcpy(res->pose, R, sizeof(R));
+    for (int i = 0; i < 3; ++i) res->pose[9 + i] = T.t[i];
+    res->n_inliers = n - nBad;
+    return 0;
+}

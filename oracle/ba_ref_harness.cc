@@ -18,6 +18,7 @@
 #include "Thirdparty/g2o/g2o/core/robust_kernel_impl.h"
 #include "Thirdparty/g2o/g2o/core/sparse_optimizer.h"
 #include "Thirdparty/g2o/g2o/core/hyper_graph_action.h"
+#include "Thirdparty/g2o/g2o/solvers/linear_solver_dense.h"
 #include "Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h"
 #include "Thirdparty/g2o/g2o/types/types_six_dof_expmap.h"
 
@@ -149,5 +150,75 @@ extern "C" int ba_ref_solve(const slamit_ba_problem* pb, const slamit_ba_opts* o
         g2o::VertexSBAPointXYZ* v = static_cast<g2o::VertexSBAPointXYZ*>(optimizer.vertex(p + maxKFid + 1));
         for (int c = 0; c < 3; ++c) res->pt_xyz[3 * p + c] = v->estimate()[c];
     }
+    return 0;
+}
+
+
+// Optimizer::PoseOptimization (S/Optimizer.cc:239-451) driven from POD inputs with the reference's g2o.
+extern "C" int pose_ref_solve(const slamit_pose_problem* pb, slamit_pose_result* res) {
+    g2o::SparseOptimizer optimizer;
+    g2o::BlockSolver_6_3::LinearSolverType* linearSolver = new g2o::LinearSolverDense<g2o::BlockSolver_6_3::PoseMatrixType>();
+    g2o::BlockSolver_6_3* solver_ptr = new g2o::BlockSolver_6_3(linearSolver);
+    g2o::OptimizationAlgorithmLevenberg* solver = new g2o::OptimizationAlgorithmLevenberg(solver_ptr);
+    optimizer.setAlgorithm(solver);
+    const int N = pb->n;
+    Eigen::Matrix<double, 3, 3> R;
+    R << pb->pose[0], pb->pose[1], pb->pose[2], pb->pose[3], pb->pose[4], pb->pose[5], pb->pose[6], pb->pose[7], pb->pose[8];
+    Eigen::Matrix<double, 3, 1> t(pb->pose[9], pb->pose[10], pb->pose[11]);
+    const g2o::SE3Quat Tcw(R, t);
+    g2o::VertexSE3Expmap* vSE3 = new g2o::VertexSE3Expmap();
+    vSE3->setEstimate(Tcw);
+    vSE3->setId(0);
+    vSE3->setFixed(false);
+    optimizer.addVertex(vSE3);
+    for (int r = 0; r < 4; ++r) { res->n_its[r] = 0; res->chi2[r] = 0; }
+    std::vector<g2o::EdgeSE3ProjectXYZOnlyPose*> edges;
+    const float deltaMono = sqrt(5.991);
+    int nInitialCorrespondences = 0;
+    for (int i = 0; i < N; ++i) {
+        nInitialCorrespondences++;
+        res->outlier[i] = 0;
+        Eigen::Matrix<double, 2, 1> obs;
+        obs << pb->uv[2 * i], pb->uv[2 * i + 1];
+        g2o::EdgeSE3ProjectXYZOnlyPose* e = new g2o::EdgeSE3ProjectXYZOnlyPose();
+        e->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(0)));
+        e->setMeasurement(obs);
+        e->setInformation(Eigen::Matrix2d::Identity() * pb->inv_sigma2[i]);
+        g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber;
+        e->setRobustKernel(rk);
+        rk->setDelta(deltaMono);
+        e->fx = pb->intr[0]; e->fy = pb->intr[1]; e->cx = pb->intr[2]; e->cy = pb->intr[3];
+        e->Xw[0] = pb->xw[3 * i]; e->Xw[1] = pb->xw[3 * i + 1]; e->Xw[2] = pb->xw[3 * i + 2];
+        optimizer.addEdge(e);
+        edges.push_back(e);
+    }
+    if (nInitialCorrespondences < 3) {
+        memcpy(res->pose, pb->pose, sizeof(double) * 12);
+        res->n_inliers = 0;
+        return 0;
+    }
+    const float chi2Mono[4] = {5.991, 5.991, 5.991, 5.991};
+    const int its[4] = {10, 10, 10, 10};
+    int nBad = 0;
+    for (size_t it = 0; it < 4; it++) {
+        vSE3->setEstimate(Tcw);
+        optimizer.initializeOptimization(0);
+        int n = optimizer.optimize(its[it]);
+        res->n_its[it] = n < 0 ? 0 : n;
+        res->chi2[it] = n > 0 ? optimizer.activeRobustChi2() : 0.0;
+        nBad = 0;
+        for (size_t i = 0; i < edges.size(); i++) {
+            g2o::EdgeSE3ProjectXYZOnlyPose* e = edges[i];
+            if (res->outlier[i]) e->computeError();
+            const float chi2 = e->chi2();
+            if (chi2 > chi2Mono[it]) { res->outlier[i] = 1; e->setLevel(1); nBad++; }
+            else { res->outlier[i] = 0; e->setLevel(0); }
+            if (it == 2) e->setRobustKernel(0);
+        }
+        if (optimizer.edges().size() < 10) break;
+    }
+    Eigen::Matrix<double, 4, 4> T = static_cast<g2o::VertexSE3Expmap*>(optimizer.vertex(0))->estimate().to_homogeneous_matrix();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) res->pose[3 * r + c] = T(r, c); res->pose[9 + r] = T(r, 3); }
+    res->n_inliers = nInitialCorrespondences - nBad;
     return 0;
 }

@@ -298,3 +298,45 @@ def ba_solve(prob, its_robust=5, its_final=10, huber_delta=HUBER_MONO, chi2_gate
 def ba_ref_solve(prob, its_robust=5, its_final=10, huber_delta=HUBER_MONO, chi2_gate=5.991, stop=None):
     """The reference's own g2o (authoring container only)."""
     return _ba_call("ref", prob, its_robust, its_final, huber_delta, chi2_gate, stop)
+
+
+# ---------------------------------------------------------------------------------------------
+# Pose-only optimisation (Optimizer::PoseOptimization)
+# ---------------------------------------------------------------------------------------------
+class _PoseProblem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("pose", C.c_void_p), ("intr", C.c_void_p), ("xw", C.c_void_p),
+                ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p)]
+
+
+class _PoseResult(C.Structure):
+    _fields_ = [("pose", C.c_void_p), ("outlier", C.c_void_p), ("n_inliers", C.c_int32),
+                ("n_its", C.c_int32 * 4), ("chi2", C.c_double * 4)]
+
+
+def _pose_call(which, prob):
+    if ("pose", which) not in _ba:
+        if which == "oracle":
+            build()
+            fn = C.CDLL(os.path.join(HERE, "libba_oracle.so")).pose_oracle_solve
+        else:
+            fn = C.CDLL(os.path.join(HERE, "_ref", "libba_ref.so")).pose_ref_solve
+        fn.argtypes = [C.POINTER(_PoseProblem), C.POINTER(_PoseResult)]
+        _ba[("pose", which)] = fn
+    keep = {k: np.ascontiguousarray(prob[k], np.float64) for k in ("pose", "intr", "xw", "uv", "inv_sigma2")}
+    n = len(keep["inv_sigma2"])
+    p = _PoseProblem(n, *[keep[k].ctypes.data for k in ("pose", "intr", "xw", "uv", "inv_sigma2")])
+    pose = np.zeros(12)
+    outl = np.zeros(max(n, 1), np.uint8)
+    r = _PoseResult(pose.ctypes.data, outl.ctypes.data, 0)
+    assert _ba[("pose", which)](C.byref(p), C.byref(r)) == 0
+    return {"pose": pose, "outlier": outl[:n].copy(), "n_inliers": r.n_inliers, "n_its": list(r.n_its), "chi2": list(r.chi2)}
+
+
+def pose_solve(prob):
+    """CPU restatement of PoseOptimization (oracle/ba_oracle.cc)."""
+    return _pose_call("oracle", prob)
+
+
+def pose_ref_solve(prob):
+    """The reference's own g2o (authoring container only)."""
+    return _pose_call("ref", prob)

@@ -31,3 +31,11 @@ def load_ba_golden(path):
                      "trials": [[int(v) for v in z["ref_trials"][s][:n[s]]] for s in range(2)],
                      "chi2_init": list(z["ref_chi2_init"])}}
     return prob, ref
+
+
+def load_pose_golden(path):
+    z = np.load(path)
+    prob = {k: z[k].astype(np.float64) for k in ("pose", "intr", "xw", "uv", "inv_sigma2")}
+    ref = {"pose": z["ref_pose"], "outlier": z["ref_outlier"], "n_inliers": int(z["ref_n_inliers"]),
+           "n_its": [int(v) for v in z["ref_n_its"]], "chi2": [float(v) for v in z["ref_chi2"]]}
+    return prob, ref

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests.helpers import ROOT, load_ba_golden
+from tests.helpers import ROOT, load_ba_golden, load_pose_golden
 
 SHIM = os.path.join(ROOT, "weiner_slamit_v2_amd", "shim")
 EXE = os.path.join(SHIM, "shim_test")
@@ -124,3 +124,22 @@ def test_shim_optimizer_local_ba(tmp_path):
     assert np.abs(t - ref["kf_pose"][:, 9:]).max() < 1e-5 * max(np.abs(ref["kf_pose"][:, 9:]).max(), 1)
     assert np.abs(pts - ref["pt_xyz"]).max() < 1e-5 * np.abs(ref["pt_xyz"]).max()
     assert erased == int(ref["edge_outlier"].sum()) and updates == P
+
+
+@pytest.mark.gpu
+def test_shim_optimizer_pose_optimization(tmp_path):
+    _build()
+    prob, ref = load_pose_golden(os.path.join(ROOT, "tests", "golden", "pose_typical.npz"))
+    n = len(prob["inv_sigma2"])
+    blob = struct.pack("<i", n) + prob["pose"].astype(np.float32).tobytes() + prob["intr"].astype(np.float32).tobytes()
+    blob += prob["xw"].astype(np.float32).tobytes() + prob["uv"].astype(np.float32).tobytes() + prob["inv_sigma2"].astype(np.float32).tobytes()
+    pin, pout = tmp_path / "p.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "pose", str(pin), str(pout)])
+    raw = open(pout, "rb").read()
+    inl = struct.unpack_from("<i", raw, 0)[0]
+    T = np.frombuffer(raw, np.float32, 12, 4).reshape(3, 4)
+    outl = np.frombuffer(raw, np.uint8, n, 52)
+    assert inl == ref["n_inliers"] and np.array_equal(outl, ref["outlier"])
+    want = np.concatenate([ref["pose"][:9].reshape(3, 3), ref["pose"][9:].reshape(3, 1)], 1)
+    assert np.abs(T - want).max() < 1e-5 * max(np.abs(want).max(), 1.0)  # float32 write-back like the reference

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/pose_*.npz from the REFERENCE's own g2o (oracle/_ref/libba_ref.so:
+pose_ref_solve = Optimizer::PoseOptimization's schedule on POD inputs).  Authoring container only."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import bindings as ob  # noqa: E402
+from weiner_slamit_v2_amd import synth  # noqa: E402
+
+CASES = {  # name: (n, outlier fraction, seed, initial pose perturbation)
+    "typical": (400, 0.15, 7, 0.02),
+    "dense1000": (1000, 0.30, 8, 0.05),
+    "few": (30, 0.10, 9, 0.02),
+    "under10": (8, 0.0, 10, 0.01),      # < 10 edges: one round only (Optimizer.cc:442-443)
+    "under3": (2, 0.0, 11, 0.01),       # < 3 correspondences: returns 0, pose untouched (:364-365)
+    "hard": (600, 0.50, 12, 0.10),
+}
+
+
+def main():
+    assert ob.ba_ref_available()
+    for name, (n, of, seed, pert) in CASES.items():
+        pr = synth.synth_pose(n, of, seed, pert)
+        r = ob.pose_ref_solve(pr)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pose_%s.npz" % name),
+                            pose=pr["pose"].astype(np.float32), intr=pr["intr"].astype(np.float32), xw=pr["xw"].astype(np.float32),
+                            uv=pr["uv"].astype(np.float32), inv_sigma2=pr["inv_sigma2"].astype(np.float32),
+                            ref_pose=r["pose"], ref_outlier=r["outlier"], ref_n_inliers=r["n_inliers"],
+                            ref_n_its=np.array(r["n_its"]), ref_chi2=np.array(r["chi2"]))
+        print(name, n, "inliers", r["n_inliers"], "its", r["n_its"])
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,16 @@ class BaResult(C.Structure):
                 ("edge_outlier", C.c_void_p), ("edge_stage1_outlier", C.c_void_p), ("stats", C.c_void_p)]
 
 
+class PoseProblem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("pose", C.c_void_p), ("intr", C.c_void_p), ("xw", C.c_void_p),
+                ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("pose", C.c_void_p), ("outlier", C.c_void_p), ("n_inliers", C.c_int32),
+                ("n_its", C.c_int32 * 4), ("chi2", C.c_double * 4)]
+
+
 _lib = None
 
 EXPORTS = [
@@ -62,7 +72,7 @@ EXPORTS = [
     "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
     "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
     "slamit_hamming_matrix", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
-    "slamit_ba_solve_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
+    "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
 ]
 
 
@@ -104,6 +114,9 @@ def lib():
             L.slamit_ba_destroy.restype = None
             L.slamit_ba_solve.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaOpts), C.POINTER(BaResult)]
             L.slamit_ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaProblem), C.POINTER(BaOpts), C.POINTER(BaResult)]
+        if hasattr(L, "slamit_pose_optimize_batch"):
+            L.slamit_pose_optimize_batch.argtypes = [i32, i32, C.POINTER(PoseProblem), C.POINTER(PoseResult)]
+            L.slamit_pose_optimize.argtypes = [i32, C.POINTER(PoseProblem), C.POINTER(PoseResult)]
         L.slamit_last_error.restype = C.c_char_p
         L.slamit_version.restype = C.c_char_p
         _lib = L
@@ -359,6 +372,29 @@ class Optimizer:
         _check(lib().slamit_ba_solve(self._h, C.byref(p), C.byref(o), C.byref(r)), "slamit_ba_solve")
         out["stats"] = self._stats(st)
         return out
+
+    @staticmethod
+    def PoseOptimization(problems, device=0):
+        """Optimizer::PoseOptimization for one problem dict or a list of them (synth.synth_pose layout):
+        returns dict(s) with pose (12), outlier flags, n_inliers, n_its[4], chi2[4]."""
+        single = isinstance(problems, dict)
+        plist = [problems] if single else list(problems)
+        n = len(plist)
+        P = (PoseProblem * n)()
+        R = (PoseResult * n)()
+        keep, outs = [], []
+        for i, pr in enumerate(plist):
+            k = {key: np.ascontiguousarray(pr[key], np.float64) for key in ("pose", "intr", "xw", "uv", "inv_sigma2")}
+            m = len(k["inv_sigma2"])
+            P[i] = PoseProblem(m, *[k[key].ctypes.data for key in ("pose", "intr", "xw", "uv", "inv_sigma2")])
+            o = {"pose": np.zeros(12), "outlier": np.zeros(max(m, 1), np.uint8)}
+            R[i] = PoseResult(o["pose"].ctypes.data, o["outlier"].ctypes.data, 0)
+            keep.append(k)
+            outs.append((o, m))
+        _check(lib().slamit_pose_optimize_batch(device, n, P, R), "slamit_pose_optimize_batch")
+        res = [{"pose": o["pose"], "outlier": o["outlier"][:m].copy(), "n_inliers": R[i].n_inliers,
+                "n_its": list(R[i].n_its), "chi2": list(R[i].chi2)} for i, (o, m) in enumerate(outs)]
+        return res[0] if single else res
 
     def LocalBundleAdjustmentBatch(self, problems, its_robust=5, its_final=10, huber_delta=HUBER_MONO,
                                    chi2_gate=5.991):

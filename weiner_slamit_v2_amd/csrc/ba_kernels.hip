@@ -27,95 +27,8 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// ---- small fp64 helpers (same formulas as Eigen / g2o) ---------------------------------------
-__device__ __forceinline__ void quat_rot(const double* q, const double* v, double* r) {
-    double uvx = 2 * (q[1] * v[2] - q[2] * v[1]), uvy = 2 * (q[2] * v[0] - q[0] * v[2]), uvz = 2 * (q[0] * v[1] - q[1] * v[0]);
-    r[0] = v[0] + q[3] * uvx + (q[1] * uvz - q[2] * uvy);
-    r[1] = v[1] + q[3] * uvy + (q[2] * uvx - q[0] * uvz);
-    r[2] = v[2] + q[3] * uvz + (q[0] * uvy - q[1] * uvx);
-}
-__device__ __forceinline__ void quat_to_R(const double* q, double* R) {
-    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
-    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
-    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
-    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
-    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
-    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
-}
-__device__ void R_to_quat(const double* m, double* q) {
-    double t = m[0] + m[4] + m[8];
-    if (t > 0) {
-        t = sqrt(t + 1.0);
-        q[3] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
-    } else {
-        int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[4 * i]) i = 2;
-        int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
-        double qq[4];
-        qq[i] = 0.5 * t;
-        t = 0.5 / t;
-        qq[3] = (m[3 * k + j] - m[3 * j + k]) * t;
-        qq[j] = (m[3 * j + i] + m[3 * i + j]) * t;
-        qq[k] = (m[3 * k + i] + m[3 * i + k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
-    }
-}
-__device__ __forceinline__ void quat_normalize(double* q) {
-    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
-    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
-}
-// T <- exp(u) * T   (SE3Quat::exp, g2o/types/se3quat.h:218-253; u = [omega, upsilon])
-__device__ void pose_oplus(double* T, const double* u) {
-    const double wx = u[0], wy = u[1], wz = u[2];
-    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
-    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-    double O2[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
-    double R[9], V[9];
-    if (theta < 0.00001) {
-        for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
-    } else {
-        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
-        for (int i = 0; i < 9; ++i) {
-            const double I = (i % 4 == 0 ? 1.0 : 0.0);
-            R[i] = I + a * O[i] + b * O2[i];
-            V[i] = I + b * O[i] + c * O2[i];
-        }
-    }
-    double qe[4], te[3], rt[3], nq[4];
-    R_to_quat(R, qe);
-    quat_normalize(qe);
-    for (int i = 0; i < 3; ++i) te[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
-    quat_rot(qe, T + 4, rt);
-    const double* b4 = T;
-    nq[3] = qe[3] * b4[3] - qe[0] * b4[0] - qe[1] * b4[1] - qe[2] * b4[2];
-    nq[0] = qe[3] * b4[0] + qe[0] * b4[3] + qe[1] * b4[2] - qe[2] * b4[1];
-    nq[1] = qe[3] * b4[1] + qe[1] * b4[3] + qe[2] * b4[0] - qe[0] * b4[2];
-    nq[2] = qe[3] * b4[2] + qe[2] * b4[3] + qe[0] * b4[1] - qe[1] * b4[0];
-    quat_normalize(nq);
-    T[0] = nq[0]; T[1] = nq[1]; T[2] = nq[2]; T[3] = nq[3];
-    T[4] = te[0] + rt[0]; T[5] = te[1] + rt[1]; T[6] = te[2] + rt[2];
-}
+#include "se3_device.h"
 
-// value of lane `l` (compile-time constant) as a wave-uniform scalar: v_readlane_b32 x2, no LDS
-__device__ __forceinline__ double readlane_d(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
 // deterministic block sum for 256-thread blocks; result valid in thread 0
 __device__ double block_sum_256(double v, double* sh /*[4]*/) {
     v = wave_sum(v);

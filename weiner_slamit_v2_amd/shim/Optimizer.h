@@ -45,6 +45,14 @@ public:
     template <class KeyFrameT, class MapT>
     static void LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap);
 
+    // Optimizer::PoseOptimization(Frame*) (Optimizer.cc:239-451) on whatever Frame type the caller has:
+    // members used: N, mTcw, mvpMapPoints (elements with GetWorldPos()), mvuRight, mvbOutlier, mvKeysUn,
+    // mvInvLevelSigma2, fx, fy, cx, cy, SetPose().  Returns the number of inliers like the reference.
+    // (The reference holds MapPoint::mGlobalMutex while reading the points; the caller's Frame type is
+    //  expected to do the same inside GetWorldPos or around this call.)
+    template <class FrameT>
+    static int PoseOptimization(FrameT* pFrame);
+
     // POD form: the window already flattened (what the template above produces).
     static int LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, const volatile bool* stop, slamit_ba_result& res);
 
@@ -78,6 +86,46 @@ inline int Optimizer::LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, co
     o.chi2_gate = 5.991;                           // :680,723
     o.stop = reinterpret_cast<const volatile uint8_t*>(stop);
     return lastStatus() = slamit_ba_solve(handleRef(), &prob, &o, &res);
+}
+
+template <class FrameT>
+int Optimizer::PoseOptimization(FrameT* pFrame) {
+    const int N = pFrame->N;
+    std::vector<double> xw, uv, isg;
+    std::vector<int> index;
+    for (int i = 0; i < N; ++i) {
+        if (!pFrame->mvpMapPoints[i]) continue;
+        if (pFrame->mvuRight[i] >= 0) { lastStatus() = SLAMIT_ERR_ARG; return 0; }  // stereo edges: not on the HIP path yet
+        pFrame->mvbOutlier[i] = false;
+        const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
+        cv::Mat Xw = pFrame->mvpMapPoints[i]->GetWorldPos();
+        for (int r = 0; r < 3; ++r) xw.push_back((double)Xw.template at<float>(r, 0));
+        uv.push_back(kpUn.pt.x); uv.push_back(kpUn.pt.y);
+        isg.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
+        index.push_back(i);
+    }
+    if ((int)index.size() < 3) return 0;  // Optimizer.cc:364-365
+    double pose[12], intr[4] = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy}, out[12];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) pose[3 * r + c] = (double)pFrame->mTcw.template at<float>(r, c);
+        pose[9 + r] = (double)pFrame->mTcw.template at<float>(r, 3);
+    }
+    std::vector<uint8_t> outlier(index.size());
+    slamit_pose_problem P;
+    P.n = (int32_t)index.size(); P.pose = pose; P.intr = intr; P.xw = xw.data(); P.uv = uv.data(); P.inv_sigma2 = isg.data();
+    slamit_pose_result R;
+    R.pose = out; R.outlier = outlier.data();
+    if ((lastStatus() = slamit_pose_optimize(deviceRef(), &P, &R)) != SLAMIT_OK) return 0;
+    for (size_t k = 0; k < index.size(); ++k) pFrame->mvbOutlier[index[k]] = outlier[k] != 0;
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T.template at<float>(r, c) = (float)out[3 * r + c];
+        T.template at<float>(r, 3) = (float)out[9 + r];
+        T.template at<float>(3, r) = 0.f;
+    }
+    T.template at<float>(3, 3) = 1.f;
+    pFrame->SetPose(T);
+    return R.n_inliers;
 }
 
 template <class KeyFrameT, class MapT>

@@ -190,11 +190,62 @@ static int run_ba(int argc, char** argv) {
     return 0;
 }
 
+// pose.bin: int32 n | float pose[12] | float intr[4] | float xw[3n] | float uv[2n] | float invsig[n]
+struct MockFrame {
+    int N;
+    cv::Mat mTcw;
+    float fx, fy, cx, cy;
+    std::vector<MockMapPoint*> mvpMapPoints;
+    std::vector<float> mvuRight, mvInvLevelSigma2;
+    std::vector<bool> mvbOutlier;
+    std::vector<cv::KeyPoint> mvKeysUn;
+    void SetPose(const cv::Mat& T) { mTcw = T.clone(); }
+};
+
+static int run_pose(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<unsigned char> raw = slurp(argv[2]);
+    const unsigned char* p = raw.data();
+    int n;
+    memcpy(&n, p, 4); p += 4;
+    const float* pose = (const float*)p; p += 48;
+    const float* intr = (const float*)p; p += 16;
+    const float* xw = (const float*)p; p += 12 * n;
+    const float* uv = (const float*)p; p += 8 * n;
+    const float* isg = (const float*)p;
+    MockFrame F;
+    std::vector<MockMapPoint> mps(n);
+    F.N = n + 5;  // a few keypoints without a map point, like a real frame
+    F.mTcw = cv::Mat(4, 4, CV_32F);
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) F.mTcw.at<float>(r, c) = pose[3 * r + c]; F.mTcw.at<float>(r, 3) = pose[9 + r]; F.mTcw.at<float>(3, r) = 0; }
+    F.mTcw.at<float>(3, 3) = 1;
+    F.fx = intr[0]; F.fy = intr[1]; F.cx = intr[2]; F.cy = intr[3];
+    F.mvpMapPoints.assign(F.N, (MockMapPoint*)0); F.mvuRight.assign(F.N, -1.f); F.mvbOutlier.assign(F.N, false);
+    F.mvKeysUn.resize(F.N); F.mvInvLevelSigma2.assign(1, 1.f);
+    for (int i = 0; i < n; ++i) {
+        mps[i].pos = cv::Mat(3, 1, CV_32F);
+        for (int r = 0; r < 3; ++r) mps[i].pos.at<float>(r, 0) = xw[3 * i + r];
+        F.mvpMapPoints[i] = &mps[i];
+        F.mvKeysUn[i] = cv::KeyPoint(uv[2 * i], uv[2 * i + 1], 31.f);
+        F.mvKeysUn[i].octave = (int)F.mvInvLevelSigma2.size();
+        F.mvInvLevelSigma2.push_back(isg[i]);
+    }
+    int inl = Optimizer::PoseOptimization(&F);
+    if (Optimizer::LastStatus() != 0) { fprintf(stderr, "pose failed: %s\n", slamit_last_error()); return 1; }
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(&inl, 4, 1, f);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) fwrite(&F.mTcw.at<float>(r, c), 4, 1, f);
+    for (int i = 0; i < n; ++i) { unsigned char o = F.mvbOutlier[i]; fwrite(&o, 1, 1, f); }
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
     if (mode == "orb") return run_orb(argc, argv);
     if (mode == "match") return run_match(argc, argv);
     if (mode == "ba") return run_ba(argc, argv);
+    if (mode == "pose") return run_pose(argc, argv);
     return 2;
 }

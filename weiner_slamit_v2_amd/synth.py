@@ -194,3 +194,26 @@ def synth_ba(n_kf=50, n_pt=2000, obs_per_pt=8, outlier_frac=0.03, seed=12345, n_
         "truth_pose": np.array([np.concatenate([Rs[k].reshape(-1), ts[k]]) for k in range(n_kf)]),
         "truth_pt": pts,
     }
+
+
+def synth_pose(n=400, outlier_frac=0.15, seed=7, perturb=0.02):
+    """One PoseOptimization problem (Optimizer.cc:239-451): n map points seen by one frame, pixel
+    noise N(0,1), a fraction of gross outliers, initial pose = truth perturbed by exp(N(0, perturb^2)).
+    All inputs float32-rounded then widened, as the reference feeds them."""
+    rs = np.random.RandomState(seed)
+    fx, fy, cx, cy = INTRINSICS
+    R, t = se3_exp([0.05, -0.1, 0.02, 0.3, -0.1, 0.2])
+    pts_c = np.stack([rs.uniform(-2.5, 2.5, n), rs.uniform(-1.8, 1.8, n), rs.uniform(3.0, 9.0, n)], 1)
+    xw = (pts_c - t) @ R  # X_w = R^T (X_c - t)
+    u = fx * pts_c[:, 0] / pts_c[:, 2] + cx + rs.normal(0, 1, n)
+    v = fy * pts_c[:, 1] / pts_c[:, 2] + cy + rs.normal(0, 1, n)
+    bad = rs.uniform(size=n) < outlier_frac
+    u[bad] += rs.choice([-1, 1], bad.sum()) * rs.uniform(8, 60, bad.sum())
+    v[bad] += rs.choice([-1, 1], bad.sum()) * rs.uniform(8, 60, bad.sum())
+    quota = np.array([217, 181, 151, 126, 105, 87, 73, 60], dtype=np.float64)
+    inv_sig = _inv_sigma2_table()[rs.choice(8, n, p=quota / quota.sum())]
+    dR, dt = se3_exp(rs.normal(0, perturb, 6))
+    pose = np.concatenate([(dR @ R).reshape(-1), dR @ t + dt])
+    f32 = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).astype(np.float64))
+    return {"pose": f32(pose), "intr": f32([fx, fy, cx, cy]), "xw": f32(xw), "uv": f32(np.stack([u, v], 1)),
+            "inv_sigma2": f32(inv_sig), "truth_pose": np.concatenate([R.reshape(-1), t]), "truth_outlier": bad}
