@@ -314,7 +314,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
                     B[l - 1].nx0 = (int16_t)sx0; B[l - 1].nx1 = (int16_t)sx1; B[l - 1].ny0 = (int16_t)sy0; B[l - 1].ny1 = (int16_t)sy1;
                 }
                 for (int l = 0; l < nl; ++l) {
-                    if (l >= 1 && B[l].nx1 - B[l].nx0 > 256) okb = false;  // kernel keeps <= 4 columns per lane
+                    if (l >= 1 && (B[l].nx1 - B[l].nx0 > 256 || B[l].ny1 - B[l].ny0 > 256)) okb = false;  // <= 4 columns per lane, row tables of 256
                     size_t bytes = (size_t)(((B[l].nx1 - B[l].nx0) + 3) & ~3) * (B[l].ny1 - B[l].ny0);
                     if (l & 1) capB = std::max(capB, bytes); else capA = std::max(capA, bytes);
                 }

@@ -129,11 +129,22 @@ __global__ __launch_bounds__(PYR_THREADS) void pyramid_fused_kernel(
                 if (x >= b.ox0 && x < b.ox1) ownmask |= 1u << j;
             } else { cx0[j] = cx1[j] = 0; ca0[j] = ca1[j] = 0; }
         }
+        // the row tables of this level's rows go through LDS once (a dependent scalar load per row
+        // would stall every iteration)
+        __shared__ int s_sy0[256], s_sy1[256], s_b01[256];
+        const int nh = b.ny1 - b.ny0;
+        for (int i = threadIdx.x; i < nh; i += PYR_THREADS) {
+            const int y = b.ny0 + i, sy = T.yofs[y];
+            s_sy0[i] = min(max(sy, 0), sh - 1) - pb.ny0;
+            s_sy1[i] = min(max(sy + 1, 0), sh - 1) - pb.ny0;
+            s_b01[i] = (int)(unsigned short)T.ibeta[2 * y] | ((int)T.ibeta[2 * y + 1] << 16);
+        }
+        __syncthreads();
         const int wy = __builtin_amdgcn_readfirstlane(ty);
         for (int y = b.ny0 + wy; y < b.ny1; y += PYR_ROWS) {
-            const int sy = T.yofs[y];
-            const int sy0 = min(max(sy, 0), sh - 1) - pb.ny0, sy1 = min(max(sy + 1, 0), sh - 1) - pb.ny0;
-            const int b0 = T.ibeta[2 * y], b1 = T.ibeta[2 * y + 1];
+            const int sy0 = s_sy0[y - b.ny0], sy1 = s_sy1[y - b.ny0];
+            const int b01 = s_b01[y - b.ny0];
+            const int b0 = (short)(b01 & 0xFFFF), b1 = b01 >> 16;
             const uint8_t* S0 = src + sy0 * spitch;
             const uint8_t* S1 = src + sy1 * spitch;
             const bool own_y = y >= b.oy0 && y < b.oy1;
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(256) void octree_kernel(
         kp.x = (int16_t)(cj * L.wCell + lx + ORB_MIN_BORDER);  // ORBextractor.cc:863-864
         kp.y = (int16_t)(ci * L.hCell + ly + ORB_MIN_BORDER);
         kp.response = (float)(unsigned)(b >> 32);
-        kp.angle = 0.f;
+        kp.angle = 0.f; kp.cs = 1.f; kp.sn = 0.f;
         if (i < L.kp_cap) OUT[i] = kp;
     }
     if (tid == 0) kp_count[kidx] = min(n, L.kp_cap);
@@ -719,36 +730,55 @@ static DiscTable make_disc() {
     return t;
 }
 
+#define IC_KP_PER_WAVE 4
+
 __global__ __launch_bounds__(256) void ic_angle_kernel(
     const OrbLevel* __restrict__ levels, int nlevels,
     const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr,
     OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, const int* __restrict__ kp_count) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int level = blockIdx.y, frame = blockIdx.z;
     const OrbLevel& L = levels[level];
-    if (i >= kp_count[frame * nlevels + level]) return;
-    OrbLevelKp* kp = lkp + L.kp_off + (size_t)frame * kp_frame_stride + i;
+    const int count = kp_count[frame * nlevels + level];
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * IC_KP_PER_WAVE;
+    if (i0 >= count) return;
     const uint8_t* src;
     int stride;
     if (level == 0) { src = img0 + (size_t)frame * img0_frame; stride = (int)img0_stride; }
     else { src = pyr + L.plane_off + (size_t)frame * L.plane_bytes; stride = L.stride; }
-    const uint8_t* center = src + (size_t)kp->y * stride + kp->x;
-    int m10 = 0, m01 = 0;
-    const int n = c_disc.n;
-    for (int idx = lane; idx < n; idx += WAVE) {
-        const int u = c_disc.u[idx], v = c_disc.v[idx];
-        const int val = center[v * stride + u];
-        m10 += u * val;
-        m01 += v * val;
-    }
+    // this lane's 12 disc pixels (749 = 11 * 64 + 45): offsets and weights live in registers
+    int off[12], wu[12], wv[12];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        m10 += __shfl_xor(m10, d, WAVE);
-        m01 += __shfl_xor(m01, d, WAVE);
+    for (int j = 0; j < 12; ++j) {
+        const int idx = lane + 64 * j;
+        const int u = c_disc.u[idx], v = c_disc.v[idx];   // padding entries are (0,0): weight zero
+        off[j] = v * stride + u; wu[j] = u; wv[j] = v;
     }
-    if (lane == 0) kp->angle = slamit_fast_atan2((float)m01, (float)m10);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
+        const int i = i0 + k;
+        if (i >= count) break;
+        OrbLevelKp* kp = lkp + L.kp_off + (size_t)frame * kp_frame_stride + i;
+        const uint8_t* center = src + (size_t)kp->y * stride + kp->x;
+        int val[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) val[j] = center[off[j]];   // 12 independent loads in flight
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { m10 += wu[j] * val[j]; m01 += wv[j] * val[j]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            m10 += __shfl_xor(m10, d, WAVE);
+            m01 += __shfl_xor(m01, d, WAVE);
+        }
+        if (lane == 0) {
+            const float ang = slamit_fast_atan2((float)m01, (float)m10);
+            float sn, cs;
+            slamit_sincosf(ang * factorPI, &sn, &cs);   // a = cos, b = sin of computeOrbDescriptor, once per keypoint
+            kp->angle = ang; kp->cs = cs; kp->sn = sn;
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -891,9 +921,7 @@ __global__ __launch_bounds__(256) void describe_kernel(
     const int o = offset + i;
     if (o >= out_cap) return;
 
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    slamit_sincosf(kp.angle * factorPI, &b, &a);  // a = cos, b = sin   (ORBextractor.cc:117-118)
+    const float a = kp.cs, b = kp.sn;  // a = cos, b = sin   (ORBextractor.cc:117-118; computed by ic_angle_kernel)
     const uint8_t* img = blur + L.blur_off + (size_t)frame * L.blur_bytes;
     const int step = L.stride;
     const uint8_t* center = img + (size_t)kp.y * step + kp.x;
@@ -1040,7 +1068,7 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0,
                    size_t img0_stride, size_t img0_frame, const uint8_t* pyr, OrbLevelKp* lkp,
                    size_t kp_frame_stride, const int* kp_count, int max_kp, int nframes) {
-    hipLaunchKernelGGL(ic_angle_kernel, dim3((max_kp + 3) / 4, nlevels, nframes), dim3(256), 0, st, levels,
+    hipLaunchKernelGGL(ic_angle_kernel, dim3((max_kp + 4 * IC_KP_PER_WAVE - 1) / (4 * IC_KP_PER_WAVE), nlevels, nframes), dim3(256), 0, st, levels,
                        nlevels, img0, img0_stride, img0_frame, pyr, lkp, kp_frame_stride, kp_count);
 }
 

@@ -59,6 +59,7 @@ struct OrbLevelKp {            // a keypoint in level coordinates, after the oct
     int16_t x, y;
     float response;
     float angle;
+    float cs, sn;              // cos / sin of the angle as computeOrbDescriptor needs them (set by the IC kernel)
 };
 
 #endif
