@@ -135,6 +135,16 @@ int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size
                                    int npairs, int max_n, int32_t* d_best_idx, int32_t* d_best,
                                    int32_t* d_second, size_t out_stride, int device, void* stream);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:248-314), batched:
+ * map point p owns descriptor rows [offsets[p], offsets[p+1]) of `desc` (its observations, in the
+ * reference's iteration order).  For each point: all-pairs Hamming distances, per row the median
+ * vDists[(int)(0.5*(N-1))] of the sorted row (self distance 0 included), and the row with the least
+ * median (first one on ties) -> best_idx[p] (relative to offsets[p]; -1 for a point without rows),
+ * best_median[p].  At most SLAMIT_DISTINCTIVE_MAX rows per point. */
+#define SLAMIT_DISTINCTIVE_MAX 128
+int slamit_distinctive_batch(const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx,
+                             int32_t* best_median);
+
 /* Full distance matrix (nq x nt, uint16), the batched form of DescriptorDistance. */
 int slamit_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out);
 

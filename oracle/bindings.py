@@ -66,6 +66,7 @@ def orb_lib():
         L.orb_oracle_distance.argtypes = [_u8p, _u8p]
         L.orb_oracle_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
         L.orb_oracle_matrix.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint16)]
+        L.orb_oracle_distinctive.argtypes = [_u8p, _i32p, C.c_int, _i32p, _i32p]
         _orb = L
     return _orb
 
@@ -204,6 +205,16 @@ def best2(q, t):
     idx, b, s = (np.zeros(len(q), np.int32) for _ in range(3))
     orb_lib().orb_oracle_best2(_ptr(q), len(q), _ptr(t), len(t), _ptr(idx, _i32p), _ptr(b, _i32p), _ptr(s, _i32p))
     return idx, b, s
+
+
+def distinctive(desc, offsets):
+    """MapPoint::ComputeDistinctiveDescriptors for a batch of points (rows offsets[p]:offsets[p+1])."""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    n = len(offsets) - 1
+    idx, med = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    orb_lib().orb_oracle_distinctive(_ptr(desc), _ptr(offsets, _i32p), n, _ptr(idx, _i32p), _ptr(med, _i32p))
+    return idx[:n], med[:n]
 
 
 def matrix(q, t):

@@ -800,6 +800,31 @@ void orb_oracle_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_
         best_idx[i] = bestIdx; best[i] = bestDist; second[i] = bestDist2;
     }
 }
+// MapPoint::ComputeDistinctiveDescriptors, S/MapPoint.cc:248-314 (float Distances[N][N], sorted row,
+// median = vDists[0.5*(N-1)], strict '<' so the first least-median row wins)
+void orb_oracle_distinctive(const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx, int32_t* best_median) {
+    for (int p = 0; p < npoints; ++p) {
+        const int o = offsets[p], N = offsets[p + 1] - o;
+        if (N <= 0) { best_idx[p] = -1; best_median[p] = 0; continue; }
+        std::vector<float> Distances((size_t)N * N);
+        for (int i = 0; i < N; ++i) {
+            Distances[(size_t)i * N + i] = 0;
+            for (int j = i + 1; j < N; ++j) {
+                int d = descriptor_distance(desc + 32 * (size_t)(o + i), desc + 32 * (size_t)(o + j));
+                Distances[(size_t)i * N + j] = (float)d;
+                Distances[(size_t)j * N + i] = (float)d;
+            }
+        }
+        int BestMedian = 2147483647, BestIdx = 0;
+        for (int i = 0; i < N; ++i) {
+            std::vector<int> vDists(Distances.begin() + (size_t)i * N, Distances.begin() + (size_t)(i + 1) * N);
+            std::sort(vDists.begin(), vDists.end());
+            int median = vDists[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        best_idx[p] = BestIdx; best_median[p] = BestMedian;
+    }
+}
 void orb_oracle_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out) {
     for (int i = 0; i < nq; ++i)
         for (int j = 0; j < nt; ++j) out[(size_t)i * nt + j] = (uint16_t)descriptor_distance(q + 32 * (size_t)i, t + 32 * (size_t)j);

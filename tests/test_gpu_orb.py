@@ -180,3 +180,20 @@ def test_extract_then_match_pair():
     ok = (obest <= 50) & (obest.astype(np.float32) < np.float32(0.9) * osec.astype(np.float32))
     assert np.array_equal(qi, np.nonzero(ok)[0]) and np.array_equal(ti, oi[ok])
     assert len(qi) > 100  # the warp is mild: many true matches
+
+
+def test_distinctive_descriptors_batch():
+    rs = np.random.RandomState(21)
+    desc, offs = [], [0]
+    for p in range(400):
+        n = int(rs.choice([0, 1, 2, 3, 5, 9, 17, 33, 64, 65, 100, 128]))
+        base = rs.randint(0, 256, (1, 32)).astype(np.uint8)
+        d = base ^ (rs.randint(0, 256, (n, 32)) < rs.randint(4, 60)).astype(np.uint8)  # clustered: many equal medians
+        desc.append(d)
+        offs.append(offs[-1] + n)
+    desc = np.concatenate(desc)
+    gi, gm = api.ORBmatcher.distinctive(desc, offs)
+    oi, om = ob.distinctive(desc, offs)
+    assert np.array_equal(gi, oi) and np.array_equal(gm, om)
+    with pytest.raises(api.SlamitError):
+        api.ORBmatcher.distinctive(rs.randint(0, 256, (129, 32)).astype(np.uint8), [0, 129])

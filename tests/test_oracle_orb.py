@@ -350,3 +350,27 @@ def test_extract_fallback_cells_used():
     o.extract(img.astype(np.uint8))
     c = o.candidates(0)
     assert ((c[:, 2] >= 7) & (c[:, 2] < 20)).any() and (c[:, 2] >= 20).any()
+
+
+def test_distinctive_descriptor_definition():
+    """MapPoint::ComputeDistinctiveDescriptors: least median (index floor(0.5*(N-1)) of the sorted row,
+    self distance included), first row wins ties."""
+    rs = np.random.RandomState(8)
+    desc, offs = [], [0]
+    for n in (1, 2, 3, 7, 20, 0, 51, 4):
+        d = rs.randint(0, 256, (n, 32)).astype(np.uint8)
+        if n == 4:
+            d[:] = d[0]      # all identical: every median 0, row 0 must win
+        desc.append(d)
+        offs.append(offs[-1] + n)
+    desc = np.concatenate(desc)
+    idx, med = ob.distinctive(desc, offs)
+    for p in range(len(offs) - 1):
+        rows = desc[offs[p]:offs[p + 1]]
+        n = len(rows)
+        if n == 0:
+            assert idx[p] == -1
+            continue
+        D = np.unpackbits(rows[:, None, :] ^ rows[None, :, :], axis=-1).sum(-1)
+        meds = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
+        assert med[p] == meds.min() and idx[p] == int(np.argmin(meds))

@@ -71,7 +71,7 @@ EXPORTS = [
     "slamit_orb_create", "slamit_orb_destroy", "slamit_orb_tables", "slamit_orb_max_keypoints",
     "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
     "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
-    "slamit_hamming_matrix", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
+    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
     "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
 ]
 
@@ -108,6 +108,7 @@ def lib():
         L.slamit_hamming_best2.argtypes = [vp, i32, vp, i32, vp, vp, vp]
         L.slamit_hamming_best2_batch_dev.argtypes = [vp, vp, sz, vp, vp, sz, i32, i32, vp, vp, vp, sz, i32, vp]
         L.slamit_hamming_matrix.argtypes = [vp, i32, vp, i32, vp]
+        L.slamit_distinctive_batch.argtypes = [vp, vp, i32, vp, vp]
         if hasattr(L, "slamit_ba_create"):
             L.slamit_ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
             L.slamit_ba_destroy.argtypes = [vp]
@@ -295,6 +296,17 @@ class ORBmatcher:
         _check(lib().slamit_hamming_best2(_np_ptr(q), len(q), _np_ptr(t), len(t), _np_ptr(idx), _np_ptr(best),
                                           _np_ptr(second)), "slamit_hamming_best2")
         return idx, best, second
+
+    @staticmethod
+    def distinctive(desc, offsets):
+        """MapPoint::ComputeDistinctiveDescriptors, batched: returns (best row per point, its median)."""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        n = len(offsets) - 1
+        idx, med = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        _check(lib().slamit_distinctive_batch(_np_ptr(desc), _np_ptr(offsets), n, _np_ptr(idx), _np_ptr(med)),
+               "slamit_distinctive_batch")
+        return idx[:n], med[:n]
 
     def match(self, q, t, th=None):
         """All-pairs match with the reference's acceptance rule: best <= th and best < nnratio*second

@@ -88,7 +88,77 @@ __global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t* __re
     }
 }
 
+// MapPoint::ComputeDistinctiveDescriptors: one wavefront per map point.  Descriptors and the N x N
+// distance matrix (u16) sit in LDS; each lane owns rows lane, lane+64 and finds its row's median by
+// bisection on the value range [0, 256] (count of entries <= mid), then the wave takes the
+// lexicographic minimum of (median, row) so the first least-median row wins like the reference's loop.
+__global__ __launch_bounds__(64) void distinctive_kernel(const uint8_t* __restrict__ desc, const int* __restrict__ offsets,
+                                                         int* __restrict__ best_idx, int* __restrict__ best_median) {
+    __shared__ uint4 rowsd[SLAMIT_DISTINCTIVE_MAX * 2];
+    __shared__ unsigned short D[SLAMIT_DISTINCTIVE_MAX * SLAMIT_DISTINCTIVE_MAX];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int o = offsets[p], n = offsets[p + 1] - o;
+    if (n <= 0) { if (lane == 0) { best_idx[p] = -1; best_median[p] = 0; } return; }
+    const uint4* G = reinterpret_cast<const uint4*>(desc + (size_t)o * 32);
+    for (int i = lane; i < 2 * n; i += 64) rowsd[i] = G[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n; i += 64) {
+        const uint4 a0 = rowsd[2 * i], a1 = rowsd[2 * i + 1];
+        for (int j = 0; j < n; ++j) {
+            const uint4 t0 = rowsd[2 * j], t1 = rowsd[2 * j + 1];
+            const int d = __popc(a0.x ^ t0.x) + __popc(a0.y ^ t0.y) + __popc(a0.z ^ t0.z) + __popc(a0.w ^ t0.w) +
+                          __popc(a1.x ^ t1.x) + __popc(a1.y ^ t1.y) + __popc(a1.z ^ t1.z) + __popc(a1.w ^ t1.w);
+            D[i * n + j] = (unsigned short)d;
+        }
+    }
+    const int k = (int)(0.5 * (n - 1));  // index of the median in the sorted row
+    unsigned bestkey = 0xFFFFFFFFu;       // (median << 16) | row
+    for (int i = lane; i < n; i += 64) {
+        int lo = 0, hi = 256;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int j = 0; j < n; ++j) c += D[i * n + j] <= mid;
+            if (c >= k + 1) hi = mid; else lo = mid + 1;
+        }
+        bestkey = min(bestkey, ((unsigned)lo << 16) | (unsigned)i);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bestkey = min(bestkey, (unsigned)__shfl_xor((int)bestkey, d, 64));
+    if (lane == 0) { best_idx[p] = (int)(bestkey & 0xFFFF); best_median[p] = (int)(bestkey >> 16); }
+}
+
 extern "C" {
+
+int slamit_distinctive_batch(const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx,
+                             int32_t* best_median) {
+    if (npoints < 0 || (npoints && (!offsets || !best_idx || !best_median))) return slamit_fail(SLAMIT_ERR_ARG, "slamit_distinctive_batch: bad argument");
+    if (npoints == 0) return SLAMIT_OK;
+    for (int p = 0; p < npoints; ++p) {
+        const int n = offsets[p + 1] - offsets[p];
+        if (n < 0 || offsets[0] < 0) return slamit_fail(SLAMIT_ERR_ARG, "slamit_distinctive_batch: offsets must be non-decreasing");
+        if (n > SLAMIT_DISTINCTIVE_MAX) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_distinctive_batch: more than SLAMIT_DISTINCTIVE_MAX rows for one point");
+    }
+    const int total = offsets[npoints];
+    if (total && !desc) return slamit_fail(SLAMIT_ERR_ARG, "slamit_distinctive_batch: null descriptors");
+    uint8_t* dd = nullptr;
+    int *doff = nullptr, *dout = nullptr;
+    hipError_t e = hipMalloc((void**)&dd, std::max<size_t>((size_t)total * 32, 32));
+    if (e == hipSuccess) e = hipMalloc((void**)&doff, sizeof(int) * ((size_t)npoints + 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, sizeof(int) * 2 * (size_t)npoints);
+    if (e == hipSuccess && total) e = hipMemcpy(dd, desc, (size_t)total * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(doff, offsets, sizeof(int) * ((size_t)npoints + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(distinctive_kernel, dim3(npoints), dim3(64), 0, 0, dd, doff, dout, dout + npoints);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(best_idx, dout, sizeof(int) * npoints, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(best_median, dout + npoints, sizeof(int) * npoints, hipMemcpyDeviceToHost);
+    hipFree(dd); hipFree(doff); hipFree(dout);
+    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_distinctive_batch");
+    return SLAMIT_OK;
+}
 
 int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size_t q_stride, const uint8_t* d_t,
                                    const int32_t* d_nt, size_t t_stride, int npairs, int max_n,
