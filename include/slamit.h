@@ -145,6 +145,52 @@ int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size
 int slamit_distinctive_batch(const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx,
                              int32_t* best_median);
 
+/* ---- Guided search ------------------------------------------------------
+ * The common core of ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:47-131) and SearchByProjection(CurrentFrame, LastFrame, th, bMono) (:1332-1474):
+ * for each query, in order, Frame::GetFeaturesInArea(u, v, r, minLevel, maxLevel)
+ * (src/Frame.cc:447-502 over the 64x48 grid of Frame::AssignFeaturesToGrid, :336-357, :505-517),
+ * skip keypoints that already carry a map point, take the nearest (and second nearest) descriptor in
+ * the reference's candidate order, accept, and MARK THE KEYPOINT TAKEN for the queries that follow
+ * (the reference assigns F.mvpMapPoints[bestIdx] inside the loop).  Projection, viewing-cosine radius
+ * and the rotation histogram stay with the caller (shim/ORBmatcher.h).  Mono only (mvuRight < 0). */
+typedef struct slamit_frame_view {
+    int32_t n;                 /* keypoints */
+    const float* kp_xy;        /* n x 2: mvKeysUn[i].pt */
+    const int32_t* kp_octave;  /* n */
+    const uint8_t* desc;       /* n x 32: mDescriptors */
+    const uint8_t* kp_taken;   /* n: 1 = mvpMapPoints[i] && mvpMapPoints[i]->Observations() > 0 on entry */
+    float min_x, min_y;        /* mnMinX, mnMinY */
+    float inv_w, inv_h;        /* mfGridElementWidthInv, mfGridElementHeightInv */
+} slamit_frame_view;
+
+typedef struct slamit_search_queries {
+    int32_t m;
+    const float* uvr;          /* m x 3: window centre u, v and half-size r (already scaled) */
+    const int32_t* level_min;  /* m */
+    const int32_t* level_max;  /* m: -1 = no upper bound (GetFeaturesInArea's default) */
+    const uint8_t* desc;       /* m x 32: pMP->GetDescriptor() */
+    const uint8_t* valid;      /* m: 0 = query skipped (mbTrackInView false, bad point, behind camera ...) */
+    const uint8_t* takes;      /* m or NULL (= all 1): 1 = pMP->Observations() > 0, i.e. a keypoint matched to
+                                  this query is skipped by the queries that follow */
+} slamit_search_queries;
+
+typedef struct slamit_search_rule {
+    int32_t th_dist;           /* accept iff bestDist <= th_dist (TH_HIGH = 100) */
+    int32_t use_ratio;         /* 1: also reject when bestLevel == bestLevel2 && bestDist > nnratio * bestDist2 */
+    float nnratio;
+} slamit_search_rule;
+
+/* match_kp[q] = index of the keypoint the query took, or -1; *nmatches = number of accepted queries.
+ * best_dist / best_level / second_dist / second_level (any may be NULL) report the selection of every
+ * query that had candidates (256 / -1 otherwise).  At most SLAMIT_SEARCH_MAX_KP keypoints and
+ * SLAMIT_SEARCH_MAX_CAND candidates per query. */
+#define SLAMIT_SEARCH_MAX_KP 8191
+#define SLAMIT_SEARCH_MAX_CAND 1024
+int slamit_guided_search(int device, const slamit_frame_view* frame, const slamit_search_queries* queries,
+                         const slamit_search_rule* rule, int32_t* match_kp, int32_t* nmatches, int32_t* best_dist,
+                         int32_t* best_level, int32_t* second_dist, int32_t* second_level);
+
 /* Full distance matrix (nq x nt, uint16), the batched form of DescriptorDistance. */
 int slamit_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out);
 

@@ -67,6 +67,9 @@ def orb_lib():
         L.orb_oracle_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
         L.orb_oracle_matrix.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint16)]
         L.orb_oracle_distinctive.argtypes = [_u8p, _i32p, C.c_int, _i32p, _i32p]
+        L.orb_oracle_guided_search.argtypes = [C.c_int, _f32p, _i32p, _u8p, _u8p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                               C.c_int, _f32p, _i32p, _i32p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_float,
+                                               _i32p, _i32p]
         _orb = L
     return _orb
 
@@ -215,6 +218,38 @@ def distinctive(desc, offsets):
     idx, med = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
     orb_lib().orb_oracle_distinctive(_ptr(desc), _ptr(offsets, _i32p), n, _ptr(idx, _i32p), _ptr(med, _i32p))
     return idx[:n], med[:n]
+
+
+def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8):
+    """Frame grid + GetFeaturesInArea + the SearchByProjection loop (see weiner_slamit_v2_amd.api.guided_search
+    for the dict layouts).  Returns (match_kp, nmatches, out4[m,4] = best dist/level, second dist/level)."""
+    f, q = normalize_search(frame, queries)
+    n, m = len(f["kp_xy"]), len(q["uvr"])
+    match = np.full(max(m, 1), -1, np.int32)
+    out4 = np.zeros((max(m, 1), 4), np.int32)
+    nm = orb_lib().orb_oracle_guided_search(
+        n, _ptr(f["kp_xy"], _f32p), _ptr(f["kp_octave"], _i32p), _ptr(f["desc"]), _ptr(f["kp_taken"]),
+        f["min_x"], f["min_y"], f["inv_w"], f["inv_h"], m, _ptr(q["uvr"], _f32p), _ptr(q["level_min"], _i32p),
+        _ptr(q["level_max"], _i32p), _ptr(q["desc"]), _ptr(q["valid"]), _ptr(q["takes"]), int(th_dist), int(bool(use_ratio)),
+        float(np.float32(nnratio)), _ptr(match, _i32p), _ptr(out4, _i32p))
+    return match[:m], nm, out4[:m]
+
+
+def normalize_search(frame, queries):
+    f = dict(kp_xy=np.ascontiguousarray(frame["kp_xy"], np.float32).reshape(-1, 2),
+             kp_octave=np.ascontiguousarray(frame["kp_octave"], np.int32),
+             desc=np.ascontiguousarray(frame["desc"], np.uint8).reshape(-1, 32),
+             kp_taken=np.ascontiguousarray(frame["kp_taken"], np.uint8))
+    for k in ("min_x", "min_y", "inv_w", "inv_h"):
+        f[k] = float(np.float32(frame[k]))
+    m = len(np.asarray(queries["uvr"]).reshape(-1, 3))
+    q = dict(uvr=np.ascontiguousarray(queries["uvr"], np.float32).reshape(-1, 3),
+             level_min=np.ascontiguousarray(queries["level_min"], np.int32),
+             level_max=np.ascontiguousarray(queries["level_max"], np.int32),
+             desc=np.ascontiguousarray(queries["desc"], np.uint8).reshape(-1, 32),
+             valid=np.ascontiguousarray(queries.get("valid", np.ones(m)), np.uint8),
+             takes=np.ascontiguousarray(queries.get("takes", np.ones(m)), np.uint8))
+    return f, q
 
 
 def matrix(q, t):

@@ -831,3 +831,94 @@ void orb_oracle_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint1
 }
 
 }  // extern "C"
+
+// ---- guided search: Frame grid + GetFeaturesInArea + the SearchByProjection loop body ----------
+// Frame::AssignFeaturesToGrid (Frame.cc:336-357), Frame::PosInGrid (:505-517),
+// Frame::GetFeaturesInArea (:447-502), ORBmatcher::SearchByProjection (ORBmatcher.cc:47-131; the
+// frame-to-frame variant :1332-1474 is the same loop with use_ratio = 0).  Mono.
+namespace {
+const int kGridCols = 64, kGridRows = 48;  // Frame.h:40-41
+struct FrameGrid {
+    std::vector<int> cell[kGridCols][kGridRows];
+};
+bool pos_in_grid(float px, float py, float minx, float miny, float invw, float invh, int& posX, int& posY) {
+    posX = (int)roundf((px - minx) * invw);
+    posY = (int)roundf((py - miny) * invh);
+    if (posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows) return false;
+    return true;
+}
+void features_in_area(const FrameGrid& g, const float* kp_xy, const int32_t* kp_octave, float minx, float miny, float invw,
+                      float invh, float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) {
+    out.clear();
+    const int nMinCellX = std::max(0, (int)floorf((x - minx - r) * invw));
+    if (nMinCellX >= kGridCols) return;
+    const int nMaxCellX = std::min((int)kGridCols - 1, (int)ceilf((x - minx + r) * invw));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)floorf((y - miny - r) * invh));
+    if (nMinCellY >= kGridRows) return;
+    const int nMaxCellY = std::min((int)kGridRows - 1, (int)ceilf((y - miny + r) * invh));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int>& vCell = g.cell[ix][iy];
+            for (size_t j = 0; j < vCell.size(); j++) {
+                const int k = vCell[j];
+                if (bCheckLevels) {
+                    if (kp_octave[k] < minLevel) continue;
+                    if (maxLevel >= 0)
+                        if (kp_octave[k] > maxLevel) continue;
+                }
+                const float distx = kp_xy[2 * k] - x, disty = kp_xy[2 * k + 1] - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) out.push_back(k);
+            }
+        }
+}
+}  // namespace
+
+extern "C" int orb_oracle_guided_search(int n, const float* kp_xy, const int32_t* kp_octave, const uint8_t* kp_desc,
+                                        const uint8_t* kp_taken, float minx, float miny, float invw, float invh, int m,
+                                        const float* uvr, const int32_t* lmin, const int32_t* lmax, const uint8_t* qdesc,
+                                        const uint8_t* valid, const uint8_t* takes, int th_dist, int use_ratio, float nnratio,
+                                        int32_t* match_kp, int32_t* out4) {
+    FrameGrid* g = new FrameGrid;
+    for (int i = 0; i < n; i++) {
+        int gx, gy;
+        if (pos_in_grid(kp_xy[2 * i], kp_xy[2 * i + 1], minx, miny, invw, invh, gx, gy)) g->cell[gx][gy].push_back(i);
+    }
+    std::vector<uint8_t> has_mp(kp_taken, kp_taken + n);
+    std::vector<int> vIndices;
+    int nmatches = 0;
+    for (int q = 0; q < m; q++) {
+        match_kp[q] = -1;
+        out4[4 * q] = 256; out4[4 * q + 1] = -1; out4[4 * q + 2] = 256; out4[4 * q + 3] = -1;
+        if (!valid[q]) continue;
+        features_in_area(*g, kp_xy, kp_octave, minx, miny, invw, invh, uvr[3 * q], uvr[3 * q + 1], uvr[3 * q + 2], lmin[q], lmax[q], vIndices);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t j = 0; j < vIndices.size(); j++) {
+            const int idx = vIndices[j];
+            if (has_mp[idx]) continue;
+            const int dist = descriptor_distance(qdesc + 32 * (size_t)q, kp_desc + 32 * (size_t)idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = kp_octave[idx];
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kp_octave[idx];
+                bestDist2 = dist;
+            }
+        }
+        out4[4 * q] = bestDist; out4[4 * q + 1] = bestLevel; out4[4 * q + 2] = bestDist2; out4[4 * q + 3] = bestLevel2;
+        if (bestDist <= th_dist) {
+            if (use_ratio && bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            match_kp[q] = bestIdx;
+            if (!takes || takes[q]) has_mp[bestIdx] = 1;
+            nmatches++;
+        }
+    }
+    delete g;
+    return nmatches;
+}
+
+

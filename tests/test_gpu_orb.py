@@ -197,3 +197,62 @@ def test_distinctive_descriptors_batch():
     assert np.array_equal(gi, oi) and np.array_equal(gm, om)
     with pytest.raises(api.SlamitError):
         api.ORBmatcher.distinctive(rs.randint(0, 256, (129, 32)).astype(np.uint8), [0, 129])
+
+
+# ---- guided search ------------------------------------------------------------------------------
+
+def _search_same(frame, queries, th, use_ratio, nnratio=0.8):
+    gm, gn, g4 = api.ORBmatcher.guided_search(frame, queries, th, use_ratio, nnratio)
+    om, on, o4 = ob.guided_search(frame, queries, th, use_ratio, nnratio)
+    assert np.array_equal(gm, om) and gn == on
+    assert np.array_equal(g4, o4)
+    return gm, gn
+
+
+@pytest.mark.parametrize("seed,n,m,crowd", [(0, 1500, 600, False), (1, 300, 900, True), (2, 0, 10, False), (3, 5, 0, False),
+                                             (4, 2500, 400, False), (5, 8191, 3000, False), (6, 1000, 2000, True)])
+def test_guided_search_synthetic(seed, n, m, crowd):
+    frame, queries = synth.synth_search(n, m, seed, th=6.0 if crowd else 3.0, crowd=crowd)
+    for use_ratio, th in ((True, 100), (False, 100), (True, 50)):
+        _search_same(frame, queries, th, use_ratio)
+
+
+def test_guided_search_kat_and_limits():
+    xy = np.array([[100, 100], [102, 101], [300, 300], [100.4, 99.6]], np.float32)
+    desc = np.zeros((4, 32), np.uint8)
+    desc[1, 0], desc[2], desc[3, 1] = 0x0F, 0xFF, 0x01
+    frame = dict(kp_xy=xy, kp_octave=np.array([1, 1, 0, 5], np.int32), desc=desc, kp_taken=np.zeros(4, np.uint8),
+                 min_x=0.0, min_y=0.0, inv_w=0.1, inv_h=0.1)
+    q = dict(uvr=np.array([[101, 100, 5], [101, 100, 5], [101, 100, 5], [300, 300, 0.5]], np.float32),
+             level_min=np.zeros(4, np.int32), level_max=np.array([1, 1, 1, -1], np.int32), desc=np.zeros((4, 32), np.uint8))
+    gm, gn = _search_same(frame, q, 100, False)
+    assert gm.tolist() == [0, 1, -1, -1] and gn == 2
+    big = synth.synth_search(8192, 4, 9)
+    with pytest.raises(api.SlamitError):
+        api.ORBmatcher.guided_search(big[0], big[1])
+    # every keypoint in one window: more candidates than SLAMIT_SEARCH_MAX_CAND -> loud capacity error
+    f, qq = synth.synth_search(1500, 4, 10, crowd=True)
+    qq["uvr"][:, 2] = 500.0
+    qq["level_min"][:] = 0
+    qq["level_max"][:] = -1
+    qq["valid"][:] = 1
+    with pytest.raises(api.SlamitError):
+        api.ORBmatcher.guided_search(f, qq)
+
+
+def test_guided_search_on_extracted_frames():
+    """Tracking-shaped use: keypoints of frame B searched with frame A's keypoints as 'map points'
+    projected through the known warp (here: identity + jitter), windows from the keypoint's octave."""
+    a = synth.synth_frame(640, 480, 50)
+    ext = api.ORBextractor(1000, 1.2, 8, 20, 7)
+    ka, da = ext(a)
+    kb, db = ext(synth.warp_frame(a, 50))
+    scale = ext.GetScaleFactors()
+    frame = dict(kp_xy=np.stack([kb["x"], kb["y"]], 1), kp_octave=kb["octave"], desc=db, kp_taken=np.zeros(len(kb), np.uint8),
+                 min_x=0.0, min_y=0.0, inv_w=float(np.float32(64) / np.float32(640)), inv_h=float(np.float32(48) / np.float32(480)))
+    r = (np.float32(15.0) * scale[ka["octave"]]).astype(np.float32)
+    q = dict(uvr=np.stack([ka["x"], ka["y"], r], 1), level_min=ka["octave"] - 1, level_max=ka["octave"] + 1, desc=da)
+    gm, gn = _search_same(frame, q, 100, False)
+    assert gn > 50
+    won = gm[gm >= 0]
+    assert len(np.unique(won)) == len(won)        # a keypoint is handed out once

@@ -374,3 +374,96 @@ def test_distinctive_descriptor_definition():
         D = np.unpackbits(rows[:, None, :] ^ rows[None, :, :], axis=-1).sum(-1)
         meds = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
         assert med[p] == meds.min() and idx[p] == int(np.argmin(meds))
+
+
+# ---- guided search (Frame grid + GetFeaturesInArea + SearchByProjection loop) ---------------------
+
+def _search_model(frame, queries, th_dist, use_ratio, nnratio):
+    """Independent numpy statement of the loop: candidates in cell-major (x, then y) order, inside a
+    cell by keypoint index; strict '<' best/second; taken marks carried forward."""
+    f, q = ob.normalize_search(frame, queries)
+    f32 = np.float32
+    xy, octv = f["kp_xy"], f["kp_octave"]
+    minx, miny, iw, ih = f32(f["min_x"]), f32(f["min_y"]), f32(f["inv_w"]), f32(f["inv_h"])
+
+    def rnd(v):  # C round(): half away from zero
+        return np.where(v >= 0, np.floor(v + f32(0.5)), np.ceil(v - f32(0.5))).astype(np.int64)
+
+    gx, gy = rnd((xy[:, 0] - minx) * iw), rnd((xy[:, 1] - miny) * ih)
+    ingrid = (gx >= 0) & (gx < 64) & (gy >= 0) & (gy < 48)
+    taken = f["kp_taken"].astype(bool).copy()
+    m = len(q["uvr"])
+    match, out4 = np.full(m, -1, np.int32), np.tile(np.array([256, -1, 256, -1], np.int32), (m, 1))
+    for i in range(m):
+        if not q["valid"][i]:
+            continue
+        x, y, r = (f32(v) for v in q["uvr"][i])
+        cx0, cx1 = max(0, int(np.floor((x - minx - r) * iw))), min(63, int(np.ceil((x - minx + r) * iw)))
+        cy0, cy1 = max(0, int(np.floor((y - miny - r) * ih))), min(47, int(np.ceil((y - miny + r) * ih)))
+        if cx0 >= 64 or cx1 < 0 or cy0 >= 48 or cy1 < 0:
+            continue
+        lo, hi = q["level_min"][i], q["level_max"][i]
+        ok = ingrid & (gx >= cx0) & (gx <= cx1) & (gy >= cy0) & (gy <= cy1) & (octv >= lo)
+        if hi >= 0:
+            ok &= octv <= hi
+        ok &= (np.abs(xy[:, 0] - x) < r) & (np.abs(xy[:, 1] - y) < r)
+        cand = np.nonzero(ok)[0]
+        if len(cand) == 0:
+            continue
+        cand = cand[np.lexsort((cand, gy[cand], gx[cand]))]
+        cand = cand[~taken[cand]]
+        if len(cand) == 0:
+            continue
+        d = np.unpackbits(f["desc"][cand] ^ q["desc"][i][None], axis=1).sum(1)
+        order = np.argsort(d, kind="stable")
+        b = order[0]
+        out4[i, 0], out4[i, 1] = d[b], octv[cand[b]]
+        if len(order) > 1:
+            out4[i, 2], out4[i, 3] = d[order[1]], octv[cand[order[1]]]
+        if out4[i, 0] <= th_dist:
+            if use_ratio and out4[i, 1] == out4[i, 3] and f32(out4[i, 0]) > f32(nnratio) * f32(out4[i, 2]):
+                continue
+            match[i] = cand[b]
+            if q["takes"][i]:
+                taken[cand[b]] = True
+    return match, int((match >= 0).sum()), out4
+
+
+def test_guided_search_kat():
+    """Hand-made: two queries aim at one keypoint; the first takes it, the second falls to the runner-up."""
+    xy = np.array([[100, 100], [102, 101], [300, 300], [100.4, 99.6]], np.float32)
+    octave = np.array([1, 1, 0, 5], np.int32)
+    desc = np.zeros((4, 32), np.uint8)
+    desc[1, 0] = 0x0F          # 4 bits from kp0
+    desc[2] = 0xFF
+    desc[3, 1] = 0x01          # 1 bit from kp0 but octave 5: outside [0,1]
+    frame = dict(kp_xy=xy, kp_octave=octave, desc=desc, kp_taken=np.zeros(4, np.uint8), min_x=0.0, min_y=0.0,
+                 inv_w=0.1, inv_h=0.1)
+    q = dict(uvr=np.array([[101, 100, 5], [101, 100, 5], [101, 100, 5], [300, 300, 0.5]], np.float32),
+             level_min=np.array([0, 0, 0, 0], np.int32), level_max=np.array([1, 1, 1, -1], np.int32),
+             desc=np.zeros((4, 32), np.uint8))
+    match, nm, out4 = ob.guided_search(frame, q, th_dist=100, use_ratio=False)
+    assert match.tolist() == [0, 1, -1, -1] and nm == 2
+    assert out4[0].tolist() == [0, 1, 4, 1] and out4[1].tolist() == [4, 1, 256, -1]
+    assert out4[2].tolist() == [256, -1, 256, -1]            # candidates exist but all are taken
+    assert out4[3].tolist() == [256, -1, 256, -1]            # kp2 is in the window, but distance 256 is not < 256
+    # ratio rule: best 4 vs second ... same level, 4 > 0.8 * 4 -> rejected
+    frame["kp_taken"] = np.array([1, 0, 0, 0], np.uint8)
+    desc2 = desc.copy(); desc2[0] = desc[1]
+    xy2 = xy.copy(); xy2[0] = (103, 100)
+    frame2 = dict(frame, desc=desc2, kp_xy=xy2, kp_taken=np.zeros(4, np.uint8))
+    match, nm, out4 = ob.guided_search(frame2, q, th_dist=100, use_ratio=True, nnratio=0.8)
+    assert out4[0].tolist() == [4, 1, 4, 1] and match[0] == -1
+
+
+@pytest.mark.parametrize("seed,n,m,crowd", [(0, 1500, 600, False), (1, 300, 900, True), (2, 0, 10, False), (3, 5, 0, False),
+                                             (4, 2500, 400, False)])
+def test_guided_search_matches_model(seed, n, m, crowd):
+    frame, queries = synth.synth_search(n, m, seed, th=3.0 if not crowd else 6.0, crowd=crowd)
+    for use_ratio, th in ((True, 100), (False, 100), (True, 50)):
+        got = ob.guided_search(frame, queries, th, use_ratio, 0.8)
+        exp = _search_model(frame, queries, th, use_ratio, 0.8)
+        assert np.array_equal(got[0], exp[0]) and got[1] == exp[1]
+        assert np.array_equal(got[2], exp[2])
+    if n and m and not crowd:
+        assert got[1] > m // 4

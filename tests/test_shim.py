@@ -143,3 +143,146 @@ def test_shim_optimizer_pose_optimization(tmp_path):
     assert inl == ref["n_inliers"] and np.array_equal(outl, ref["outlier"])
     want = np.concatenate([ref["pose"][:9].reshape(3, 3), ref["pose"][9:].reshape(3, 1)], 1)
     assert np.abs(T - want).max() < 1e-5 * max(np.abs(want).max(), 1.0)  # float32 write-back like the reference
+
+
+def _search_frame_blob(variant, frame, n, m, th, nnratio, scale, angle, state, max_x, max_y):
+    blob = struct.pack("<iiiff", variant, n, m, th, nnratio)
+    blob += struct.pack("<6f", frame["min_x"], max_x, frame["min_y"], max_y, frame["inv_w"], frame["inv_h"])
+    blob += scale.tobytes() + frame["kp_xy"].astype(np.float32).tobytes() + frame["kp_octave"].astype(np.int32).tobytes()
+    blob += angle.astype(np.float32).tobytes() + state.astype(np.int32).tobytes() + frame["desc"].tobytes()
+    return blob
+
+
+def _apply_in_order(n, state, match):
+    """What the reference's loop leaves in mvpMapPoints: a later query overwrites an earlier one (possible only
+    when the earlier map point had no observations)."""
+    owner = np.where(state > 0, -2, -1).astype(np.int32)
+    for q, k in enumerate(match):
+        if k >= 0:
+            owner[k] = q
+    return owner
+
+
+@pytest.mark.gpu
+def test_shim_search_by_projection_local_map(tmp_path):
+    """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) through the template + mock types."""
+    from oracle import bindings as ob
+    from weiner_slamit_v2_amd import synth
+
+    _build()
+    n, m, th, nnratio = 1800, 700, 3.0, 0.8
+    frame, qs = synth.synth_search(n, m, 31)
+    rs = np.random.RandomState(5)
+    scale = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    state = np.where(frame["kp_taken"] > 0, 1, rs.randint(0, 2, n) * 2).astype(np.int32)   # 1 taken, 2 = point w/o observations
+    viewcos = rs.choice(np.array([0.9995, 0.95], np.float32), m)
+    level = rs.randint(0, 8, m).astype(np.int32)
+    inview = (rs.rand(m) < 0.9).astype(np.int32)
+    bad = (rs.rand(m) < 0.05).astype(np.int32)
+    nobs = (rs.rand(m) < 0.95).astype(np.int32) * 3
+    proj = qs["uvr"][:, :2].astype(np.float32)
+    blob = _search_frame_blob(0, frame, n, m, th, nnratio, scale, np.zeros(n, np.float32), state, 645.1, 483.9)
+    blob += proj.tobytes() + viewcos.tobytes() + level.tobytes() + inview.tobytes() + bad.tobytes() + nobs.tobytes()
+    blob += qs["desc"].tobytes()
+    pin, pout = tmp_path / "s.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "search", str(pin), str(pout)])
+    r = np.fromfile(pout, np.int32)
+    assert r[0] == 0
+    # expected: the same queries, in order, through the oracle
+    keep = np.nonzero((inview != 0) & (bad == 0))[0]
+    rad = (np.where(viewcos > np.float32(0.998), np.float32(2.5), np.float32(4.0)).astype(np.float32) * np.float32(th)) * scale[level]
+    q = dict(uvr=np.concatenate([proj, rad[:, None]], 1)[keep], level_min=level[keep] - 1, level_max=level[keep],
+             desc=qs["desc"][keep], takes=(nobs[keep] > 0).astype(np.uint8))
+    f = dict(frame, kp_taken=(state == 1).astype(np.uint8))
+    match, nm, _ = ob.guided_search(f, q, 100, True, nnratio)
+    assert r[1] == nm and nm > 50
+    full = np.full(m, -1, np.int32)
+    full[keep] = match
+    assert np.array_equal(r[2:], _apply_in_order(n, state, full))
+
+
+@pytest.mark.gpu
+def test_shim_search_by_projection_last_frame(tmp_path):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono): projection on the host, search on the
+    device, rotation histogram on the host."""
+    from oracle import bindings as ob
+    from weiner_slamit_v2_amd import synth
+
+    _build()
+    f32 = np.float32
+    n, m, th = 1500, 1200, 15.0
+    rs = np.random.RandomState(8)
+    frame, _ = synth.synth_search(n, 4, 32)
+    scale = (f32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    fx, fy, cx, cy = f32(520.9), f32(521.0), f32(325.1), f32(249.7)
+    Rc, tc = synth.se3_exp(np.array([0.01, -0.02, 0.015, 0.03, -0.01, 0.02]))
+    Rc, tc = Rc.astype(np.float32), tc.astype(np.float32)
+    # last-frame map points: back-project current keypoints (with jitter) to depth 2..8 in the CURRENT camera
+    src = rs.randint(0, n, m)
+    depth = rs.uniform(2, 8, m)
+    px = frame["kp_xy"][src].astype(np.float64) + rs.uniform(-6, 6, (m, 2))
+    pc = np.stack([(px[:, 0] - cx) / fx * depth, (px[:, 1] - cy) / fy * depth, depth], 1)
+    pc[::50] *= -1                                      # some behind the camera
+    world = ((pc - tc.astype(np.float64)) @ Rc.astype(np.float64)).astype(np.float32)   # R^T (pc - t)
+    loct = frame["kp_octave"][src].astype(np.int32)
+    angle_cur = rs.uniform(0, 360, n).astype(np.float32)
+    lang = ((angle_cur[src] + np.where(rs.rand(m) < 0.8, 12.0, rs.uniform(0, 360, m))) % 360.0).astype(np.float32)
+    has = (rs.rand(m) < 0.9).astype(np.int32)
+    outl = (rs.rand(m) < 0.05).astype(np.int32)
+    nobs = (rs.rand(m) < 0.95).astype(np.int32) * 2
+    qdesc = frame["desc"][src].copy()
+    flip = rs.randint(0, 256, (m, 40))
+    for j in range(m):
+        for b in flip[j, :rs.randint(0, 40)]:
+            qdesc[j, b >> 3] ^= np.uint8(1 << (b & 7))
+    state = np.where(frame["kp_taken"] > 0, 1, 0).astype(np.int32)
+    Tcw = np.concatenate([Rc.reshape(-1), tc]).astype(np.float32)
+    blob = _search_frame_blob(1, frame, n, m, th, 0.9, scale, angle_cur, state, 645.1, 483.9)
+    blob += Tcw.tobytes() + Tcw.tobytes() + np.array([fx, fy, cx, cy, 0.08], np.float32).tobytes() + struct.pack("<i", 1)
+    blob += world.tobytes() + lang.tobytes() + has.tobytes() + outl.tobytes() + loct.tobytes() + nobs.tobytes() + qdesc.tobytes()
+    pin, pout = tmp_path / "s.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "search", str(pin), str(pout)])
+    r = np.fromfile(pout, np.int32)
+    assert r[0] == 0
+    # expected, float32 step by step as ORBmatcher.cc:1363-1386 computes it
+    X, Y, Z = world[:, 0], world[:, 1], world[:, 2]
+    xc = ((Rc[0, 0] * X + Rc[0, 1] * Y) + Rc[0, 2] * Z) + tc[0]
+    yc = ((Rc[1, 0] * X + Rc[1, 1] * Y) + Rc[1, 2] * Z) + tc[1]
+    zc = ((Rc[2, 0] * X + Rc[2, 1] * Y) + Rc[2, 2] * Z) + tc[2]
+    with np.errstate(divide="ignore"):
+        invz = (1.0 / zc.astype(np.float64)).astype(np.float32)
+    u = (fx * xc) * invz + cx
+    v = (fy * yc) * invz + cy
+    ok = (has != 0) & (outl == 0) & ~(invz < 0) & ~(u < f32(frame["min_x"])) & ~(u > f32(645.1)) & ~(v < f32(frame["min_y"])) & ~(v > f32(483.9))
+    keep = np.nonzero(ok)[0]
+    q = dict(uvr=np.stack([u, v, f32(th) * scale[loct]], 1)[keep], level_min=loct[keep] - 1, level_max=loct[keep] + 1,
+             desc=qdesc[keep], takes=(nobs[keep] > 0).astype(np.uint8))
+    match, nm, _ = ob.guided_search(dict(frame, kp_taken=(state == 1).astype(np.uint8)), q, 100, False, 0.9)
+    full = np.full(m, -1, np.int32)
+    full[keep] = match
+    owner = _apply_in_order(n, state, full)
+    # rotation histogram (ORBmatcher.cc:1436-1469): bins of bestIdx2 in visiting order
+    hist = [[] for _ in range(30)]
+    factor = f32(1.0) / f32(30)
+    for qi in keep:
+        k = full[qi]
+        if k < 0:
+            continue
+        rot = f32(lang[qi] - angle_cur[k])
+        if rot < 0:
+            rot = f32(rot + f32(360))
+        b = int(np.floor(f32(rot * factor) + f32(0.5)))
+        hist[0 if b == 30 else b].append(k)
+    sizes = [len(h) for h in hist]
+    order = sorted(range(30), key=lambda i: -sizes[i])
+    top = max(sizes)
+    assert top > 100 and sizes[order[1]] < 0.1 * top, "test premise: one dominant rotation bin"
+    for i in range(30):
+        if i != order[0]:
+            for k in hist[i]:
+                owner[k] = -1
+                nm -= 1
+    assert r[1] == nm
+    assert np.array_equal(r[2:], owner)

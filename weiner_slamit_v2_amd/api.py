@@ -55,6 +55,21 @@ class BaResult(C.Structure):
                 ("edge_outlier", C.c_void_p), ("edge_stage1_outlier", C.c_void_p), ("stats", C.c_void_p)]
 
 
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("kp_xy", C.c_void_p), ("kp_octave", C.c_void_p), ("desc", C.c_void_p),
+                ("kp_taken", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float), ("inv_w", C.c_float),
+                ("inv_h", C.c_float)]
+
+
+class SearchQueries(C.Structure):
+    _fields_ = [("m", C.c_int32), ("uvr", C.c_void_p), ("level_min", C.c_void_p), ("level_max", C.c_void_p),
+                ("desc", C.c_void_p), ("valid", C.c_void_p), ("takes", C.c_void_p)]
+
+
+class SearchRule(C.Structure):
+    _fields_ = [("th_dist", C.c_int32), ("use_ratio", C.c_int32), ("nnratio", C.c_float)]
+
+
 class PoseProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("pose", C.c_void_p), ("intr", C.c_void_p), ("xw", C.c_void_p),
                 ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p)]
@@ -71,7 +86,7 @@ EXPORTS = [
     "slamit_orb_create", "slamit_orb_destroy", "slamit_orb_tables", "slamit_orb_max_keypoints",
     "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
     "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
-    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
+    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
     "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
 ]
 
@@ -109,6 +124,8 @@ def lib():
         L.slamit_hamming_best2_batch_dev.argtypes = [vp, vp, sz, vp, vp, sz, i32, i32, vp, vp, vp, sz, i32, vp]
         L.slamit_hamming_matrix.argtypes = [vp, i32, vp, i32, vp]
         L.slamit_distinctive_batch.argtypes = [vp, vp, i32, vp, vp]
+        L.slamit_guided_search.argtypes = [i32, C.POINTER(FrameView), C.POINTER(SearchQueries), C.POINTER(SearchRule),
+                                           vp, vp, vp, vp, vp, vp]
         if hasattr(L, "slamit_ba_create"):
             L.slamit_ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
             L.slamit_ba_destroy.argtypes = [vp]
@@ -307,6 +324,43 @@ class ORBmatcher:
         _check(lib().slamit_distinctive_batch(_np_ptr(desc), _np_ptr(offsets), n, _np_ptr(idx), _np_ptr(med)),
                "slamit_distinctive_batch")
         return idx[:n], med[:n]
+
+    @staticmethod
+    def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8, device=0):
+        """The loop body of ORBmatcher::SearchByProjection (ORBmatcher.cc:47-131, :1332-1474) for all
+        queries in order: window query over the frame grid, best/second Hamming, accept, mark taken.
+        frame: dict kp_xy (n,2) f32, kp_octave (n) i32, desc (n,32) u8, kp_taken (n) u8, min_x, min_y,
+        inv_w, inv_h.  queries: dict uvr (m,3) f32, level_min, level_max (m) i32, desc (m,32) u8,
+        optional valid / takes (m) u8.  Returns (match_kp[m], nmatches, out4[m,4])."""
+        f = dict(kp_xy=np.ascontiguousarray(frame["kp_xy"], np.float32).reshape(-1, 2),
+                 kp_octave=np.ascontiguousarray(frame["kp_octave"], np.int32),
+                 desc=np.ascontiguousarray(frame["desc"], np.uint8).reshape(-1, 32),
+                 kp_taken=np.ascontiguousarray(frame["kp_taken"], np.uint8))
+        uvr = np.ascontiguousarray(queries["uvr"], np.float32).reshape(-1, 3)
+        m, n = len(uvr), len(f["kp_xy"])
+        q = dict(level_min=np.ascontiguousarray(queries["level_min"], np.int32),
+                 level_max=np.ascontiguousarray(queries["level_max"], np.int32),
+                 desc=np.ascontiguousarray(queries["desc"], np.uint8).reshape(-1, 32),
+                 valid=np.ascontiguousarray(queries.get("valid", np.ones(m)), np.uint8),
+                 takes=np.ascontiguousarray(queries.get("takes", np.ones(m)), np.uint8))
+        for k, a in list(f.items())[1:]:
+            if len(a) != n:
+                raise SlamitError("guided_search: frame[%s] has %d rows, expected %d" % (k, len(a), n))
+        for k, a in q.items():
+            if len(a) != m:
+                raise SlamitError("guided_search: queries[%s] has %d rows, expected %d" % (k, len(a), m))
+        fv = FrameView(n, _np_ptr(f["kp_xy"]), _np_ptr(f["kp_octave"]), _np_ptr(f["desc"]), _np_ptr(f["kp_taken"]),
+                       frame["min_x"], frame["min_y"], frame["inv_w"], frame["inv_h"])
+        sq = SearchQueries(m, _np_ptr(uvr), _np_ptr(q["level_min"]), _np_ptr(q["level_max"]), _np_ptr(q["desc"]),
+                           _np_ptr(q["valid"]), _np_ptr(q["takes"]))
+        rule = SearchRule(int(th_dist), int(bool(use_ratio)), float(nnratio))
+        match = np.full(max(m, 1), -1, np.int32)
+        out4 = np.zeros((4, max(m, 1)), np.int32)
+        nm = C.c_int32(0)
+        _check(lib().slamit_guided_search(device, C.byref(fv), C.byref(sq), C.byref(rule), _np_ptr(match), C.byref(nm),
+                                          _np_ptr(out4[0]), _np_ptr(out4[1]), _np_ptr(out4[2]), _np_ptr(out4[3])),
+               "slamit_guided_search")
+        return match[:m], nm.value, out4[:, :m].T.copy()
 
     def match(self, q, t, th=None):
         """All-pairs match with the reference's acceptance rule: best <= th and best < nnratio*second

@@ -46,6 +46,34 @@ bool ORBmatcher::BestTwo(const cv::Mat& query, const cv::Mat& train, std::vector
                                 bestDist.data(), secondDist.data()) == SLAMIT_OK;
 }
 
+static int g_status = 0;
+int ORBmatcher::LastStatus() { return g_status; }
+void ORBmatcher::setStatus(int rc) { g_status = rc; }
+
+bool ORBmatcher::GuidedSearch(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& descriptors,
+                              const std::vector<uint8_t>& kpTaken, float minX, float minY, float invW, float invH,
+                              const GuidedQueries& q, int thDist, bool useRatio, float nnratio, std::vector<int>& matchKp) {
+    const int n = (int)keysUn.size(), m = q.size();
+    matchKp.assign(m, -1);
+    g_status = SLAMIT_OK;
+    if (m == 0) return true;
+    std::vector<float> xy(2 * (size_t)n);
+    std::vector<int32_t> oct(n);
+    for (int i = 0; i < n; ++i) { xy[2 * i] = keysUn[i].pt.x; xy[2 * i + 1] = keysUn[i].pt.y; oct[i] = keysUn[i].octave; }
+    std::vector<uint8_t> td;
+    slamit_frame_view fv;
+    fv.n = n; fv.kp_xy = xy.data(); fv.kp_octave = oct.data(); fv.desc = n ? packed_rows(descriptors, td) : nullptr;
+    fv.kp_taken = kpTaken.data(); fv.min_x = minX; fv.min_y = minY; fv.inv_w = invW; fv.inv_h = invH;
+    slamit_search_queries sq;
+    sq.m = m; sq.uvr = q.uvr.data(); sq.level_min = q.lmin.data(); sq.level_max = q.lmax.data(); sq.desc = q.desc.data();
+    sq.valid = q.valid.data(); sq.takes = q.takes.data();
+    slamit_search_rule rule;
+    rule.th_dist = thDist; rule.use_ratio = useRatio ? 1 : 0; rule.nnratio = nnratio;
+    int nm = 0;
+    g_status = slamit_guided_search(0, &fv, &sq, &rule, matchKp.data(), &nm, nullptr, nullptr, nullptr, nullptr);
+    return g_status == SLAMIT_OK;
+}
+
 int ORBmatcher::SearchBruteForce(const std::vector<cv::KeyPoint>& keys1, const cv::Mat& desc1,
                                  const std::vector<cv::KeyPoint>& keys2, const cv::Mat& desc2,
                                  std::vector<int>& vnMatches12, int th) {

@@ -3,11 +3,18 @@
 //
 // In scope: DescriptorDistance, the best / second-best selection with
 // the reference's strict-'<' first-index rule, the TH_LOW / TH_HIGH / ratio acceptance and the
-// rotation-consistency histogram (ComputeThreeMaxima).  The eleven projection/BoW search drivers
-// stay with the caller for now (§8f "next" rank 2): they gather candidate index lists on the host
-// and then need exactly the batched distance + selection calls below.
+// rotation-consistency histogram (ComputeThreeMaxima), and — §8f "next" rank 2 — the two tracking-thread
+// guided searches, SearchByProjection(Frame&, vector<MapPoint*>&, th) and
+// SearchByProjection(CurrentFrame, LastFrame, th, bMono): projection and window sizing are host code
+// over the caller's Frame / MapPoint types (templates, like Optimizer.h), the grid window query +
+// Hamming best/second + greedy assignment of every map point is ONE slamit_guided_search call.
+// The remaining BoW / Sim3 / fuse / triangulation drivers stay with the caller.
 #ifndef SLAMIT_SHIM_ORBMATCHER_H
 #define SLAMIT_SHIM_ORBMATCHER_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
 
 #include <vector>
 
@@ -44,16 +51,163 @@ public:
                          const std::vector<cv::KeyPoint>& keys2, const cv::Mat& desc2,
                          std::vector<int>& vnMatches12, int th = -1);
 
+    // Tracking::SearchLocalPoints' search (ORBmatcher.cc:47-131).  Members used on the caller's types:
+    //   Frame    : mvKeysUn, mDescriptors, mvpMapPoints, mvuRight, mvScaleFactors, static mnMinX, mnMinY,
+    //              mfGridElementWidthInv, mfGridElementHeightInv
+    //   MapPoint : mbTrackInView, isBad(), mnTrackScaleLevel, mTrackViewCos, mTrackProjX, mTrackProjY,
+    //              GetDescriptor(), Observations()
+    // Mono only: a frame with a stereo keypoint (mvuRight > 0) is refused (returns 0, LastStatus() != 0).
+    template <class FrameT, class MapPointT>
+    int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3);
+
+    // Tracking::TrackWithMotionModel's search (ORBmatcher.cc:1332-1474).  Additional members:
+    //   Frame    : N, mTcw, mvbOutlier, mvKeys, fx, fy, cx, cy, mb, static mnMaxX, mnMaxY
+    //   MapPoint : GetWorldPos()
+    template <class FrameT>
+    int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono);
+
+    // The device call both templates make.  kp_taken / queries are in the order the reference visits them.
+    struct GuidedQueries {
+        std::vector<float> uvr;
+        std::vector<int32_t> lmin, lmax;
+        std::vector<uint8_t> desc, valid, takes;
+        void add(float u, float v, float r, int l0, int l1, const cv::Mat& d, bool takesKp) {
+            uvr.push_back(u); uvr.push_back(v); uvr.push_back(r);
+            lmin.push_back(l0); lmax.push_back(l1);
+            const uint8_t* p = d.ptr<uint8_t>(0);
+            desc.insert(desc.end(), p, p + 32);
+            valid.push_back(1); takes.push_back(takesKp ? 1 : 0);
+        }
+        int size() const { return (int)lmin.size(); }
+    };
+    static bool GuidedSearch(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& descriptors,
+                             const std::vector<uint8_t>& kpTaken, float minX, float minY, float invW, float invH,
+                             const GuidedQueries& q, int thDist, bool useRatio, float nnratio, std::vector<int>& matchKp);
+    static int LastStatus();
+
     static const int TH_LOW;
     static const int TH_HIGH;
     static const int HISTO_LENGTH;
 
 protected:
+    static void setStatus(int rc);
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
 
     float mfNNratio;
     bool mbCheckOrientation;
 };
+
+// ---- templates --------------------------------------------------------------------------------
+
+template <class FrameT, class MapPointT>
+int ORBmatcher::SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th) {
+    const bool bFactor = th != 1.0;
+    const int n = (int)F.mvKeysUn.size();
+    std::vector<uint8_t> taken(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (F.mvuRight[i] > 0) { setStatus(-2 /*SLAMIT_ERR_ARG*/); return 0; }
+        if (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) taken[i] = 1;
+    }
+    GuidedQueries q;
+    std::vector<MapPointT*> who;
+    for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
+        MapPointT* pMP = vpMapPoints[iMP];
+        if (!pMP->mbTrackInView) continue;
+        if (pMP->isBad()) continue;
+        const int nPredictedLevel = pMP->mnTrackScaleLevel;
+        // RadiusByViewingCos (ORBmatcher.cc:134-140)
+        float r = pMP->mTrackViewCos > 0.998 ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        q.add(pMP->mTrackProjX, pMP->mTrackProjY, r * F.mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel,
+              pMP->GetDescriptor(), pMP->Observations() > 0);
+        who.push_back(pMP);
+    }
+    std::vector<int> matchKp;
+    if (!GuidedSearch(F.mvKeysUn, F.mDescriptors, taken, F.mnMinX, F.mnMinY, F.mfGridElementWidthInv, F.mfGridElementHeightInv, q,
+                      TH_HIGH, true, mfNNratio, matchKp))
+        return 0;
+    int nmatches = 0;
+    for (size_t k = 0; k < who.size(); ++k)
+        if (matchKp[k] >= 0) { F.mvpMapPoints[matchKp[k]] = who[k]; nmatches++; }
+    return nmatches;
+}
+
+template <class FrameT>
+int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono) {
+    const int n = (int)CurrentFrame.mvKeysUn.size();
+    std::vector<uint8_t> taken(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (CurrentFrame.mvuRight[i] > 0) { setStatus(-2 /*SLAMIT_ERR_ARG*/); return 0; }
+        if (CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0) taken[i] = 1;
+    }
+    float Rcw[3][3], tcw[3], Rlw[3][3], tlw[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) { Rcw[r][c] = CurrentFrame.mTcw.template at<float>(r, c); Rlw[r][c] = LastFrame.mTcw.template at<float>(r, c); }
+        tcw[r] = CurrentFrame.mTcw.template at<float>(r, 3); tlw[r] = LastFrame.mTcw.template at<float>(r, 3);
+    }
+    float twc[3];
+    for (int r = 0; r < 3; ++r) twc[r] = -Rcw[0][r] * tcw[0] + -Rcw[1][r] * tcw[1] + -Rcw[2][r] * tcw[2];
+    const float tlc2 = Rlw[2][0] * twc[0] + Rlw[2][1] * twc[1] + Rlw[2][2] * twc[2] + tlw[2];
+    const bool bForward = tlc2 > CurrentFrame.mb && !bMono;
+    const bool bBackward = -tlc2 > CurrentFrame.mb && !bMono;
+
+    GuidedQueries q;
+    std::vector<int> who;   // index into LastFrame
+    for (int i = 0; i < LastFrame.N; i++) {
+        auto* pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP || LastFrame.mvbOutlier[i]) continue;
+        const cv::Mat x3Dw = pMP->GetWorldPos();
+        const float X = x3Dw.template at<float>(0, 0), Y = x3Dw.template at<float>(1, 0), Z = x3Dw.template at<float>(2, 0);
+        const float xc = Rcw[0][0] * X + Rcw[0][1] * Y + Rcw[0][2] * Z + tcw[0];
+        const float yc = Rcw[1][0] * X + Rcw[1][1] * Y + Rcw[1][2] * Z + tcw[1];
+        const float zc = Rcw[2][0] * X + Rcw[2][1] * Y + Rcw[2][2] * Z + tcw[2];
+        const float invzc = 1.0 / zc;
+        if (invzc < 0) continue;
+        const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+        const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        const int nLastOctave = LastFrame.mvKeys[i].octave;
+        const float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+        int l0, l1;
+        if (bForward) { l0 = nLastOctave; l1 = -1; }
+        else if (bBackward) { l0 = 0; l1 = nLastOctave; }
+        else { l0 = nLastOctave - 1; l1 = nLastOctave + 1; }
+        q.add(u, v, radius, l0, l1, pMP->GetDescriptor(), pMP->Observations() > 0);
+        who.push_back(i);
+    }
+    std::vector<int> matchKp;
+    if (!GuidedSearch(CurrentFrame.mvKeysUn, CurrentFrame.mDescriptors, taken, CurrentFrame.mnMinX, CurrentFrame.mnMinY,
+                      CurrentFrame.mfGridElementWidthInv, CurrentFrame.mfGridElementHeightInv, q, TH_HIGH, false, mfNNratio, matchKp))
+        return 0;
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (size_t k = 0; k < who.size(); ++k) {
+        const int bestIdx2 = matchKp[k];
+        if (bestIdx2 < 0) continue;
+        CurrentFrame.mvpMapPoints[bestIdx2] = LastFrame.mvpMapPoints[who[k]];
+        nmatches++;
+        if (mbCheckOrientation) {
+            float rot = LastFrame.mvKeysUn[who[k]].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdx2);
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                    CurrentFrame.mvpMapPoints[rotHist[i][j]] = nullptr;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
 
 }  // namespace ORB_SLAM2
 

@@ -4,6 +4,8 @@
 //     shim_test orb   <in.raw> <w> <h> <out.bin>
 //     shim_test match <descA.bin> <nA> <descB.bin> <nB> <out.bin>
 //     shim_test ba    <problem.bin> <out.bin>
+//     shim_test pose  <problem.bin> <out.bin>
+//     shim_test search <problem.bin> <out.bin>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -240,6 +242,133 @@ static int run_pose(int argc, char** argv) {
     return 0;
 }
 
+// ---- guided search: mock Frame / MapPoint with the members ORBmatcher.h documents -------------------
+struct MockTrackPoint {
+    bool mbTrackInView, bad;
+    int mnTrackScaleLevel, nobs, id;
+    float mTrackViewCos, mTrackProjX, mTrackProjY;
+    cv::Mat desc, pos;
+    bool isBad() { return bad; }
+    int Observations() { return nobs; }
+    cv::Mat GetDescriptor() { return desc.clone(); }
+    cv::Mat GetWorldPos() { return pos.clone(); }
+};
+struct MockSearchFrame {
+    int N;
+    cv::Mat mTcw, mDescriptors;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    std::vector<MockTrackPoint*> mvpMapPoints;
+    std::vector<float> mvuRight, mvScaleFactors;
+    std::vector<bool> mvbOutlier;
+    float fx, fy, cx, cy, mb;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+};
+float MockSearchFrame::mnMinX, MockSearchFrame::mnMaxX, MockSearchFrame::mnMinY, MockSearchFrame::mnMaxY;
+float MockSearchFrame::mfGridElementWidthInv, MockSearchFrame::mfGridElementHeightInv;
+
+struct Reader {
+    const unsigned char* p;
+    template <class T> T get() { T v; memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+    template <class T> const T* arr(size_t n) { const T* a = (const T*)p; p += n * sizeof(T); return a; }
+};
+
+static cv::Mat mat_from(const float* v, int rows) {
+    cv::Mat m(rows, 1, CV_32F);
+    for (int r = 0; r < rows; ++r) m.at<float>(r, 0) = v[r];
+    return m;
+}
+static cv::Mat pose_from(const float* p12) {   // R row-major (9) then t (3)
+    cv::Mat T = cv::Mat::zeros(4, 4, CV_32F);
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T.at<float>(r, c) = p12[3 * r + c]; T.at<float>(r, 3) = p12[9 + r]; }
+    T.at<float>(3, 3) = 1;
+    return T;
+}
+
+// problem.bin (all little-endian, 4-byte aligned arrays first):
+//   int32 variant n m ; float th nnratio ; float minx maxx miny maxy invw invh ; float scale[8]
+//   current frame: float xy[2n] ; int32 octave[n] ; float angle[n] ; int32 state[n] (0 none, 1 map point with
+//   observations, 2 map point without) ; u8 desc[32n]
+//   variant 0 (map points): float proj[2m] viewcos[m] ; int32 level[m] inview[m] bad[m] nobs[m] ; u8 desc[32m]
+//   variant 1 (last frame): float Tcw[12] Tlw[12] intr[5] ; int32 mono ; float world[3m] angle[m] ;
+//                           int32 has[m] outlier[m] octave[m] nobs[m] ; u8 desc[32m]
+// out.bin: int32 status nmatches ; int32 owner[n] (-1 none, -2 the frame's own earlier point, else query index)
+static int run_search(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<unsigned char> raw = slurp(argv[2]);
+    Reader R{raw.data()};
+    const int variant = R.get<int>(), n = R.get<int>(), m = R.get<int>();
+    const float th = R.get<float>(), nnratio = R.get<float>();
+    MockSearchFrame::mnMinX = R.get<float>(); MockSearchFrame::mnMaxX = R.get<float>();
+    MockSearchFrame::mnMinY = R.get<float>(); MockSearchFrame::mnMaxY = R.get<float>();
+    MockSearchFrame::mfGridElementWidthInv = R.get<float>(); MockSearchFrame::mfGridElementHeightInv = R.get<float>();
+    const float* scale = R.arr<float>(8);
+    const float* xy = R.arr<float>(2 * (size_t)n);
+    const int* oct = R.arr<int>(n);
+    const float* ang = R.arr<float>(n);
+    const int* state = R.arr<int>(n);
+    const unsigned char* desc = R.arr<unsigned char>(32 * (size_t)n);
+    MockSearchFrame F;
+    F.N = n;
+    F.mvScaleFactors.assign(scale, scale + 8);
+    F.mDescriptors = cv::Mat(n, 32, CV_8U);
+    F.mvKeysUn.resize(n); F.mvuRight.assign(n, -1.f); F.mvpMapPoints.assign(n, (MockTrackPoint*)0); F.mvbOutlier.assign(n, false);
+    MockTrackPoint own1, own2;
+    own1.nobs = 3; own2.nobs = 0; own1.id = own2.id = -2;
+    for (int i = 0; i < n; ++i) {
+        F.mvKeysUn[i] = cv::KeyPoint(xy[2 * i], xy[2 * i + 1], 31.f, ang[i], 0, oct[i]);
+        memcpy(F.mDescriptors.ptr(i), desc + 32 * (size_t)i, 32);
+        if (state[i] == 1) F.mvpMapPoints[i] = &own1;
+        if (state[i] == 2) F.mvpMapPoints[i] = &own2;
+    }
+    F.mvKeys = F.mvKeysUn;
+    std::vector<MockTrackPoint> mps(m);
+    int nm = 0;
+    if (variant == 0) {
+        const float* proj = R.arr<float>(2 * (size_t)m);
+        const float* vc = R.arr<float>(m);
+        const int* level = R.arr<int>(m); const int* inview = R.arr<int>(m); const int* bad = R.arr<int>(m); const int* nobs = R.arr<int>(m);
+        const unsigned char* qd = R.arr<unsigned char>(32 * (size_t)m);
+        std::vector<MockTrackPoint*> vp(m);
+        for (int q = 0; q < m; ++q) {
+            MockTrackPoint& p = mps[q];
+            p.id = q; p.mbTrackInView = inview[q] != 0; p.bad = bad[q] != 0; p.mnTrackScaleLevel = level[q]; p.nobs = nobs[q];
+            p.mTrackViewCos = vc[q]; p.mTrackProjX = proj[2 * q]; p.mTrackProjY = proj[2 * q + 1];
+            p.desc = cv::Mat(1, 32, CV_8U); memcpy(p.desc.ptr(0), qd + 32 * (size_t)q, 32);
+            vp[q] = &p;
+        }
+        ORBmatcher matcher(nnratio, true);
+        nm = matcher.SearchByProjection(F, vp, th);
+    } else {
+        const float* Tcw = R.arr<float>(12); const float* Tlw = R.arr<float>(12); const float* intr = R.arr<float>(5);
+        const int mono = R.get<int>();
+        const float* world = R.arr<float>(3 * (size_t)m); const float* lang = R.arr<float>(m);
+        const int* has = R.arr<int>(m); const int* outl = R.arr<int>(m); const int* loct = R.arr<int>(m); const int* nobs = R.arr<int>(m);
+        const unsigned char* qd = R.arr<unsigned char>(32 * (size_t)m);
+        MockSearchFrame L;
+        L.N = m; L.mTcw = pose_from(Tlw); F.mTcw = pose_from(Tcw);
+        F.fx = intr[0]; F.fy = intr[1]; F.cx = intr[2]; F.cy = intr[3]; F.mb = intr[4];
+        L.mvKeys.resize(m); L.mvpMapPoints.assign(m, (MockTrackPoint*)0); L.mvbOutlier.assign(m, false);
+        for (int q = 0; q < m; ++q) {
+            MockTrackPoint& p = mps[q];
+            p.id = q; p.nobs = nobs[q]; p.pos = mat_from(world + 3 * (size_t)q, 3);
+            p.desc = cv::Mat(1, 32, CV_8U); memcpy(p.desc.ptr(0), qd + 32 * (size_t)q, 32);
+            L.mvKeys[q] = cv::KeyPoint(0.f, 0.f, 31.f, lang[q], 0, loct[q]);
+            if (has[q]) L.mvpMapPoints[q] = &p;
+            L.mvbOutlier[q] = outl[q] != 0;
+        }
+        L.mvKeysUn = L.mvKeys;
+        ORBmatcher matcher(0.9f, true);
+        nm = matcher.SearchByProjection(F, L, th, mono != 0);
+    }
+    const int status = ORBmatcher::LastStatus();
+    if (status != 0) fprintf(stderr, "search failed: %s\n", slamit_last_error());
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(&status, 4, 1, f); fwrite(&nm, 4, 1, f);
+    for (int i = 0; i < n; ++i) { int o = F.mvpMapPoints[i] ? F.mvpMapPoints[i]->id : -1; fwrite(&o, 4, 1, f); }
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
@@ -247,5 +376,6 @@ int main(int argc, char** argv) {
     if (mode == "match") return run_match(argc, argv);
     if (mode == "ba") return run_ba(argc, argv);
     if (mode == "pose") return run_pose(argc, argv);
+    if (mode == "search") return run_search(argc, argv);
     return 2;
 }

@@ -217,3 +217,59 @@ def synth_pose(n=400, outlier_frac=0.15, seed=7, perturb=0.02):
     f32 = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).astype(np.float64))
     return {"pose": f32(pose), "intr": f32([fx, fy, cx, cy]), "xw": f32(xw), "uv": f32(np.stack([u, v], 1)),
             "inv_sigma2": f32(inv_sig), "truth_pose": np.concatenate([R.reshape(-1), t]), "truth_outlier": bad}
+
+
+def synth_search(n_kp=1500, m=600, seed=0, width=640, height=480, th=3.0, crowd=False):
+    """A guided-search problem in the shape Tracking::SearchLocalPoints hands to
+    ORBmatcher::SearchByProjection: a frame's undistorted keypoints + grid constants, and map-point
+    queries projected near some of them (several queries may aim at the same keypoint, which is what
+    makes the reference's loop order-dependent).  Returns (frame, queries) dicts for api / oracle."""
+    rs = np.random.RandomState(1000 + seed)
+    # undistorted image bounds are slightly outside the sensor (Frame::ComputeImageBounds)
+    min_x, max_x, min_y, max_y = np.float32(-4.3), np.float32(width + 5.1), np.float32(-2.7), np.float32(height + 3.9)
+    inv_w = np.float32(64) / np.float32(max_x - min_x)   # Frame.cc:90-91
+    inv_h = np.float32(48) / np.float32(max_y - min_y)
+    span = 60.0 if crowd else None
+    if crowd:
+        xy = np.stack([rs.uniform(300, 300 + span, n_kp), rs.uniform(200, 200 + span, n_kp)], 1).astype(np.float32)
+    else:
+        xy = np.stack([rs.uniform(min_x - 2, max_x + 2, n_kp), rs.uniform(min_y - 2, max_y + 2, n_kp)], 1).astype(np.float32)
+    octave = rs.randint(0, 8, n_kp).astype(np.int32)
+    desc = rs.randint(0, 256, (n_kp, 32)).astype(np.uint8)
+    taken = (rs.rand(n_kp) < 0.15).astype(np.uint8)
+    scale = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    tgt = rs.randint(0, max(n_kp, 1), m) if n_kp else np.zeros(m, np.int64)
+    tgt[m // 2:] = tgt[:m - m // 2][rs.permutation(m - m // 2)]        # second half re-targets the first half
+    uvr = np.zeros((m, 3), np.float32)
+    lmin, lmax = np.zeros(m, np.int32), np.zeros(m, np.int32)
+    qdesc = np.zeros((m, 32), np.uint8)
+    for q in range(m):
+        k = int(tgt[q]) if n_kp else 0
+        lvl = int(octave[k]) if n_kp else 0
+        pl = int(np.clip(lvl + rs.randint(-1, 2), 0, 7))                 # predicted level
+        r = np.float32(th) * np.float32(rs.choice([2.5, 4.0])) * scale[pl]
+        base = xy[k] if n_kp else np.zeros(2, np.float32)
+        uvr[q] = (base[0] + rs.uniform(-0.7, 0.7) * r, base[1] + rs.uniform(-0.7, 0.7) * r, r)
+        mode = rs.randint(0, 4)
+        if mode == 0:
+            lmin[q], lmax[q] = pl - 1, pl                                # SearchByProjection(F, MPs): [level-1, level]
+        elif mode == 1:
+            lmin[q], lmax[q] = pl, -1                                    # frame-to-frame, forward motion
+        elif mode == 2:
+            lmin[q], lmax[q] = 0, pl                                     # backward motion
+        else:
+            lmin[q], lmax[q] = pl - 1, pl + 1
+        d = (desc[k] if n_kp else np.zeros(32, np.uint8)).copy()
+        flips = rs.randint(0, 70)                                        # up to ~70 flipped bits around the target
+        for b in rs.randint(0, 256, flips):
+            d[b >> 3] ^= np.uint8(1 << (b & 7))
+        qdesc[q] = d
+    valid = (rs.rand(m) < 0.9).astype(np.uint8)
+    takes = (rs.rand(m) < 0.95).astype(np.uint8)
+    # a few windows entirely outside the grid
+    for q in range(0, m, 37):
+        uvr[q, 0] = max_x + 500.0 if (q // 37) % 2 else min_x - 500.0
+    frame = dict(kp_xy=xy, kp_octave=octave, desc=desc, kp_taken=taken, min_x=float(min_x), min_y=float(min_y),
+                 inv_w=float(inv_w), inv_h=float(inv_h))
+    queries = dict(uvr=uvr, level_min=lmin, level_max=lmax, desc=qdesc, valid=valid, takes=takes)
+    return frame, queries
