@@ -27,7 +27,8 @@ void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const Pyr
                   int smem_bytes, int nframes);
 size_t orbk_fast_smem(int max_wcell, int max_hcell);
 hipError_t orbk_fast_prepare(int max_wcell, int max_hcell);
-void orbk_fast(hipStream_t st, const OrbLevel* levels, int nlevels, int cells_per_frame, const uint8_t* img0,
+int orbk_fast_cells(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out);
+void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const uint32_t* d_cells, int cells_per_frame, const uint8_t* img0,
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, unsigned long long* cand,
                size_t cand_frame_stride, int* cand_count, int iniTh, int minTh, int max_wcell, int max_hcell, int nframes);
 size_t orbk_octree_smem(int node_cap);
@@ -99,7 +100,9 @@ struct slamit_orb {
     unsigned long long* d_cand;
     uint32_t* d_ws_xy;
     uint16_t* d_ws_node;
-    int* d_counts;  // [2][max_batch][nlevels]: cand_count, kp_count
+    uint32_t* d_cells;   // FAST cell table (orbk_fast_cells), fast_cells entries of 8 words
+    int fast_cells;
+    int* d_counts;  // cand_count [max_batch][nlevels][ORB_CC_PAD] then kp_count [max_batch][nlevels]
     OrbLevelKp* d_lkp;
     int* d_tab_i[ORB_MAX_LEVELS][2];      // xofs, yofs per level (level >= 1)
     short* d_tab_s[ORB_MAX_LEVELS][2];    // ialpha, ibeta
@@ -128,7 +131,7 @@ static void orb_free(slamit_orb* h) {
     if (!h) return;
     hipSetDevice(h->device);
     hipFree(h->d_levels); hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cand); hipFree(h->d_ws_xy);
-    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
+    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
     hipFree(h->d_out_desc); hipFree(h->d_out_n); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
@@ -252,7 +255,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
     ALLOC(h->d_cand, sizeof(unsigned long long) * h->cand_frame_stride * B);
     ALLOC(h->d_ws_xy, sizeof(uint32_t) * h->cand_frame_stride * B);
     ALLOC(h->d_ws_node, sizeof(uint16_t) * h->cand_frame_stride * B);
-    ALLOC(h->d_counts, sizeof(int) * 2 * B * nl);
+    ALLOC(h->d_counts, sizeof(int) * (ORB_CC_PAD + 1) * B * nl);
     ALLOC(h->d_lkp, sizeof(OrbLevelKp) * h->kp_frame_stride * B);
     h->d_in_stride = round_up((size_t)std::max(p->width, 1), 64);
     h->d_in_frame = h->d_in_stride * std::max(p->height, 1);
@@ -265,6 +268,12 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
     ALLOC(h->d_scratch, h->scratch_bytes);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess && !empty) e = hipMemcpy(h->d_levels, h->levels.data(), sizeof(OrbLevel) * nl, hipMemcpyHostToDevice);
+    {
+        std::vector<uint32_t> cells;
+        h->fast_cells = empty ? 0 : orbk_fast_cells(h->levels.data(), nl, cells);
+        ALLOC(h->d_cells, sizeof(uint32_t) * std::max<size_t>(cells.size(), 8));
+        if (e == hipSuccess && !cells.empty()) e = hipMemcpy(h->d_cells, cells.data(), sizeof(uint32_t) * cells.size(), hipMemcpyHostToDevice);
+    }
     for (int l = 1; l < nl && e == hipSuccess && !empty; ++l) {
         std::vector<int> xo, yo;
         std::vector<short> xa, ya;
@@ -394,8 +403,8 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     if (stride < (size_t)h->p.width || (nframes > 1 && frame_stride < stride * (size_t)h->p.height))
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: stride smaller than the frame");
     int* cand_count = h->d_counts;
-    int* kp_count = h->d_counts + (size_t)h->p.max_batch * nl;
-    HIP_TRY(hipMemsetAsync(cand_count, 0, sizeof(int) * nframes * nl, st));
+    int* kp_count = h->d_counts + (size_t)h->p.max_batch * nl * ORB_CC_PAD;
+    HIP_TRY(hipMemsetAsync(cand_count, 0, sizeof(int) * nframes * nl * ORB_CC_PAD, st));
     // K1: pyramid, level l from level l-1
     prof_mark(h, st, ST_RESIZE, true);
     if (h->pyr_regions) {
@@ -415,7 +424,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     prof_mark(h, st, ST_RESIZE, false);
     // K2: FAST + NMS + per-cell threshold fallback -> candidate lists
     prof_mark(h, st, ST_FAST, true);
-    orbk_fast(st, h->d_levels, nl, h->cells_per_frame, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
+    orbk_fast(st, h->levels.data(), nl, h->d_cells, h->fast_cells, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
               h->cand_frame_stride, cand_count, h->p.ini_th_fast, h->p.min_th_fast, h->max_wcell, h->max_hcell, nframes);
     prof_mark(h, st, ST_FAST, false);
     // K4: octree
@@ -525,7 +534,7 @@ int slamit_orb_debug_candidates(slamit_orb* h, int frame, int level, int32_t* xy
     HIP_TRY(hipSetDevice(h->device));
     const OrbLevel& L = h->levels[level];
     int n = 0;
-    HIP_TRY(hipMemcpy(&n, h->d_counts + frame * h->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, h->d_counts + (size_t)(frame * h->nlevels + level) * ORB_CC_PAD, sizeof(int), hipMemcpyDeviceToHost));
     n = std::min(n, L.cand_cap);
     *n_out = n;
     if (!xys || n == 0) return SLAMIT_OK;

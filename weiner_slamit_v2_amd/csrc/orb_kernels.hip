@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "orb_types.h"
 #include "slamit_math.h"
 #include "../../include/slamit.h"
@@ -228,9 +231,27 @@ __device__ __forceinline__ void wave_sync_lds() {
 
 #define FAST_LIST_CAP 448   // flushed to the scoring step whenever fewer than 256 slots are free
 
+#ifdef FAST_DIAG   // diagnostic builds only (tools/diag): per-phase wave cycles, one record per wave
+#define FD_MAXW 65536
+__device__ unsigned long long g_fast_ph[FD_MAXW * 8];
+extern "C" int slamit_diag_fast(unsigned long long* out, int reset) {
+    if (reset) { void* p; hipGetSymbolAddress(&p, HIP_SYMBOL(g_fast_ph)); return (int)hipMemset(p, 0, sizeof(unsigned long long) * FD_MAXW * 8); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_ph), sizeof(unsigned long long) * FD_MAXW * 8);
+}
+#define FD_DECL unsigned long long fd_ph[6] = {0, 0, 0, 0, 0, 0}, fd_prev = __builtin_amdgcn_s_memtime(), fd_surv = 0, fd_t0 = fd_prev
+#define FD_STAMP(i) do { unsigned long long tn = __builtin_amdgcn_s_memtime(); fd_ph[i] += tn - fd_prev; fd_prev = tn; } while (0)
+#define FD_FLUSH(npx) do { const int fd_w = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv; if (lane == 0 && fd_w < FD_MAXW) { \
+    unsigned long long* o = g_fast_ph + 8 * (size_t)fd_w; for (int k = 0; k < 5; ++k) o[k] = fd_ph[k]; \
+    o[5] = (fd_surv << 32) | (unsigned)(npx); o[6] = fd_t0; o[7] = fd_prev; } } while (0)
+#else
+#define FD_DECL
+#define FD_STAMP(i)
+#define FD_FLUSH(npx)
+#endif
+
 template <int PITCH>
 __global__ __launch_bounds__(256) void fast_cells_kernel(
-    const OrbLevel* __restrict__ levels, int nlevels, int cells_per_frame,
+    const FastTab tab, const uint4* __restrict__ cells, int nlevels, int ncells,
     const uint8_t* __restrict__ img0, unsigned img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr,
     unsigned long long* __restrict__ cand, size_t cand_frame_stride,
@@ -240,26 +261,26 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int frame = blockIdx.y;
     const int cell = blockIdx.x * 4 + wv;
-    if (cell >= cells_per_frame) return;
+    if (cell >= ncells) return;
+    FD_DECL;
     // per-wave LDS carve: image tile | score tile | survivor list | keypoint list
-    const int tile_bytes = tile_rows * PITCH + 16, sc_bytes = sc_rows * PITCH;
+    const int tile_bytes = (tile_rows * PITCH + 16 + 15) & ~15, sc_bytes = sc_rows * PITCH;
     const int per_wave = (tile_bytes + sc_bytes + 2 * FAST_LIST_CAP + 2 * kp_cap + 15) & ~15;
     uint8_t* tile = fsm + wv * per_wave;
     uint8_t* sc = tile + tile_bytes;
     unsigned short* s_list = reinterpret_cast<unsigned short*>(sc + sc_bytes);
     unsigned short* s_kp = s_list + FAST_LIST_CAP;
 
-    int level = 0;
-    while (level + 1 < nlevels && cell >= levels[level + 1].cell_base) ++level;
-    const OrbLevel& L = levels[level];
-    const int c = cell - L.cell_base;
-    const int ci = c / L.nCols, cj = c - ci * L.nCols;
-    const int iniX = ORB_MIN_BORDER + cj * L.wCell, iniY = ORB_MIN_BORDER + ci * L.hCell;
-    if (iniY >= L.maxBorderY - 3 || iniX >= L.maxBorderX - 6) return;  // ORBextractor.cc:810,819
-    const int cw = min(L.wCell + 6, L.maxBorderX - iniX);
-    const int ch = min(L.hCell + 6, L.maxBorderY - iniY);
+    // the cell's geometry and every division it needs, precomputed on the host (orbk_fast_cells): two scalar
+    // 16-byte loads instead of ~400 instructions of level search and integer division per wave
+    const uint4 ca = cells[2 * cell], cb = cells[2 * cell + 1];
+    const int level = (int)(ca.x & 255u), c = (int)(ca.x >> 8);
+    const int iniX = (int)(ca.y & 0xFFFFu), iniY = (int)(ca.y >> 16);
+    const int cw = (int)(ca.z & 255u), ch = (int)((ca.z >> 8) & 255u);
+    const int nd = (int)((ca.z >> 16) & 255u), rows_per_it = (int)(ca.z >> 24);
+    const unsigned inv_nd = ca.w, inv_g = cb.x, inv_sw = cb.y, inv_cw = cb.z;
+    const FastLevel& L = tab.lv[level];
     const int sw = cw - 6, sh = ch - 6;  // scan area = FAST's [3, n-3)
-    if (sw <= 0 || sh <= 0) return;
 
     const uint8_t* src;
     unsigned stride;
@@ -274,21 +295,33 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
         const unsigned shift = (unsigned)((uintptr_t)(src - 1) & 3);
         const uint8_t* abase = src - 1 - shift;            // 4-byte aligned iff the row pitch is
         const bool aligned = (stride & 3) == 0;
-        const int nd = (cw + 1 + 3) >> 2;                  // dwords per row (LDS cols 0 .. cw)
-        const int rows_per_it = 64 / nd > 0 ? 64 / nd : 1;
-        const int rsub = lane / nd, d = lane - rsub * nd;
+        const int rsub = (int)(__umul24(lane, inv_nd) >> 20), d = lane - rsub * nd;   // nd dwords per row (LDS cols 0 .. cw)
         if (aligned) {
-            for (int r0 = 0; r0 < ch; r0 += rows_per_it) {
-                const int r = r0 + rsub;
-                if (rsub < rows_per_it && r < ch) {
-                    const uint32_t* g = reinterpret_cast<const uint32_t*>(abase + __umul24(r, stride)) + d;
-                    const uint32_t lo = g[0], hi = g[1];
-                    *reinterpret_cast<uint32_t*>(&tile[r * PITCH + 4 * d]) = __builtin_amdgcn_alignbyte(hi, lo, shift);
+            // all global loads of up to 8 row groups are issued before the first LDS store: one memory
+            // round trip per wave instead of one per row group (rows past the window are clamped, not skipped)
+            const int rs = min(rsub, rows_per_it - 1);
+            const unsigned step = __umul24(rows_per_it, stride);
+            for (int r0 = 0; r0 < ch; r0 += 8 * rows_per_it) {
+                uint32_t lo[8], hi[8];
+                const unsigned last = __umul24(ch - 1, stride) + 4u * d;
+                unsigned off = __umul24(r0 + rs, stride) + 4u * d;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t* g = reinterpret_cast<const uint32_t*>(abase + min(off, last));
+                    lo[k] = g[0]; hi[k] = g[1];
+                    off += step;
+                }
+                uint8_t* t = &tile[(r0 + rsub) * PITCH + 4 * d];
+                int r = r0 + rsub;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (rsub < rows_per_it && r < ch)
+                        *reinterpret_cast<uint32_t*>(t) = __builtin_amdgcn_alignbyte(hi[k], lo[k], shift);
+                    t += rows_per_it * PITCH; r += rows_per_it;
                 }
             }
         } else {
             const int npx = cw * ch;
-            const unsigned inv_cw = (1u << 20) / (unsigned)cw + 1;
             for (int p = lane; p < npx; p += WAVE) {
                 const int r = (int)(__umul24(p, inv_cw) >> 20);
                 const int cc = p - r * cw;
@@ -296,13 +329,15 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
             }
         }
     }
-    for (int i = lane; i < sc_bytes / 4; i += WAVE) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    {   // zero the rows of the score tile this cell uses (plus the ring around them), 16 bytes per lane
+        const int nz = ((sh + 2) * PITCH + 15) >> 4;
+        for (int i = lane; i < nz; i += WAVE) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     wave_sync_lds();
+    FD_STAMP(0);
 
     const int ngrp = (sw + 3) >> 2;          // groups of 4 scan pixels per row
     const int nitems = ngrp * sh;
-    const unsigned inv_g = (1u << 20) / (unsigned)ngrp + 1;
-    const unsigned inv_sw = (1u << 20) / (unsigned)sw + 1;
 
     // Two attempts like the reference: FAST at iniThFAST, and only if the cell stays empty, again at
     // minThFAST (ORBextractor.cc:827-833).  Per attempt:
@@ -343,11 +378,14 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
                     const unsigned dN = DARK(N), dE = DARK(E), dS = DARK(S), dW = DARK(Wv);
 #undef BRIGHT
 #undef DARK
-                    flags = ((bN & bE) | (bE & bS) | (bS & bW) | (bW & bN) | (dN & dE) | (dE & dS) | (dS & dW) | (dW & dN)) & 0x80808080u;
+                    // two adjacent compass points of one polarity: NE | ES | SW | WN == (N | S) & (E | W)
+                    flags = (((bN | bS) & (bE | bW)) | ((dN | dS) & (dE | dW))) & 0x80808080u;
+                    const int over = x0 + 4 - sw;            // pixels of this group beyond the scan row (0..3)
+                    if (over > 0) flags &= 0x80808080u >> (8 * over);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int pass = ((flags >> (8 * j + 7)) & 1u) && (x0 + j < sw);
+                    const int pass = (flags >> (8 * j + 7)) & 1u;
                     const unsigned long long m = __ballot(pass);
                     if (pass) s_list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(y * sw + x0 + j);
                     nlist += __popcll(m);
@@ -356,6 +394,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
             // score the listed pixels once the list could overflow, and at the end
             if (nlist > FAST_LIST_CAP - 256 || i0 + WAVE >= nitems) {
                 wave_sync_lds();
+                FD_STAMP(1);
+#ifdef FAST_DIAG
+                fd_surv += nlist;
+#endif
                 for (int i = lane; i < nlist; i += WAVE) {
                     const int p = s_list[i];
                     const int y = (int)(__umul24(p, inv_sw) >> 20);
@@ -365,6 +407,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
                 }
                 wave_sync_lds();
                 nlist = 0;
+                FD_STAMP(2);
             }
         }
         // NMS straight off the score tile, 4 pixels per lane, zero dwords skipped
@@ -392,21 +435,26 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = (keep >> j) & 1u;
-                const unsigned long long m = __ballot(k);
-                if (k) s_kp[nkp + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(y * sw + x0 + j);
-                nkp += __popcll(m);
+            // two strict maxima are never adjacent, so a group of 4 keeps at most 2 pixels: two ballots compact them
+            const int cnt = __popc(keep);
+            const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2);
+            if (b1) {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int pos = nkp + __popcll(b1 & lt) + __popcll(b2 & lt);
+                const int p0 = y * sw + x0;
+                if (cnt >= 1) s_kp[pos] = (unsigned short)(p0 + __ffs(keep) - 1);
+                if (cnt >= 2) s_kp[pos + 1] = (unsigned short)(p0 + 31 - __clz(keep));
+                nkp += __popcll(b1) + __popcll(b2);
             }
         }
         wave_sync_lds();
+        FD_STAMP(3);
         if (nkp > 0 || minTh >= th) break;  // found corners, or the retry cannot find more
         th = minTh;
     }
-    if (nkp == 0) return;
+    if (nkp == 0) { FD_FLUSH(sw * sh); return; }
     int base = 0;
-    if (lane == 0) base = atomicAdd(&cand_count[frame * nlevels + level], nkp);
+    if (lane == 0) base = atomicAdd(&cand_count[(frame * nlevels + level) * ORB_CC_PAD], nkp);
     base = __shfl(base, 0, WAVE);
     unsigned long long* out = cand + L.cand_off + (size_t)frame * cand_frame_stride;
     for (int i = lane; i < nkp; i += WAVE) {
@@ -418,6 +466,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
         const int o = base + i;
         if (o < L.cand_cap) out[o] = ((unsigned long long)S << 32) | order;
     }
+    FD_STAMP(4);
+    FD_FLUSH(sw * sh);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -501,7 +551,7 @@ __global__ __launch_bounds__(256) void octree_kernel(
     __shared__ int s_n, s_expand, s_k, s_flag;
 
     const int kidx = frame * nlevels + level;
-    const int n_keys = min(cand_count[kidx], L.cand_cap);
+    const int n_keys = min(cand_count[kidx * ORB_CC_PAD], L.cand_cap);
     const int N = L.quota;
     const unsigned long long* K = cand + L.cand_off + (size_t)frame * cand_frame_stride;
     uint32_t* XY = ws_xy + L.cand_off + (size_t)frame * cand_frame_stride;
@@ -1017,8 +1067,8 @@ size_t orbk_fast_smem(int max_wcell, int max_hcell) {
     const int P = fast_pitch(max_wcell);
     const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
     const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
-    const int per_wave = (tile_rows * P + 16 + sc_rows * P + 2 * FAST_LIST_CAP + 2 * kp_cap + 15) & ~15;
-    return (size_t)4 * per_wave;
+    const int per_wave = (((tile_rows * P + 16 + 15) & ~15) + sc_rows * P + 2 * FAST_LIST_CAP + 2 * kp_cap + 15) & ~15;
+    return (size_t)4 * per_wave + 16;   // + the score tile's zeroing may round its last 16-byte store up
 }
 
 hipError_t orbk_fast_prepare(int max_wcell, int max_hcell) {
@@ -1028,7 +1078,34 @@ hipError_t orbk_fast_prepare(int max_wcell, int max_hcell) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<72>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
-void orbk_fast(hipStream_t st, const OrbLevel* levels, int nlevels, int cells_per_frame,
+// Cell table: the non-empty FAST cells of every level in the reference's visiting order (level, row, column;
+// ORBextractor.cc:805-822), 8 words per cell:
+//   0: level | cell index in the level << 8      1: iniX | iniY << 16
+//   2: cw | ch << 8 | nd << 16 | rows_per_it << 24   (window size; dwords per staged row; staged rows per wave pass)
+//   3..6: division magics  floor(2^20 / g) + 1  for g = nd, (sw + 3) / 4, sw, cw
+int orbk_fast_cells(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out) {
+    out.clear();
+    auto magic = [](int g) { return (uint32_t)((1u << 20) / (unsigned)std::max(g, 1) + 1u); };
+    for (int l = 0; l < nlevels; ++l) {
+        const OrbLevel& L = host_levels[l];
+        for (int c = 0; c < L.ncells; ++c) {
+            const int ci = c / L.nCols, cj = c - ci * L.nCols;
+            const int iniX = ORB_MIN_BORDER + cj * L.wCell, iniY = ORB_MIN_BORDER + ci * L.hCell;
+            if (iniY >= L.maxBorderY - 3 || iniX >= L.maxBorderX - 6) continue;  // ORBextractor.cc:810,819
+            const int cw = std::min(L.wCell + 6, L.maxBorderX - iniX), ch = std::min(L.hCell + 6, L.maxBorderY - iniY);
+            const int sw = cw - 6, sh = ch - 6;
+            if (sw <= 0 || sh <= 0) continue;
+            const int nd = (cw + 1 + 3) >> 2, rpi = std::max(64 / nd, 1);
+            const uint32_t w[8] = {(uint32_t)l | ((uint32_t)c << 8), (uint32_t)iniX | ((uint32_t)iniY << 16),
+                                   (uint32_t)cw | ((uint32_t)ch << 8) | ((uint32_t)nd << 16) | ((uint32_t)rpi << 24),
+                                   magic(nd), magic((sw + 3) >> 2), magic(sw), magic(cw), 0u};
+            out.insert(out.end(), w, w + 8);
+        }
+    }
+    return (int)(out.size() / 8);
+}
+
+void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const uint32_t* d_cells, int cells_per_frame,
                const uint8_t* img0, size_t img0_stride, size_t img0_frame, const uint8_t* pyr,
                unsigned long long* cand, size_t cand_frame_stride, int* cand_count, int iniTh, int minTh,
                int max_wcell, int max_hcell, int nframes) {
@@ -1036,12 +1113,20 @@ void orbk_fast(hipStream_t st, const OrbLevel* levels, int nlevels, int cells_pe
     const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
     const dim3 grid((cells_per_frame + 3) / 4, nframes);
     const size_t smem = orbk_fast_smem(max_wcell, max_hcell);
+    FastTab tab = {};
+    for (int l = 0; l < nlevels && l < ORB_MAX_LEVELS; ++l) {
+        const OrbLevel& S = host_levels[l];
+        FastLevel& D = tab.lv[l];
+        D.cell_base = S.cell_base; D.nCols = S.nCols; D.wCell = S.wCell; D.hCell = S.hCell;
+        D.maxBorderX = S.maxBorderX; D.maxBorderY = S.maxBorderY; D.stride = S.stride; D.cand_cap = S.cand_cap;
+        D.plane_off = S.plane_off; D.plane_bytes = S.plane_bytes; D.cand_off = S.cand_off;
+    }
     if (fast_pitch(max_wcell) == 48)
-        hipLaunchKernelGGL(fast_cells_kernel<48>, grid, dim3(256), smem, st, levels, nlevels, cells_per_frame, img0,
+        hipLaunchKernelGGL(fast_cells_kernel<48>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
                            (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
                            sc_rows, kp_cap);
     else
-        hipLaunchKernelGGL(fast_cells_kernel<72>, grid, dim3(256), smem, st, levels, nlevels, cells_per_frame, img0,
+        hipLaunchKernelGGL(fast_cells_kernel<72>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
                            (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
                            sc_rows, kp_cap);
 }

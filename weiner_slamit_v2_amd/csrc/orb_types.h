@@ -10,6 +10,8 @@
 #define ORB_MIN_BORDER 16        // EDGE_THRESHOLD - 3   (ORBextractor.cc:789)
 #define ORB_CELL_MAX 59          // wCell, hCell < 60 because nCols = floor(width/30)
 #define ORB_TILE_MAX (ORB_CELL_MAX + 6)
+#define ORB_CC_PAD 32            // ints between two (frame, level) candidate counters: one 128-byte line each, so the
+                                 // FAST waves' atomics do not serialise on one L2 line
 
 // One pyramid level.  Planes of all frames of a batch are stored level-major:
 //   plane(level, frame) = pyr + plane_off + frame * plane_bytes, rows of `stride` bytes
@@ -42,6 +44,14 @@ struct OrbLevel {
     float scale;               // mvScaleFactor[level]
     float patch_size;          // (float)(int)(31 * scale)
 };
+
+// What fast_cells_kernel needs of every level, passed BY VALUE in the kernel arguments: a wave finds its level
+// and geometry with scalar loads of known addresses instead of a chain of dependent loads through a table in HBM.
+struct FastLevel {
+    int32_t cell_base, nCols, wCell, hCell, maxBorderX, maxBorderY, stride, cand_cap;
+    uint64_t plane_off, plane_bytes, cand_off;
+};
+struct FastTab { FastLevel lv[ORB_MAX_LEVELS]; };
 
 // Fused pyramid: one workgroup builds ALL levels of one image region, each level out of the
 // previous one held in LDS.  Per (block, level): the region whose pixels this block stores to HBM
