@@ -137,6 +137,34 @@ def test_device_buffer_entry_point():
         _assert_same(kg, d_desc[i, :n[i]].cpu().numpy(), ko, do, "dev[%d]" % i)
 
 
+def test_device_buffer_unaligned_views():
+    """Caller-owned device images that are NOT 4-byte aligned (odd row pitch, odd base address): the extractor
+    takes its byte-wise staging paths and the fused-pyramid fallback; results stay bit-exact."""
+    import torch
+
+    frames = np.stack([synth.synth_frame(640, 480, 60 + i) for i in range(2)])
+    ext, orc = api.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=2), ob.OrbOracle(1000)
+    ext._bind(640, 480, 2)
+    cap = ext.max_keypoints
+    for pitch, lead in ((643, 1), (641, 0), (644, 2)):
+        big = torch.zeros((2, 481, pitch), dtype=torch.uint8, device="cuda")
+        flat = big.view(-1)[lead:lead + 2 * 481 * pitch - pitch]
+        view = flat.as_strided((2, 480, 640), (481 * pitch, pitch, 1))
+        view.copy_(torch.from_numpy(frames).cuda())
+        d_kps = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(2, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ext.extract_batch_dev(view, d_kps, d_desc, d_n, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        n = d_n.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(np.uint8).reshape(2, cap, 28)
+        for i in range(2):
+            ko, do = orc.extract(frames[i])
+            kg = kps[i, :n[i]].copy().view(api.KP_DTYPE).reshape(-1)
+            _assert_same(kg, d_desc[i, :n[i]].cpu().numpy(), ko, do, "pitch%d+%d[%d]" % (pitch, lead, i))
+
+
 # ---- Hamming ------------------------------------------------------------------------------------
 
 def test_hamming_random_and_ties():

@@ -21,10 +21,14 @@ hipError_t orbk_upload_pattern(hipStream_t st);
 void orbk_resize(hipStream_t st, const uint8_t* src, int sw, int sh, size_t sstride, size_t sframe,
                  uint8_t* dst, int dw, int dh, size_t dstride, size_t dframe, const int* xofs,
                  const short* ialpha, const int* yofs, const short* ibeta, int nframes);
+bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const short* ialpha, const int* yofs,
+                        const short* ibeta, std::vector<uint32_t>& col, std::vector<uint32_t>& row);
+void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, uint8_t* dst, int dw, int dh,
+                       size_t dstride, size_t dframe, const uint32_t* d_col, const uint32_t* d_row, int nframes);
 hipError_t orbk_pyramid_prepare(int smem_bytes);
 void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const PyrBox* boxes, const PyrTabs* tabs,
                   int nregions, const uint8_t* img0, size_t img0_stride, size_t img0_frame, uint8_t* pyr, int bufA_bytes,
-                  int smem_bytes, int nframes);
+                  int smem_bytes, int nframes, int l_first, int l_last, int threads);
 size_t orbk_fast_smem(int max_wcell, int max_hcell);
 hipError_t orbk_fast_prepare(int max_wcell, int max_hcell);
 int orbk_fast_cells(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out);
@@ -106,9 +110,13 @@ struct slamit_orb {
     OrbLevelKp* d_lkp;
     int* d_tab_i[ORB_MAX_LEVELS][2];      // xofs, yofs per level (level >= 1)
     short* d_tab_s[ORB_MAX_LEVELS][2];    // ialpha, ibeta
+    uint32_t* d_rs_col[ORB_MAX_LEVELS];   // resize_rows4_kernel tables (orbk_resize_tables)
+    uint32_t* d_rs_row[ORB_MAX_LEVELS];
+    int pyr_mode;                         // 0 per-level rows4 (default), 1 fused segments (SLAMIT_PYR_FUSED)
     PyrBox* d_boxes;                      // fused pyramid: [nregions][nlevels]
     PyrTabs* d_tabs;                      // [nlevels]
-    int pyr_regions, pyr_bufA, pyr_smem;
+    struct PyrSeg { int first, last, nregions, box_off, bufA, smem, threads; };
+    std::vector<PyrSeg> pyr_segs;          // empty = per-level fallback kernel
     // staging for the host-pointer entry points
     uint8_t* d_in;
     size_t d_in_stride, d_in_frame;
@@ -135,6 +143,7 @@ static void orb_free(slamit_orb* h) {
     hipFree(h->d_out_desc); hipFree(h->d_out_n); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
+    for (int l = 0; l < ORB_MAX_LEVELS; ++l) { hipFree(h->d_rs_col[l]); hipFree(h->d_rs_row[l]); }
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -274,6 +283,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         ALLOC(h->d_cells, sizeof(uint32_t) * std::max<size_t>(cells.size(), 8));
         if (e == hipSuccess && !cells.empty()) e = hipMemcpy(h->d_cells, cells.data(), sizeof(uint32_t) * cells.size(), hipMemcpyHostToDevice);
     }
+    bool rows4_ok = true;
     for (int l = 1; l < nl && e == hipSuccess && !empty; ++l) {
         std::vector<int> xo, yo;
         std::vector<short> xa, ya;
@@ -285,8 +295,18 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         if (e == hipSuccess) e = hipMemcpy(h->d_tab_i[l][1], yo.data(), yo.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(h->d_tab_s[l][0], xa.data(), xa.size() * 2, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(h->d_tab_s[l][1], ya.data(), ya.size() * 2, hipMemcpyHostToDevice);
+        std::vector<uint32_t> ct, rt;
+        if (!orbk_resize_tables(h->levels[l].w, h->levels[l].h, h->levels[l - 1].w, h->levels[l - 1].h, xo.data(), xa.data(), yo.data(),
+                                ya.data(), ct, rt))
+            rows4_ok = false;
+        ALLOC(h->d_rs_col[l], ct.size() * 4); ALLOC(h->d_rs_row[l], rt.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(h->d_rs_col[l], ct.data(), ct.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->d_rs_row[l], rt.data(), rt.size() * 4, hipMemcpyHostToDevice);
     }
-    // ---- fused pyramid: per-region boxes (own / need) for every level ----
+    // ---- fused pyramid: the levels are built in SEGMENTS (default: 0 -> 1,2 | 2 -> 3,4 | 4 -> 5..): one launch
+    // per segment, each workgroup reads its patch of the segment's first level and produces the following levels
+    // out of LDS.  Short segments keep the halo (pixels computed only because a deeper level needs them) small;
+    // per region and level the boxes say what it stores ("own") and what it has to compute ("need").
     if (e == hipSuccess && !empty && nl > 1) {
         std::vector<std::vector<int> > XO(nl), YO(nl);
         for (int l = 1; l < nl; ++l) {
@@ -294,52 +314,80 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
             resize_axis(h->levels[l].w, h->levels[l - 1].w, true, XO[l], dummy);
             resize_axis(h->levels[l].h, h->levels[l - 1].h, false, YO[l], dummy);
         }
-        const int GX = std::max(1, (p->width + 127) / 128), GY = std::max(1, (p->height + 95) / 96);
-        std::vector<PyrBox> boxes((size_t)GX * GY * nl);
-        size_t capA = 16, capB = 16;
+        // Default: ONE segment, regions of 128x96 level-0 pixels (what the unaligned / large-scale-factor fallback was
+        // tuned for).  SLAMIT_PYR_SEGS="2,4" / SLAMIT_PYR_TILE="64x48" (tile at the segment's last level) are
+        // diagnostic knobs for experiments with shorter chains.
+        std::vector<int> cuts;
+        if (const char* sv = getenv("SLAMIT_PYR_SEGS"))
+            for (const char* q = sv; *q;) { int v = atoi(q); if (v > 0 && v < nl - 1) cuts.push_back(v); while (*q && *q != ',') ++q; if (*q) ++q; }
+        std::sort(cuts.begin(), cuts.end());
+        cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+        int tw = 0, th = 0;
+        if (const char* sv = getenv("SLAMIT_PYR_TILE")) { if (sscanf(sv, "%dx%d", &tw, &th) != 2 || tw < 8 || th < 8) tw = th = 0; }
+        std::vector<PyrBox> boxes;
         bool okb = true;
-        for (int gy = 0; gy < GY && okb; ++gy)
-            for (int gx = 0; gx < GX && okb; ++gx) {
-                PyrBox* B = &boxes[((size_t)gy * GX + gx) * nl];
-                for (int l = 0; l < nl; ++l) {
-                    const OrbLevel& L = h->levels[l];
-                    B[l].ox0 = (int16_t)((long)gx * L.w / GX); B[l].ox1 = (int16_t)((long)(gx + 1) * L.w / GX);
-                    B[l].oy0 = (int16_t)((long)gy * L.h / GY); B[l].oy1 = (int16_t)((long)(gy + 1) * L.h / GY);
-                    if (l == 0) { B[l].ox0 = B[l].ox1 = B[l].oy0 = B[l].oy1 = 0; }  // level 0 is only read
-                    else if (B[l].ox1 <= B[l].ox0 || B[l].oy1 <= B[l].oy0) okb = false;
-                }
-                B[nl - 1].nx0 = B[nl - 1].ox0; B[nl - 1].nx1 = B[nl - 1].ox1;
-                B[nl - 1].ny0 = B[nl - 1].oy0; B[nl - 1].ny1 = B[nl - 1].oy1;
-                for (int l = nl - 1; l >= 1 && okb; --l) {
-                    const int sw = h->levels[l - 1].w, sh = h->levels[l - 1].h;
-                    int sx0 = XO[l][B[l].nx0], sx1 = std::min(XO[l][B[l].nx1 - 1] + 1, sw - 1) + 1;
-                    int sy0 = std::min(std::max(YO[l][B[l].ny0], 0), sh - 1);
-                    int sy1 = std::min(std::max(YO[l][B[l].ny1 - 1] + 1, 0), sh - 1) + 1;
-                    if (l - 1 >= 1) {
-                        sx0 = std::min(sx0, (int)B[l - 1].ox0); sx1 = std::max(sx1, (int)B[l - 1].ox1);
-                        sy0 = std::min(sy0, (int)B[l - 1].oy0); sy1 = std::max(sy1, (int)B[l - 1].oy1);
+        int first = 0;
+        h->pyr_segs.clear();
+        for (size_t si = 0; si <= cuts.size() && okb; ++si) {
+            const int last = si < cuts.size() ? cuts[si] : nl - 1;
+            slamit_orb::PyrSeg seg;
+            seg.first = first; seg.last = last; seg.box_off = (int)boxes.size();
+            const OrbLevel& LL = h->levels[last];
+            const int GX = tw ? std::max(1, (LL.w + tw - 1) / tw) : std::max(1, (p->width + 127) / 128);
+            const int GY = th ? std::max(1, (LL.h + th - 1) / th) : std::max(1, (p->height + 95) / 96);
+            seg.nregions = GX * GY;
+            boxes.resize(boxes.size() + (size_t)GX * GY * nl);
+            size_t capA = 16, capB = 16;
+            for (int gy = 0; gy < GY && okb; ++gy)
+                for (int gx = 0; gx < GX && okb; ++gx) {
+                    PyrBox* B = &boxes[seg.box_off + ((size_t)gy * GX + gx) * nl];
+                    for (int l = first; l <= last; ++l) {
+                        const OrbLevel& L = h->levels[l];
+                        B[l].ox0 = (int16_t)((long)gx * L.w / GX); B[l].ox1 = (int16_t)((long)(gx + 1) * L.w / GX);
+                        B[l].oy0 = (int16_t)((long)gy * L.h / GY); B[l].oy1 = (int16_t)((long)(gy + 1) * L.h / GY);
+                        if (l == first) { B[l].ox0 = B[l].ox1 = B[l].oy0 = B[l].oy1 = 0; }  // the segment's source is only read
+                        else if (B[l].ox1 <= B[l].ox0 || B[l].oy1 <= B[l].oy0) okb = false;
                     }
-                    if (l - 1 == 0) sx0 &= ~3;  // dword-aligned level-0 patch
-                    B[l - 1].nx0 = (int16_t)sx0; B[l - 1].nx1 = (int16_t)sx1; B[l - 1].ny0 = (int16_t)sy0; B[l - 1].ny1 = (int16_t)sy1;
+                    B[last].nx0 = B[last].ox0; B[last].nx1 = B[last].ox1;
+                    B[last].ny0 = B[last].oy0; B[last].ny1 = B[last].oy1;
+                    for (int l = last; l > first && okb; --l) {
+                        const int sw = h->levels[l - 1].w, sh = h->levels[l - 1].h;
+                        int sx0 = XO[l][B[l].nx0], sx1 = std::min(XO[l][B[l].nx1 - 1] + 1, sw - 1) + 1;
+                        int sy0 = std::min(std::max(YO[l][B[l].ny0], 0), sh - 1);
+                        int sy1 = std::min(std::max(YO[l][B[l].ny1 - 1] + 1, 0), sh - 1) + 1;
+                        if (l - 1 > first) {
+                            sx0 = std::min(sx0, (int)B[l - 1].ox0); sx1 = std::max(sx1, (int)B[l - 1].ox1);
+                            sy0 = std::min(sy0, (int)B[l - 1].oy0); sy1 = std::max(sy1, (int)B[l - 1].oy1);
+                        }
+                        if (l - 1 == first) sx0 &= ~3;  // dword-aligned source patch
+                        B[l - 1].nx0 = (int16_t)sx0; B[l - 1].nx1 = (int16_t)sx1; B[l - 1].ny0 = (int16_t)sy0; B[l - 1].ny1 = (int16_t)sy1;
+                    }
+                    for (int l = first; l <= last; ++l) {
+                        if (l > first && (B[l].nx1 - B[l].nx0 > 256 || B[l].ny1 - B[l].ny0 > 256)) okb = false;  // <= 4 columns per lane, row tables of 256
+                        size_t bytes = (size_t)(((B[l].nx1 - B[l].nx0) + 3) & ~3) * (B[l].ny1 - B[l].ny0);
+                        if ((l - first) & 1) capB = std::max(capB, bytes); else capA = std::max(capA, bytes);
+                    }
                 }
-                for (int l = 0; l < nl; ++l) {
-                    if (l >= 1 && (B[l].nx1 - B[l].nx0 > 256 || B[l].ny1 - B[l].ny0 > 256)) okb = false;  // <= 4 columns per lane, row tables of 256
-                    size_t bytes = (size_t)(((B[l].nx1 - B[l].nx0) + 3) & ~3) * (B[l].ny1 - B[l].ny0);
-                    if (l & 1) capB = std::max(capB, bytes); else capA = std::max(capA, bytes);
-                }
-            }
-        h->pyr_regions = okb ? GX * GY : 0;
-        h->pyr_bufA = (int)round_up(capA, 16);
-        h->pyr_smem = h->pyr_bufA + (int)round_up(capB, 16);
-        if (h->pyr_smem > 150 * 1024) h->pyr_regions = 0;  // fall back to the per-level kernel
-        if (h->pyr_regions) {
+            seg.bufA = (int)round_up(capA, 16);
+            seg.smem = seg.bufA + (int)round_up(capB, 16);
+            if (seg.smem > 150 * 1024) okb = false;
+            seg.threads = tw && (size_t)tw * th <= 64 * 48 ? 256 : 512;
+            h->pyr_segs.push_back(seg);
+            first = last;
+        }
+        h->pyr_mode = (getenv("SLAMIT_PYR_FUSED") || !rows4_ok) ? 1 : 0;
+        if (getenv("SLAMIT_PYR_PER_LEVEL")) { okb = false; h->pyr_mode = 1; }   // diagnostic: force the old per-level kernel
+        if (!okb) h->pyr_segs.clear();                      // fall back to the per-level kernel
+        if (!h->pyr_segs.empty()) {
             std::vector<PyrTabs> tabs(nl);
             for (int l = 0; l < nl; ++l) { tabs[l].xofs = h->d_tab_i[l][0]; tabs[l].ialpha = h->d_tab_s[l][0]; tabs[l].yofs = h->d_tab_i[l][1]; tabs[l].ibeta = h->d_tab_s[l][1]; }
             ALLOC(h->d_boxes, sizeof(PyrBox) * boxes.size());
             ALLOC(h->d_tabs, sizeof(PyrTabs) * nl);
             if (e == hipSuccess) e = hipMemcpy(h->d_boxes, boxes.data(), sizeof(PyrBox) * boxes.size(), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(h->d_tabs, tabs.data(), sizeof(PyrTabs) * nl, hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = orbk_pyramid_prepare(h->pyr_smem);
+            int smax = 0;
+            for (const slamit_orb::PyrSeg& sg : h->pyr_segs) smax = std::max(smax, sg.smem);
+            if (e == hipSuccess) e = orbk_pyramid_prepare(smax);
         }
     }
 #undef ALLOC
@@ -376,7 +424,7 @@ int slamit_orb_max_keypoints(const slamit_orb* h) { return h ? h->max_out : 0; }
 enum { ST_RESIZE = 0, ST_FAST, ST_OCTREE, ST_ANGLE, ST_BLUR, ST_DESCRIBE, ST_COUNT };
 
 static void prof_mark(slamit_orb* h, hipStream_t st, int stage, bool begin) {
-    if (!h->prof_on || h->prof_ev.size() >= 2 * 16384) return;
+    if (!h->prof_on || (h->prof_on == 2 && stage != ST_FAST) || h->prof_ev.size() >= 2 * 16384) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     hipEventRecord(e, st);
@@ -407,9 +455,19 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     HIP_TRY(hipMemsetAsync(cand_count, 0, sizeof(int) * nframes * nl * ORB_CC_PAD, st));
     // K1: pyramid, level l from level l-1
     prof_mark(h, st, ST_RESIZE, true);
-    if (h->pyr_regions) {
-        orbk_pyramid(st, h->d_levels, nl, h->d_boxes, h->d_tabs, h->pyr_regions, d_gray, stride, frame_stride, h->d_pyr,
-                     h->pyr_bufA, h->pyr_smem, nframes);
+    const bool src0_aligned = ((((uintptr_t)d_gray) | stride | frame_stride) & 3) == 0;
+    if (h->pyr_mode == 0 && src0_aligned) {
+        for (int l = 1; l < nl; ++l) {
+            const OrbLevel& S = h->levels[l - 1];
+            const OrbLevel& D = h->levels[l];
+            const uint8_t* src = l == 1 ? d_gray : h->d_pyr + S.plane_off;
+            orbk_resize_rows4(st, src, l == 1 ? stride : (size_t)S.stride, l == 1 ? frame_stride : h->pyr_frame_total,
+                              h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride, h->pyr_frame_total, h->d_rs_col[l], h->d_rs_row[l], nframes);
+        }
+    } else if (!h->pyr_segs.empty()) {
+        for (const slamit_orb::PyrSeg& sg : h->pyr_segs)
+            orbk_pyramid(st, h->d_levels, nl, h->d_boxes + sg.box_off, h->d_tabs, sg.nregions, d_gray, stride, frame_stride, h->d_pyr,
+                         sg.bufA, sg.smem, nframes, sg.first, sg.last, sg.threads);
     } else {
         for (int l = 1; l < nl; ++l) {
             const OrbLevel& S = h->levels[l - 1];

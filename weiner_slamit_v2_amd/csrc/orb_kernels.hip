@@ -64,55 +64,156 @@ __global__ __launch_bounds__(256) void resize_level_kernel(
 }
 
 // --------------------------------------------------------------------------------------------
+// K1 (per level, the path used when planes are 4-byte aligned): one lane = 4 adjacent dst pixels of
+// one dst row, items flattened over (row, group) so every lane of every wave is busy.  All per-column
+// and per-row arithmetic the reference does at run time is in two host-built tables (orbk_resize_tables):
+//   column group (2 x uint4): byte offset of the 12-byte source window | byte shift | offsets of its 2nd and
+//       3rd dword (clamped into the row) ; v_perm selectors of the 4 left taps and the 4 right taps ;
+//       4 x (ialpha0 | ialpha1 << 16)
+//   row (uint2): sy0 | sy1 << 16 (clamped) ; ibeta0 | ibeta1 << 16
+// A source row costs 3 aligned dword loads, 2 v_alignbyte, 2 v_perm; no LDS, no halo, no barrier.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_rows4_kernel(
+    const uint8_t* __restrict__ src, size_t sstride, size_t sframe,
+    uint8_t* __restrict__ dst, size_t dstride, size_t dframe,
+    const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, int ngroups, unsigned inv_groups, int nitems) {
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= nitems) return;
+    const int y = (int)__umulhi((unsigned)item, inv_groups);
+    const int g = item - y * ngroups;
+    const uint4 c0 = coltab[2 * g], c1 = coltab[2 * g + 1];
+    const uint2 rt = rowtab[y];
+    const unsigned b = c0.x & 0xFFFFu, sh = (c0.x >> 16) & 3u, off1 = (c0.x >> 20) & 15u, off2 = (c0.x >> 24) & 15u;
+    const uint8_t* S = src + (size_t)blockIdx.y * sframe + b;
+    const uint8_t* S0 = S + (size_t)(rt.x & 0xFFFFu) * sstride;
+    const uint8_t* S1 = S + (size_t)(rt.x >> 16) * sstride;
+    const uint32_t p0 = *reinterpret_cast<const uint32_t*>(S0), p1 = *reinterpret_cast<const uint32_t*>(S0 + off1),
+                   p2 = *reinterpret_cast<const uint32_t*>(S0 + off2);
+    const uint32_t q0 = *reinterpret_cast<const uint32_t*>(S1), q1 = *reinterpret_cast<const uint32_t*>(S1 + off1),
+                   q2 = *reinterpret_cast<const uint32_t*>(S1 + off2);
+    const uint32_t plo = __builtin_amdgcn_alignbyte(p1, p0, sh), phi = __builtin_amdgcn_alignbyte(p2, p1, sh);
+    const uint32_t qlo = __builtin_amdgcn_alignbyte(q1, q0, sh), qhi = __builtin_amdgcn_alignbyte(q2, q1, sh);
+    const uint32_t L0 = __builtin_amdgcn_perm(phi, plo, c0.y), R0 = __builtin_amdgcn_perm(phi, plo, c0.z);
+    const uint32_t L1 = __builtin_amdgcn_perm(qhi, qlo, c0.y), R1 = __builtin_amdgcn_perm(qhi, qlo, c0.z);
+    const int b0 = (int)(rt.y & 0xFFFFu), b1 = (int)(rt.y >> 16);
+    const uint32_t al[4] = {c1.x, c1.y, c1.z, c1.w};
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int a0 = (int)(al[j] & 0xFFFFu), a1 = (int)(al[j] >> 16);
+        const int r0 = (int)((L0 >> (8 * j)) & 0xFFu) * a0 + (int)((R0 >> (8 * j)) & 0xFFu) * a1;
+        const int r1 = (int)((L1 >> (8 * j)) & 0xFFu) * a0 + (int)((R1 >> (8 * j)) & 0xFFu) * a1;
+        const int v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+        out |= (uint32_t)v << (8 * j);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.y * dframe + (size_t)y * dstride + 4 * g) = out;
+}
+
+// Host: tables of resize_rows4_kernel for one level from the reference-shaped xofs/ialpha/yofs/ibeta tables.
+// Coefficients are non-negative (bilinear) and <= 2048, rows/columns < 65536 (checked by the caller).
+// Returns false when the geometry does not fit the kernel (scale factor > 2.3: taps of one group further than
+// 8 bytes apart; planes of 64K pixels or more): the caller then uses the fused / generic kernels.
+bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const short* ialpha, const int* yofs,
+                        const short* ibeta, std::vector<uint32_t>& col, std::vector<uint32_t>& row) {
+    const int ng = (dw + 3) / 4, row_end = (sw + 3) & ~3;
+    if (sw >= 65536 || sh >= 65536) return false;
+    col.assign((size_t)ng * 8, 0u);
+    for (int g = 0; g < ng; ++g) {
+        int L[4], R[4];
+        uint32_t a[4];
+        for (int j = 0; j < 4; ++j) {
+            const int x = 4 * g + j;
+            if (x < dw) {
+                L[j] = xofs[x]; R[j] = std::min(xofs[x] + 1, sw - 1);
+                a[j] = (uint32_t)(unsigned short)ialpha[2 * x] | ((uint32_t)(unsigned short)ialpha[2 * x + 1] << 16);
+            } else { L[j] = L[0]; R[j] = L[0]; a[j] = 0; }   // padding pixels of the last dword: written as 0
+        }
+        const int base = L[0] & ~3, s = L[0] & 3;
+        const int off1 = base + 8 <= row_end ? 4 : 0, off2 = base + 12 <= row_end ? 8 : off1;
+        uint32_t selL = 0, selR = 0;
+        for (int j = 0; j < 4; ++j) {   // byte index inside the 8 bytes that start at L[0]
+            if (L[j] < L[0] || R[j] < L[0] || L[j] - L[0] > 7 || R[j] - L[0] > 7 || ialpha[0] < 0) return false;
+            selL |= (uint32_t)(L[j] - L[0]) << (8 * j);
+            selR |= (uint32_t)(R[j] - L[0]) << (8 * j);
+        }
+        uint32_t* c = &col[(size_t)g * 8];
+        c[0] = (uint32_t)base | ((uint32_t)s << 16) | ((uint32_t)off1 << 20) | ((uint32_t)off2 << 24);
+        c[1] = selL; c[2] = selR; c[3] = 0;
+        c[4] = a[0]; c[5] = a[1]; c[6] = a[2]; c[7] = a[3];
+    }
+    row.assign((size_t)dh * 2, 0u);
+    for (int y = 0; y < dh; ++y) {
+        const int sy0 = std::min(std::max(yofs[y], 0), sh - 1), sy1 = std::min(std::max(yofs[y] + 1, 0), sh - 1);
+        row[2 * (size_t)y] = (uint32_t)sy0 | ((uint32_t)sy1 << 16);
+        row[2 * (size_t)y + 1] = (uint32_t)(unsigned short)ibeta[2 * y] | ((uint32_t)(unsigned short)ibeta[2 * y + 1] << 16);
+        if (ibeta[2 * y] < 0 || ibeta[2 * y + 1] < 0) return false;
+    }
+    for (int x = 0; x < dw; ++x) if (ialpha[2 * x] < 0 || ialpha[2 * x + 1] < 0) return false;
+    return true;
+}
+
+void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, uint8_t* dst, int dw, int dh,
+                       size_t dstride, size_t dframe, const uint32_t* d_col, const uint32_t* d_row, int nframes) {
+    const int ng = (dw + 3) / 4, nitems = ng * dh;
+    const unsigned inv = (unsigned)((0x100000000ull + (unsigned)ng - 1) / (unsigned)ng);
+    hipLaunchKernelGGL(resize_rows4_kernel, dim3((nitems + 255) / 256, nframes), dim3(256), 0, st, src, sstride, sframe, dst,
+                       dstride, dframe, reinterpret_cast<const uint4*>(d_col), reinterpret_cast<const uint2*>(d_row), ng, inv, nitems);
+}
+
+// --------------------------------------------------------------------------------------------
 // K1 (fused): the whole pyramid in ONE launch.  Workgroup (region, frame) loads its level-0 patch
 // once, then produces level 1, 2, ... each from the previous level kept in LDS (two ping-pong
 // buffers), storing only the pixels it owns.  The chain of integer roundings is exactly the
 // reference's (level l is always computed from level l-1), but no level is ever re-read from HBM
 // and six dependent launches disappear.  Boxes come from the host (orb_api.hip: build_pyr_boxes).
 // --------------------------------------------------------------------------------------------
-#define PYR_THREADS 512
-#define PYR_ROWS (PYR_THREADS / 64)
+#define PYR_THREADS 512   // upper bound; the launch picks 256 or 512
 
 __global__ __launch_bounds__(PYR_THREADS) void pyramid_fused_kernel(
     const OrbLevel* __restrict__ levels, int nlevels, const PyrBox* __restrict__ boxes,
     const PyrTabs* __restrict__ tabs, const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
-    uint8_t* __restrict__ pyr, int bufA_bytes) {
+    uint8_t* __restrict__ pyr, int bufA_bytes, int l_first, int l_last) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pbuf[];
     uint8_t* buf[2] = {pbuf, pbuf + bufA_bytes};
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int PYR_ROWS = blockDim.x >> 6, NT = blockDim.x;
     const int frame = blockIdx.y;
     const PyrBox* B = boxes + (size_t)blockIdx.x * nlevels;
-    // level-0 patch (its x0 is a multiple of 4: whole dwords when the caller's image is 4-byte aligned)
+    // source patch of the segment's first level (its x0 is a multiple of 4: whole dwords when the plane is
+    // 4-byte aligned — pyramid planes always are, the caller's level 0 usually)
     {
-        const PyrBox b = B[0];
+        const PyrBox b = B[l_first];
         const int nw = b.nx1 - b.nx0, pitch = (nw + 3) & ~3;
-        const uint8_t* S = img0 + (size_t)frame * img0_frame;
-        const bool aligned = ((((uintptr_t)S) | img0_stride) & 3) == 0;
-        const int w0 = levels[0].w;
+        const uint8_t* S;
+        size_t sstride;
+        if (l_first == 0) { S = img0 + (size_t)frame * img0_frame; sstride = img0_stride; }
+        else { S = pyr + levels[l_first].plane_off + (size_t)frame * levels[l_first].plane_bytes; sstride = (size_t)levels[l_first].stride; }
+        const bool aligned = ((((uintptr_t)S) | sstride) & 3) == 0;
+        const int w0 = levels[l_first].w;
         if (aligned) {
             const int nd = pitch >> 2;
             for (int y = b.ny0 + ty; y < b.ny1; y += PYR_ROWS)
                 for (int d = tx; d < nd; d += 64) {
                     const int x = b.nx0 + 4 * d;
                     uint32_t v;
-                    if (x + 4 <= w0) v = *reinterpret_cast<const uint32_t*>(S + (size_t)y * img0_stride + x);
-                    else { v = 0; for (int j = 0; j < 4; ++j) if (x + j < w0) v |= (uint32_t)S[(size_t)y * img0_stride + x + j] << (8 * j); }
+                    if (x + 4 <= w0) v = *reinterpret_cast<const uint32_t*>(S + (size_t)y * sstride + x);
+                    else { v = 0; for (int j = 0; j < 4; ++j) if (x + j < w0) v |= (uint32_t)S[(size_t)y * sstride + x + j] << (8 * j); }
                     *reinterpret_cast<uint32_t*>(&buf[0][(y - b.ny0) * pitch + 4 * d]) = v;
                 }
         } else {
             for (int y = b.ny0 + ty; y < b.ny1; y += PYR_ROWS)
                 for (int x = b.nx0 + tx; x < b.nx1; x += 64)
-                    buf[0][(y - b.ny0) * pitch + (x - b.nx0)] = S[(size_t)y * img0_stride + x];
+                    buf[0][(y - b.ny0) * pitch + (x - b.nx0)] = S[(size_t)y * sstride + x];
         }
     }
     __syncthreads();
-    for (int l = 1; l < nlevels; ++l) {
+    for (int l = l_first + 1; l <= l_last; ++l) {
         const PyrBox b = B[l], pb = B[l - 1];
         const OrbLevel& L = levels[l];
         const int sw = levels[l - 1].w, sh = levels[l - 1].h;
         const PyrTabs T = tabs[l];
-        const uint8_t* src = buf[(l - 1) & 1];
-        uint8_t* dst = buf[l & 1];
+        const uint8_t* src = buf[(l - 1 - l_first) & 1];
+        uint8_t* dst = buf[(l - l_first) & 1];
         const int spitch = ((pb.nx1 - pb.nx0) + 3) & ~3, dpitch = ((b.nx1 - b.nx0) + 3) & ~3;
         uint8_t* plane = pyr + L.plane_off + (size_t)frame * L.plane_bytes;
         // a lane keeps the coefficients of its (<= 4) columns in registers; rows are wave-uniform, so
@@ -136,7 +237,7 @@ __global__ __launch_bounds__(PYR_THREADS) void pyramid_fused_kernel(
         // would stall every iteration)
         __shared__ int s_sy0[256], s_sy1[256], s_b01[256];
         const int nh = b.ny1 - b.ny0;
-        for (int i = threadIdx.x; i < nh; i += PYR_THREADS) {
+        for (int i = threadIdx.x; i < nh; i += NT) {
             const int y = b.ny0 + i, sy = T.yofs[y];
             s_sy0[i] = min(max(sy, 0), sh - 1) - pb.ny0;
             s_sy1[i] = min(max(sy + 1, 0), sh - 1) - pb.ny0;
@@ -1056,9 +1157,9 @@ hipError_t orbk_pyramid_prepare(int smem_bytes) {
 
 void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const PyrBox* boxes, const PyrTabs* tabs,
                   int nregions, const uint8_t* img0, size_t img0_stride, size_t img0_frame, uint8_t* pyr, int bufA_bytes,
-                  int smem_bytes, int nframes) {
-    hipLaunchKernelGGL(pyramid_fused_kernel, dim3(nregions, nframes), dim3(PYR_THREADS), smem_bytes, st, levels, nlevels, boxes,
-                       tabs, img0, img0_stride, img0_frame, pyr, bufA_bytes);
+                  int smem_bytes, int nframes, int l_first, int l_last, int threads) {
+    hipLaunchKernelGGL(pyramid_fused_kernel, dim3(nregions, nframes), dim3(threads), smem_bytes, st, levels, nlevels, boxes,
+                       tabs, img0, img0_stride, img0_frame, pyr, bufA_bytes, l_first, l_last);
 }
 
 static int fast_pitch(int max_wcell) { return max_wcell + 11 <= 48 ? 48 : 72; }  // LDS columns 0 .. sw + 10 are touched
