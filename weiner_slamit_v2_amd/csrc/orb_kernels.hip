@@ -81,16 +81,18 @@ __global__ __launch_bounds__(256) void resize_rows4_kernel(
     if (item >= nitems) return;
     const int y = (int)__umulhi((unsigned)item, inv_groups);
     const int g = item - y * ngroups;
-    const uint4 c0 = coltab[2 * g], c1 = coltab[2 * g + 1];
-    const uint2 rt = rowtab[y];
+    // uniform 64-bit bases + 32-bit per-lane offsets (planes are far below 4 GB): global_load saddr + voffset
+    const uint8_t* ct = reinterpret_cast<const uint8_t*>(coltab);
+    const uint4 c0 = *reinterpret_cast<const uint4*>(ct + 32u * (unsigned)g), c1 = *reinterpret_cast<const uint4*>(ct + 32u * (unsigned)g + 16u);
+    const uint2 rt = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(rowtab) + 8u * (unsigned)y);
     const unsigned b = c0.x & 0xFFFFu, sh = (c0.x >> 16) & 3u, off1 = (c0.x >> 20) & 15u, off2 = (c0.x >> 24) & 15u;
-    const uint8_t* S = src + (size_t)blockIdx.y * sframe + b;
-    const uint8_t* S0 = S + (size_t)(rt.x & 0xFFFFu) * sstride;
-    const uint8_t* S1 = S + (size_t)(rt.x >> 16) * sstride;
-    const uint32_t p0 = *reinterpret_cast<const uint32_t*>(S0), p1 = *reinterpret_cast<const uint32_t*>(S0 + off1),
-                   p2 = *reinterpret_cast<const uint32_t*>(S0 + off2);
-    const uint32_t q0 = *reinterpret_cast<const uint32_t*>(S1), q1 = *reinterpret_cast<const uint32_t*>(S1 + off1),
-                   q2 = *reinterpret_cast<const uint32_t*>(S1 + off2);
+    const uint8_t* S = src + (size_t)blockIdx.y * sframe;
+    const unsigned ss = (unsigned)sstride;
+    const unsigned o0 = (rt.x & 0xFFFFu) * ss + b, o1 = (rt.x >> 16) * ss + b;
+    const uint32_t p0 = *reinterpret_cast<const uint32_t*>(S + o0), p1 = *reinterpret_cast<const uint32_t*>(S + (o0 + off1)),
+                   p2 = *reinterpret_cast<const uint32_t*>(S + (o0 + off2));
+    const uint32_t q0 = *reinterpret_cast<const uint32_t*>(S + o1), q1 = *reinterpret_cast<const uint32_t*>(S + (o1 + off1)),
+                   q2 = *reinterpret_cast<const uint32_t*>(S + (o1 + off2));
     const uint32_t plo = __builtin_amdgcn_alignbyte(p1, p0, sh), phi = __builtin_amdgcn_alignbyte(p2, p1, sh);
     const uint32_t qlo = __builtin_amdgcn_alignbyte(q1, q0, sh), qhi = __builtin_amdgcn_alignbyte(q2, q1, sh);
     const uint32_t L0 = __builtin_amdgcn_perm(phi, plo, c0.y), R0 = __builtin_amdgcn_perm(phi, plo, c0.z);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void resize_rows4_kernel(
         const int v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
         out |= (uint32_t)v << (8 * j);
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.y * dframe + (size_t)y * dstride + 4 * g) = out;
+    *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.y * dframe + ((unsigned)y * (unsigned)dstride + 4u * (unsigned)g)) = out;
 }
 
 // Host: tables of resize_rows4_kernel for one level from the reference-shaped xofs/ialpha/yofs/ibeta tables.
@@ -936,10 +938,14 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
 // K6: 7x7 Gaussian blur, fixed point taps [18,34,49,55,49,34,18] (sum 257), REFLECT_101 on the
 // un-padded level.  Workgroup = 64x16 output tile; rows pass kept as u16 in LDS (<= 255*257).
 // --------------------------------------------------------------------------------------------
+// BORDER_REFLECT_101 for the coordinates the blur can produce: at most one reflection is ever needed for a pixel
+// that contributes to an output (|overshoot| <= 3 and every level is >= 62 pixels wide and tall, slamit_orb_create
+// refuses smaller ones); coordinates further out (only staged, never used by an in-image output) are clamped so
+// that their address stays inside the plane.  Branch-free.
 __device__ __forceinline__ int reflect101(int p, int len) {
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
+    p = p < 0 ? -p : p;
+    p = p >= len ? 2 * len - 2 - p : p;
+    return min(max(p, 0), len - 1);
 }
 
 // One launch covers every level of every frame: blockIdx.x walks the per-level tile lists
@@ -950,16 +956,19 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // through the REFLECT_101 map.
 #define BLUR_STEPS 4
 
-__device__ __forceinline__ uint32_t blur_fetch(const uint8_t* S, size_t sstride, bool aligned, int w, int h, int bx, int by,
-                                               int i) {
-    const int r = i / 18, c4 = i - r * 18;
-    const int gy = reflect101(by + r - 3, h);
-    const int gx0 = bx - 4 + 4 * c4;
-    const uint8_t* rowp = S + (size_t)gy * sstride;
-    if (aligned && gx0 >= 0 && gx0 + 4 <= w) return *reinterpret_cast<const uint32_t*>(rowp + gx0);
+typedef unsigned short blur_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {   // a.lo*b.lo + a.hi*b.hi + c (v_dot2_u32_u16)
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, a), __builtin_bit_cast(blur_us2, b), c, false);
+}
+
+// One staged dword of a step: columns gx0 .. gx0+3 of image row (by + r - 3), REFLECT_101 at the borders.  Everything
+// that does not depend on the step (r, gx0, whether the dword lies inside the row) is computed once per thread.
+__device__ __forceinline__ uint32_t blur_fetch(const uint8_t* S, unsigned sstride, bool whole, int w, int h, int gx0, int row) {
+    const unsigned ro = (unsigned)reflect101(row, h) * sstride;
+    if (whole) return *reinterpret_cast<const uint32_t*>(S + (ro + (unsigned)gx0));
     uint32_t v = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v |= (uint32_t)rowp[reflect101(gx0 + j, w)] << (8 * j);
+    for (int j = 0; j < 4; ++j) v |= (uint32_t)S[ro + (unsigned)reflect101(gx0 + j, w)] << (8 * j);
     return v;
 }
 
@@ -968,7 +977,9 @@ __global__ __launch_bounds__(256) void blur_all_kernel(
     const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
     __shared__ __attribute__((aligned(16))) uint8_t in[22][72];
-    __shared__ __attribute__((aligned(16))) uint16_t rows[22][64];
+    // row-pass results as VERTICAL PAIRS: rp[p][c] = row 2p | row 2p+1 << 16 (each <= 255 * 257), the operand
+    // shape of v_dot2_u32_u16 in the column pass
+    __shared__ __attribute__((aligned(16))) uint32_t rp[11][64];
     const int tid = threadIdx.x;
     const int frame = blockIdx.y;
     int level = 0;
@@ -986,55 +997,67 @@ __global__ __launch_bounds__(256) void blur_all_kernel(
     else { S = pyr + L.plane_off + (size_t)frame * L.plane_bytes; sstride = (size_t)L.stride; }
     const bool aligned = ((((uintptr_t)S) | sstride) & 3) == 0;
     uint8_t* D = blur + L.blur_off + (size_t)frame * L.blur_bytes;
-    // in[r][k] holds column bx - 4 + k of row by - 3 + r
-    const int i0 = tid, i1 = tid + 256;  // 22 * 18 = 396 dwords per step
-    uint32_t v0 = blur_fetch(S, sstride, aligned, w, h, bx, by0, i0);
-    uint32_t v1 = i1 < 22 * 18 ? blur_fetch(S, sstride, aligned, w, h, bx, by0, i1) : 0;
-    *reinterpret_cast<uint32_t*>(&in[i0 / 18][4 * (i0 % 18)]) = v0;
-    if (i1 < 22 * 18) *reinterpret_cast<uint32_t*>(&in[i1 / 18][4 * (i1 % 18)]) = v1;
+    // in[r][k] holds column bx - 4 + k of row by - 3 + r; a thread stages dwords i0 and i1 of the 22 x 18 of a step
+    const int i0 = tid, i1 = tid + 256;
+    const bool has1 = i1 < 22 * 18;
+    const int r0 = i0 / 18, r1 = i1 / 18;
+    const int g0 = bx - 4 + 4 * (i0 - r0 * 18), g1 = bx - 4 + 4 * (i1 - r1 * 18);
+    const bool whole0 = aligned && g0 >= 0 && g0 + 4 <= w, whole1 = aligned && g1 >= 0 && g1 + 4 <= w;
+    uint32_t* const st0 = reinterpret_cast<uint32_t*>(&in[r0][4 * (i0 - r0 * 18)]);
+    uint32_t* const st1 = reinterpret_cast<uint32_t*>(&in[has1 ? r1 : 0][has1 ? 4 * (i1 - r1 * 18) : 0]);
+    const unsigned ss = (unsigned)sstride;
+    uint32_t v0 = blur_fetch(S, ss, whole0, w, h, g0, by0 + r0 - 3);
+    uint32_t v1 = has1 ? blur_fetch(S, ss, whole1, w, h, g1, by0 + r1 - 3) : 0;
+    *st0 = v0;
+    if (has1) *st1 = v1;
     __syncthreads();
+    // taps as dot-product operands: bytes for the row pass, halfword pairs for the column pass (which pair of
+    // rows a tap pair meets depends on the parity of the output row)
+    const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
+    const int cy = tid >> 4, cx4 = (tid & 15) * 4;
+    const bool odd = cy & 1;
+    const uint32_t k0 = odd ? (18u << 16) : (18u | (34u << 16)), k1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16));
+    const uint32_t k2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), k3 = odd ? (34u | (18u << 16)) : 18u;
 #pragma unroll 1
     for (int s = 0; s < BLUR_STEPS; ++s) {
         const int by = by0 + 16 * s;
         const bool more = s + 1 < BLUR_STEPS && by + 16 < h;
         if (more) {
-            v0 = blur_fetch(S, sstride, aligned, w, h, bx, by + 16, i0);
-            if (i1 < 22 * 18) v1 = blur_fetch(S, sstride, aligned, w, h, bx, by + 16, i1);
+            v0 = blur_fetch(S, ss, whole0, w, h, g0, by + 16 + r0 - 3);
+            if (has1) v1 = blur_fetch(S, ss, whole1, w, h, g1, by + 16 + r1 - 3);
         }
-        // row pass: thread -> 4 adjacent outputs of one of the 22 rows (taps sum to 257: fits u16)
-        for (int i = tid; i < 22 * 16; i += 256) {
-            const int r = i >> 4, c = (i & 15) * 4;
-            // three ALIGNED dwords (columns bx+c-4 .. bx+c+7); q[k] = column bx + c - 3 + k.
-            // (Byte-wise reads at the odd offset get merged into unaligned ds_read_b64, which costs
-            //  ~30 LDS cycles per instruction on gfx950: measured with SQ_LDS_IDX_ACTIVE.)
-            const uint32_t* pw = reinterpret_cast<const uint32_t*>(&in[r][c]);
-            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-            int q[10];
-            q[0] = (w0 >> 8) & 0xFF; q[1] = (w0 >> 16) & 0xFF; q[2] = w0 >> 24;
-            q[3] = w1 & 0xFF; q[4] = (w1 >> 8) & 0xFF; q[5] = (w1 >> 16) & 0xFF; q[6] = w1 >> 24;
-            q[7] = w2 & 0xFF; q[8] = (w2 >> 8) & 0xFF; q[9] = (w2 >> 16) & 0xFF;
+        // row pass: thread -> 4 adjacent outputs of TWO rows (2p, 2p+1).  Output o needs the 7 bytes at columns
+        // c+o-3 .. c+o+3 = stream bytes o+1 .. o+7 of three ALIGNED dwords (columns c-4 .. c+7): two v_dot4_u32_u8
+        // on byte quads cut out with v_alignbyte.  (Unaligned LDS reads cost ~30 cycles each on gfx950.)
+        if (tid < 11 * 16) {
+            const int p = tid >> 4, c = (tid & 15) * 4;
+            uint32_t o[2][4];
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                rows[r][c + o] = (uint16_t)(18 * (q[o] + q[o + 6]) + 34 * (q[o + 1] + q[o + 5]) + 49 * (q[o + 2] + q[o + 4]) + 55 * q[o + 3]);
+            for (int rr = 0; rr < 2; ++rr) {
+                const uint32_t* pw = reinterpret_cast<const uint32_t*>(&in[2 * p + rr][c]);
+                const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+                o[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TA, 0u, false), false);
+                o[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TA, 0u, false), false);
+                o[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TA, 0u, false), false);
+                o[rr][3] = __builtin_amdgcn_udot4(w2, TB, __builtin_amdgcn_udot4(w1, TA, 0u, false), false);
+            }
+            *reinterpret_cast<uint4*>(&rp[p][c]) = make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16),
+                                                               o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
         }
         __syncthreads();
         if (more) {
-            *reinterpret_cast<uint32_t*>(&in[i0 / 18][4 * (i0 % 18)]) = v0;
-            if (i1 < 22 * 18) *reinterpret_cast<uint32_t*>(&in[i1 / 18][4 * (i1 % 18)]) = v1;
+            *st0 = v0;
+            if (has1) *st1 = v1;
         }
-        const int x4 = (tid & 15) * 4, y = tid >> 4;
-        if (bx + x4 < w && by + y < h) {
-            uint32_t out = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = x4 + i;
-                int acc = 18 * (rows[y][c] + rows[y + 6][c]) + 34 * (rows[y + 1][c] + rows[y + 5][c]) +
-                          49 * (rows[y + 2][c] + rows[y + 4][c]) + 55 * rows[y + 3][c];
-                int v = (acc + (1 << 15)) >> 16;
-                v = min(v, 255);
-                out |= (uint32_t)v << (8 * i);
-            }
-            *reinterpret_cast<uint32_t*>(D + (size_t)(by + y) * L.stride + bx + x4) = out;
+        if (bx + cx4 < w && by + cy < h) {
+            // output row cy uses rows cy .. cy+6: four row pairs starting at pair cy >> 1
+            const int pb = cy >> 1;
+            const uint4 a0 = *reinterpret_cast<const uint4*>(&rp[pb][cx4]), a1 = *reinterpret_cast<const uint4*>(&rp[pb + 1][cx4]);
+            const uint4 a2 = *reinterpret_cast<const uint4*>(&rp[pb + 2][cx4]), a3 = *reinterpret_cast<const uint4*>(&rp[pb + 3][cx4]);
+#define BLUR_COL(f) min((udot2(a3.f, k3, udot2(a2.f, k2, udot2(a1.f, k1, udot2(a0.f, k0, 1u << 15)))) >> 16), 255u)
+            const uint32_t out = BLUR_COL(x) | (BLUR_COL(y) << 8) | (BLUR_COL(z) << 16) | (BLUR_COL(w) << 24);
+#undef BLUR_COL
+            *reinterpret_cast<uint32_t*>(D + (size_t)(by + cy) * L.stride + bx + cx4) = out;
         }
         if (!more) break;
         __syncthreads();
