@@ -173,7 +173,12 @@ def main():
     d_best = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_second = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     gather = shard.SummaryGather(B, 2, dev, world)  # per-frame (keypoints, matches) to every rank
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # ONE non-default stream carries the whole step: extract(k) -> match(k) are ordered by the stream.  (A NULL
+    # stream handle would mean "the extractor's own stream" to the C-ABI and un-order the two calls.)
+    tstream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     def step(k):
         cur, prv = k & 1, (k & 1) ^ 1

@@ -127,14 +127,30 @@ def test_device_buffer_entry_point():
     d_desc = torch.zeros((3, cap, 32), dtype=torch.uint8, device="cuda")
     d_n = torch.zeros(3, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    ext.extract_batch_dev(d_frames, d_kps, d_desc, d_n, stream=torch.cuda.current_stream().cuda_stream)
+    # a caller-owned, non-default stream: extract and the all-pairs match of frames (0,1), (1,2) are enqueued back
+    # to back with no host synchronisation in between (the bench's pattern); only the stream orders them
+    s = torch.cuda.Stream()
+    d_idx = torch.zeros((2, cap), dtype=torch.int32, device="cuda")
+    d_best = torch.zeros((2, cap), dtype=torch.int32, device="cuda")
+    d_second = torch.zeros((2, cap), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
+    assert s.cuda_stream != 0
+    ext.extract_batch_dev(d_frames, d_kps, d_desc, d_n, stream=s.cuda_stream)
+    api.ORBmatcher.best2_batch_dev(d_desc[0:2], d_n[0:2], d_desc[1:3], d_n[1:3], d_idx, d_best, d_second, cap,
+                                   device=0, stream=s.cuda_stream)
+    s.synchronize()
     n = d_n.cpu().numpy()
     kps = d_kps.cpu().numpy().view(np.uint8).reshape(3, cap, 28)
+    descs = []
     for i in range(3):
         ko, do = orc.extract(frames[i])
         kg = kps[i, :n[i]].copy().view(api.KP_DTYPE).reshape(-1)
         _assert_same(kg, d_desc[i, :n[i]].cpu().numpy(), ko, do, "dev[%d]" % i)
+        descs.append(do)
+    for p in range(2):
+        oi, obest, osec = ob.best2(descs[p], descs[p + 1])
+        assert np.array_equal(d_idx[p, :n[p]].cpu().numpy(), oi) and np.array_equal(d_best[p, :n[p]].cpu().numpy(), obest)
+        assert np.array_equal(d_second[p, :n[p]].cpu().numpy(), osec)
 
 
 def test_device_buffer_unaligned_views():
