@@ -62,6 +62,14 @@ def test_720p_2000():
     _check_frame(ext, orc, synth.synth_frame(1280, 720, 7), "720p", stages=True)
 
 
+def test_dense_candidates_take_the_hbm_key_workspace():
+    """More level-0 candidates than the octree's LDS key arrays hold (10240): the kernel's HBM-workspace variant."""
+    ext, orc = api.ORBextractor(2000, 1.2, 8, 20, 7), ob.OrbOracle(2000)
+    img = synth.noise_frame(1280, 720, 5)
+    _check_frame(ext, orc, img, "noise720p", stages=False)
+    assert len(ext.debug_candidates(0, 0)) > 10240
+
+
 def test_edge_images():
     ext, orc = api.ORBextractor(1000, 1.2, 8, 20, 7), ob.OrbOracle(1000)
     # flat: zero keypoints on every level

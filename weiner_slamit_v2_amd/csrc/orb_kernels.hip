@@ -600,10 +600,11 @@ __device__ __forceinline__ Box16 child_box(const Box16& b, int q) {
     return c;
 }
 
-// exclusive scan of a[0..len) in place (LDS), returns the total; all 256 threads call it
-__device__ int block_exclusive_scan(int* a, int len, int* wave_tmp /*[4+1]*/) {
+// exclusive scan of a[0..len) in place (LDS), returns the total; all NT threads call it
+template <int NT>
+__device__ int block_exclusive_scan(int* a, int len, int* wave_tmp /*[NT / 64]*/) {
     const int tid = threadIdx.x;
-    const int C = (len + 255) / 256;
+    const int C = (len + NT - 1) / NT;
     const int lo = min(tid * C, len), hi = min(lo + C, len);
     int sum = 0;
     for (int i = lo; i < hi; ++i) sum += a[i];
@@ -616,9 +617,13 @@ __device__ int block_exclusive_scan(int* a, int len, int* wave_tmp /*[4+1]*/) {
     }
     if ((tid & 63) == 63) wave_tmp[tid >> 6] = incl;
     __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < (tid >> 6); ++w) wbase += wave_tmp[w];
-    int total = wave_tmp[0] + wave_tmp[1] + wave_tmp[2] + wave_tmp[3];
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const int v = wave_tmp[w];
+        wbase += w < (tid >> 6) ? v : 0;
+        total += v;
+    }
     int run = wbase + incl - sum;
     for (int i = lo; i < hi; ++i) {
         int v = a[i];
@@ -629,19 +634,29 @@ __device__ int block_exclusive_scan(int* a, int len, int* wave_tmp /*[4+1]*/) {
     return total;
 }
 
-__global__ __launch_bounds__(256) void octree_kernel(
-    const OrbLevel* __restrict__ levels, int nlevels,
-    const unsigned long long* __restrict__ cand, size_t cand_frame_stride,
-    const int* __restrict__ cand_count,
-    uint32_t* __restrict__ ws_xy, uint16_t* __restrict__ ws_node,
-    OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, int* __restrict__ kp_count,
-    int node_cap, int level_override /* -1: blockIdx.x */) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef OCT_DIAG   // diagnostic builds only: per (frame, level) workgroup phase ticks
+__device__ unsigned long long g_oct_ph[4096 * 8];
+extern "C" int slamit_diag_oct(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_ph), sizeof(unsigned long long) * 4096 * 8); }
+#define OD_DECL unsigned long long od_ph[6] = {0, 0, 0, 0, 0, 0}, od_prev = __builtin_amdgcn_s_memtime(), od_rt0 = __builtin_amdgcn_s_memrealtime(); int od_pass = 0
+#define OD_STAMP(i) do { unsigned long long tn = __builtin_amdgcn_s_memtime(); od_ph[i] += tn - od_prev; od_prev = tn; } while (0)
+#else
+#define OD_DECL
+#define OD_STAMP(i)
+#endif
+
+#ifndef OCT_THREADS
+#define OCT_THREADS 512
+#endif
+#ifndef OCT_LDS_KEYS
+#define OCT_LDS_KEYS 10240   // candidates of one (frame, level) that fit the LDS key arrays (6 bytes each); more -> HBM workspace
+#endif
+
+// XY / ND: per-candidate position and current node, in LDS when the list fits (LK) and in the HBM workspace otherwise.
+template <int NT, bool LK>
+__device__ __forceinline__ void octree_body(
+    const OrbLevel& L, const unsigned long long* __restrict__ K, int n_keys, uint32_t* XY, uint16_t* ND,
+    OrbLevelKp* __restrict__ OUT, int* __restrict__ kp_count_out, unsigned char* smem, int cap, int* wave_tmp, int* s_vars) {
     const int tid = threadIdx.x;
-    const int level = level_override >= 0 ? level_override : blockIdx.x;
-    const int frame = blockIdx.y;
-    const OrbLevel& L = levels[level];
-    const int cap = node_cap;
     // LDS carve (all 8-byte aligned)
     unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);              // cap
     Box16* box[2] = {reinterpret_cast<Box16*>(best + cap), reinterpret_cast<Box16*>(best + cap) + cap};
@@ -650,20 +665,9 @@ __global__ __launch_bounds__(256) void octree_kernel(
     int* scanbuf = childcnt + 4 * cap;   // 5*cap
     int* rankv = scanbuf + 5 * cap;      // cap   (rank of an expandable node in the sorted order)
     int* sorted = rankv + cap;           // cap   (node index at each rank)
-    __shared__ int wave_tmp[8];
-    __shared__ int s_n, s_expand, s_k, s_flag;
-
-    const int kidx = frame * nlevels + level;
-    const int n_keys = min(cand_count[kidx * ORB_CC_PAD], L.cand_cap);
+    int& s_n = s_vars[0]; int& s_expand = s_vars[1]; int& s_k = s_vars[2]; int& s_flag = s_vars[3];
     const int N = L.quota;
-    const unsigned long long* K = cand + L.cand_off + (size_t)frame * cand_frame_stride;
-    uint32_t* XY = ws_xy + L.cand_off + (size_t)frame * cand_frame_stride;
-    uint16_t* ND = ws_node + L.cand_off + (size_t)frame * cand_frame_stride;
-    OrbLevelKp* OUT = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
-    if (n_keys == 0) {
-        if (tid == 0) kp_count[kidx] = 0;
-        return;
-    }
+    OD_DECL;
 
     // ---- roots (ORBextractor.cc:556-598) ----
     const int nIni = L.nIni;
@@ -673,16 +677,26 @@ __global__ __launch_bounds__(256) void octree_kernel(
         cnt[0][tid] = 0;
     }
     __syncthreads();
-    for (int k = tid; k < n_keys; k += 256) {
-        unsigned order = (unsigned)K[k];
-        int lx = order & 63, ly = (order >> 6) & 63, cell = order >> 12;
-        int ci = cell / L.nCols, cj = cell - ci * L.nCols;
-        int x = cj * L.wCell + lx, y = ci * L.hCell + ly;
-        XY[k] = (uint32_t)x | ((uint32_t)y << 16);
-        int r = (int)((float)x / L.hX);  // vpIniNodes[kp.pt.x/hX]
-        r = min(r, nIni - 1);
-        ND[k] = (uint16_t)r;
-        atomicAdd(&cnt[0][r], 1);
+    {
+        const int nCols = L.nCols, wCell = L.wCell, hCell = L.hCell;
+        const unsigned inv_cols = 0xFFFFFFFFu / (unsigned)nCols + 1u;   // cell / nCols == umulhi(cell, inv) while cell * nCols < 2^32
+        const float hX = L.hX;
+        for (int k = tid; k < n_keys; k += NT) {
+            unsigned order = (unsigned)K[k];
+            int lx = order & 63, ly = (order >> 6) & 63, cell = order >> 12;
+            int ci = (int)__umulhi((unsigned)cell, inv_cols), cj = cell - ci * nCols;
+            int x = cj * wCell + lx, y = ci * hCell + ly;
+            XY[k] = (uint32_t)x | ((uint32_t)y << 16);
+            int r = (int)((float)x / hX);  // vpIniNodes[kp.pt.x/hX]
+            r = min(r, nIni - 1);
+            ND[k] = (uint16_t)r;
+            // every key of a wave falls into one of <= 8 roots: count per root with ballots, one atomic per wave and
+            // root (same-address LDS atomics of 64 lanes would serialise)
+            for (int q = 0; q < nIni; ++q) {
+                const unsigned long long m = __ballot(r == q);
+                if (m && (tid & 63) == (int)__builtin_ctzll(m)) atomicAdd(&cnt[0][q], (int)__popcll(m));
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {  // erase empty roots, keep order (<= 8 roots)
@@ -695,19 +709,23 @@ __global__ __launch_bounds__(256) void octree_kernel(
     }
     __syncthreads();
     if (s_flag) {
-        for (int k = tid; k < n_keys; k += 256) ND[k] = (uint16_t)scanbuf[ND[k]];
+        for (int k = tid; k < n_keys; k += NT) ND[k] = (uint16_t)scanbuf[ND[k]];
         __syncthreads();
     }
 
     int cur = 0;
     int n = s_n;
     bool finish = false, careful = false;
+    OD_STAMP(0);
     while (!finish) {
         const int prevSize = n;
+#ifdef OCT_DIAG
+        ++od_pass;
+#endif
         // children populations of every expandable node
-        for (int i = tid; i < 4 * n; i += 256) childcnt[i] = 0;
+        for (int i = tid; i < 4 * n; i += NT) childcnt[i] = 0;
         __syncthreads();
-        for (int k = tid; k < n_keys; k += 256) {
+        for (int k = tid; k < n_keys; k += NT) {
             int nd = ND[k];
             if (cnt[cur][nd] > 1) {
                 uint32_t xy = XY[k];
@@ -717,6 +735,7 @@ __global__ __launch_bounds__(256) void octree_kernel(
             }
         }
         __syncthreads();
+        OD_STAMP(1);
 
         int kproc;  // number of parents split in this pass, in processing order
         if (!careful) {
@@ -724,37 +743,39 @@ __global__ __launch_bounds__(256) void octree_kernel(
             kproc = -1;
         } else {
             // "largest first": rank expandable nodes by (population desc, list position asc)
-            for (int i = tid; i < n; i += 256) {
-                int ci_ = cnt[cur][i];
+            // one wavefront per node i, lanes over j: rank = number of expandable nodes that come before i
+            for (int i = tid >> 6; i < n; i += NT / 64) {
+                const int ci_ = cnt[cur][i];
                 int r = -1;
                 if (ci_ > 1) {
                     r = 0;
-                    for (int j = 0; j < n; ++j) {
-                        int cj_ = cnt[cur][j];
-                        r += (cj_ > 1) && (cj_ > ci_ || (cj_ == ci_ && j < i));
+                    for (int j0 = 0; j0 < n; j0 += 64) {
+                        const int j = j0 + (tid & 63);
+                        const int cj_ = j < n ? cnt[cur][j] : 0;
+                        r += (int)__popcll(__ballot((cj_ > 1) && (cj_ > ci_ || (cj_ == ci_ && j < i))));
                     }
-                    sorted[r] = i;
+                    if ((tid & 63) == 0) sorted[r] = i;
                 }
-                rankv[i] = r;
+                if ((tid & 63) == 0) rankv[i] = r;
             }
             if (tid == 0) s_expand = 0;
             __syncthreads();
             // m = number of expandable nodes
             int local = 0;
-            for (int i = tid; i < n; i += 256) local += cnt[cur][i] > 1;
+            for (int i = tid; i < n; i += NT) local += cnt[cur][i] > 1;
             if (local) atomicAdd(&s_expand, local);
             __syncthreads();
             const int m = s_expand;
             // gains in sorted order, prefix, first position where the list reaches N
-            for (int s = tid; s < m; s += 256) {
+            for (int s = tid; s < m; s += NT) {
                 int i = sorted[s];
                 const int* cc = &childcnt[i * 4];
                 scanbuf[s] = (cc[0] > 0) + (cc[1] > 0) + (cc[2] > 0) + (cc[3] > 0) - 1;
             }
             if (tid == 0) s_k = m;
             __syncthreads();
-            block_exclusive_scan(scanbuf, m, wave_tmp);  // scanbuf[s] = gain of ranks < s
-            for (int s = tid; s < m; s += 256) {
+            block_exclusive_scan<NT>(scanbuf, m, wave_tmp);  // scanbuf[s] = gain of ranks < s
+            for (int s = tid; s < m; s += NT) {
                 int i = sorted[s];
                 const int* cc = &childcnt[i * 4];
                 int g = (cc[0] > 0) + (cc[1] > 0) + (cc[2] > 0) + (cc[3] > 0) - 1;
@@ -764,36 +785,37 @@ __global__ __launch_bounds__(256) void octree_kernel(
             kproc = s_k;
         }
 
+        OD_STAMP(2);
         // flags of the new list: children of split parents in reverse processing order (n4..n1),
         // then the nodes that stay, in their old order
         int nchildslots;
         if (!careful) {
             nchildslots = 4 * n;
-            for (int e = tid; e < 4 * n; e += 256) {
+            for (int e = tid; e < 4 * n; e += NT) {
                 int i = n - 1 - (e >> 2), q = 3 - (e & 3);
                 scanbuf[e] = (cnt[cur][i] > 1) && (childcnt[i * 4 + q] > 0);
             }
-            for (int i = tid; i < n; i += 256) scanbuf[4 * n + i] = cnt[cur][i] <= 1;
+            for (int i = tid; i < n; i += NT) scanbuf[4 * n + i] = cnt[cur][i] <= 1;
         } else {
             nchildslots = 4 * kproc;
-            for (int e = tid; e < nchildslots; e += 256) {
+            for (int e = tid; e < nchildslots; e += NT) {
                 int s = kproc - 1 - (e >> 2), q = 3 - (e & 3);
                 scanbuf[e] = childcnt[sorted[s] * 4 + q] > 0;
             }
-            for (int i = tid; i < n; i += 256) {
+            for (int i = tid; i < n; i += NT) {
                 int r = rankv[i];
                 scanbuf[nchildslots + i] = !(r >= 0 && r < kproc);
             }
         }
         __syncthreads();
-        const int n_new = block_exclusive_scan(scanbuf, nchildslots + n, wave_tmp);
+        const int n_new = block_exclusive_scan<NT>(scanbuf, nchildslots + n, wave_tmp);
         // (n_new <= cap by construction: a full pass only runs while n + 3*expandable <= N, the
         //  largest-first pass stops within 3 of N; clamp anyway for memory safety)
         const int nxt = cur ^ 1;
         if (tid == 0) s_expand = 0;
         __syncthreads();
         int local_expand = 0;
-        for (int e = tid; e < nchildslots; e += 256) {
+        for (int e = tid; e < nchildslots; e += NT) {
             int i, q;
             if (!careful) { i = n - 1 - (e >> 2); q = 3 - (e & 3); }
             else { i = sorted[kproc - 1 - (e >> 2)]; q = 3 - (e & 3); }
@@ -808,7 +830,7 @@ __global__ __launch_bounds__(256) void octree_kernel(
                 local_expand += cc > 1;
             }
         }
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += NT) {
             bool stays = !careful ? (cnt[cur][i] <= 1) : !(rankv[i] >= 0 && rankv[i] < kproc);
             if (stays) {
                 int pos = scanbuf[nchildslots + i];
@@ -816,8 +838,9 @@ __global__ __launch_bounds__(256) void octree_kernel(
             }
         }
         if (local_expand) atomicAdd(&s_expand, local_expand);
+        OD_STAMP(3);
         // re-label the keys
-        for (int k = tid; k < n_keys; k += 256) {
+        for (int k = tid; k < n_keys; k += NT) {
             int nd = ND[k];
             bool split = !careful ? (cnt[cur][nd] > 1) : (rankv[nd] >= 0 && rankv[nd] < kproc);
             int pos;
@@ -839,18 +862,19 @@ __global__ __launch_bounds__(256) void octree_kernel(
         __syncthreads();
         if (n >= N || n == prevSize) finish = true;            // ORBextractor.cc:682, 747
         else if (!careful && n + nToExpand * 3 > N) careful = true;  // :686
+        OD_STAMP(4);
     }
 
     // ---- best key per node (ORBextractor.cc:755-773): max response, first in input order ----
-    for (int i = tid; i < n; i += 256) best[i] = 0ull;
+    for (int i = tid; i < n; i += NT) best[i] = 0ull;
     __syncthreads();
-    for (int k = tid; k < n_keys; k += 256) {
+    for (int k = tid; k < n_keys; k += NT) {
         unsigned long long c = K[k];
         unsigned long long packed = (c & 0xFFFFFFFF00000000ull) | (0xFFFFFFFFu - (unsigned)c);
         atomicMax(&best[ND[k]], packed);
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         unsigned long long b = best[i];
         unsigned order = 0xFFFFFFFFu - (unsigned)b;
         int lx = order & 63, ly = (order >> 6) & 63, cell = order >> 12;
@@ -862,7 +886,45 @@ __global__ __launch_bounds__(256) void octree_kernel(
         kp.angle = 0.f; kp.cs = 1.f; kp.sn = 0.f;
         if (i < L.kp_cap) OUT[i] = kp;
     }
-    if (tid == 0) kp_count[kidx] = min(n, L.kp_cap);
+    if (tid == 0) *kp_count_out = min(n, L.kp_cap);
+#ifdef OCT_DIAG
+    OD_STAMP(5);
+    if (tid == 0) {
+        const int w = blockIdx.y * gridDim.x + blockIdx.x;
+        if (w < 4096) { unsigned long long* o = g_oct_ph + 8 * w; for (int k = 0; k < 6; ++k) o[k] = od_ph[k]; o[6] = ((unsigned long long)od_pass << 32) | (unsigned)n_keys; o[7] = od_rt0; o[5] = __builtin_amdgcn_s_memrealtime(); }
+    }
+#endif
+}
+
+__global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
+    const OrbLevel* __restrict__ levels, int nlevels,
+    const unsigned long long* __restrict__ cand, size_t cand_frame_stride,
+    const int* __restrict__ cand_count,
+    uint32_t* __restrict__ ws_xy, uint16_t* __restrict__ ws_node,
+    OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, int* __restrict__ kp_count,
+    int node_cap, int level_override /* -1: blockIdx.x */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int wave_tmp[OCT_THREADS / 64];
+    __shared__ int s_vars[4];
+    __shared__ uint32_t k_xy[OCT_LDS_KEYS];
+    __shared__ uint16_t k_nd[OCT_LDS_KEYS];
+    const int level = level_override >= 0 ? level_override : blockIdx.x;
+    const int frame = blockIdx.y;
+    const OrbLevel& L = levels[level];
+    const int kidx = frame * nlevels + level;
+    const int n_keys = min(cand_count[kidx * ORB_CC_PAD], L.cand_cap);
+    const unsigned long long* K = cand + L.cand_off + (size_t)frame * cand_frame_stride;
+    OrbLevelKp* OUT = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
+    if (n_keys == 0) {
+        if (threadIdx.x == 0) kp_count[kidx] = 0;
+        return;
+    }
+    if (n_keys <= OCT_LDS_KEYS)
+        octree_body<OCT_THREADS, true>(L, K, n_keys, k_xy, k_nd, OUT, &kp_count[kidx], smem, node_cap, wave_tmp, s_vars);
+    else
+        octree_body<OCT_THREADS, false>(L, K, n_keys, ws_xy + L.cand_off + (size_t)frame * cand_frame_stride,
+                                        ws_node + L.cand_off + (size_t)frame * cand_frame_stride, OUT, &kp_count[kidx], smem,
+                                        node_cap, wave_tmp, s_vars);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1255,9 +1317,10 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
                            sc_rows, kp_cap);
 }
 
-size_t orbk_octree_smem(int node_cap) {
+size_t orbk_octree_smem(int node_cap) {   // dynamic part (node arrays); the kernel adds 6 * OCT_LDS_KEYS bytes of static LDS
     return (size_t)node_cap * (8 + 2 * 8 + 2 * 4 + 4 * 4 + 5 * 4 + 4 + 4) + 64;
 }
+size_t orbk_octree_static_smem() { return (size_t)OCT_LDS_KEYS * 6 + 256; }
 
 hipError_t orbk_octree_prepare(int node_cap) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel),
@@ -1269,7 +1332,7 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
                  OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int nframes,
                  int level_override) {
     dim3 grid(level_override >= 0 ? 1 : nlevels, nframes);
-    hipLaunchKernelGGL(octree_kernel, grid, dim3(256), orbk_octree_smem(node_cap), st, levels, nlevels, cand,
+    hipLaunchKernelGGL(octree_kernel, grid, dim3(OCT_THREADS), orbk_octree_smem(node_cap), st, levels, nlevels, cand,
                        cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
                        level_override);
 }
