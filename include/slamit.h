@@ -123,6 +123,7 @@ int slamit_orb_debug_candidates(slamit_orb* h, int frame, int level, int32_t* xy
 
 /* ---- Hamming matcher -------------------------------------------------------------------- */
 
+#define SLAMIT_HAMMING_MAX_TRAIN 65535   /* train rows per set in the best/second entry points (index packed in 16 bits) */
 /* For each of nq query descriptors: best and second-best Hamming distance over the train
  * descriptors, and the index of the best (strict '<', first index wins; the reference's
  * selection rule, src/ORBmatcher.cc:1404-1428). With nt == 0: best = second = 256, idx = -1. */

@@ -36,29 +36,33 @@ __global__ __launch_bounds__(256) void hamming_best2_kernel(
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
     const bool live = qi < nq;
     if (live) { a0 = Q[2 * (size_t)qi]; a1 = Q[2 * (size_t)qi + 1]; }
-    int b = 256, s = 256, bi = -1;
+    // (best, second) are the two smallest keys (distance << 16 | train index): strict '<' with the first index
+    // winning ties is exactly the order of these keys, and a min / max / min triple updates both without a branch
+    unsigned kb = 0xFFFFFFFFu, ks = 0xFFFFFFFFu;
     for (int base = 0; base < nt; base += HM_TILE) {
         const int rows = min(HM_TILE, nt - base);
         __syncthreads();
         for (int i = tid; i < rows * 2; i += 256) tile[i] = T[2 * (size_t)base + i];
         __syncthreads();
+#pragma unroll 4
         for (int j = slice; j < rows; j += 4) {
-            uint4 t0 = tile[2 * j], t1 = tile[2 * j + 1];
-            int d = __popc(a0.x ^ t0.x) + __popc(a0.y ^ t0.y) + __popc(a0.z ^ t0.z) + __popc(a0.w ^ t0.w) +
-                    __popc(a1.x ^ t1.x) + __popc(a1.y ^ t1.y) + __popc(a1.z ^ t1.z) + __popc(a1.w ^ t1.w);
-            if (d < b) { s = b; b = d; bi = base + j; }
-            else if (d < s) s = d;
+            const uint4 t0 = tile[2 * j], t1 = tile[2 * j + 1];
+            const unsigned d = __popc(a0.x ^ t0.x) + __popc(a0.y ^ t0.y) + __popc(a0.z ^ t0.z) + __popc(a0.w ^ t0.w) +
+                               __popc(a1.x ^ t1.x) + __popc(a1.y ^ t1.y) + __popc(a1.z ^ t1.z) + __popc(a1.w ^ t1.w);
+            const unsigned k = (d << 16) | (unsigned)(base + j);
+            ks = min(ks, max(kb, k));
+            kb = min(kb, k);
         }
     }
-    // merge the 4 slices of each query (lanes 4k..4k+3)
+    // merge the 4 slices of each query (lanes 4k..4k+3): two smallest of the union
 #pragma unroll
     for (int m = 1; m <= 2; m <<= 1) {
-        int ob = __shfl_xor(b, m, 64), os = __shfl_xor(s, m, 64), oi = __shfl_xor(bi, m, 64);
-        // (b, bi) < (ob, oi) lexicographically; an empty slice has b = 256, bi = -1 and never wins
-        bool mine = (b < ob) || (b == ob && (oi < 0 || (bi >= 0 && bi < oi)));
-        if (mine) s = min(s, ob);
-        else { s = min(os, b); b = ob; bi = oi; }
+        const unsigned ob = (unsigned)__shfl_xor((int)kb, m, 64), os = (unsigned)__shfl_xor((int)ks, m, 64);
+        ks = min(min(ks, os), max(kb, ob));
+        kb = min(kb, ob);
     }
+    const int b = kb == 0xFFFFFFFFu ? 256 : (int)(kb >> 16), bi = kb == 0xFFFFFFFFu ? -1 : (int)(kb & 0xFFFFu);
+    const int s = ks == 0xFFFFFFFFu ? 256 : (int)(ks >> 16);
     if (live && slice == 0) {
         size_t o = (size_t)pair * out_stride + qi;
         best_idx[o] = bi; best[o] = b; second[o] = s;
@@ -169,6 +173,7 @@ int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size
     if ((q_stride & 15) || (t_stride & 15) || ((uintptr_t)d_q & 15) || ((uintptr_t)d_t & 15))
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_best2_batch_dev: descriptors must be 16-byte aligned");
     if (npairs == 0 || max_n == 0) return SLAMIT_OK;
+    if (max_n > SLAMIT_HAMMING_MAX_TRAIN) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_hamming_best2_batch_dev: more than SLAMIT_HAMMING_MAX_TRAIN descriptors per set");
     HIP_TRY(hipSetDevice(device));
     dim3 grid((max_n + 63) / 64, npairs);
     hipLaunchKernelGGL(hamming_best2_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_q, d_nq, 0, q_stride, d_t, d_nt,
@@ -182,6 +187,7 @@ int slamit_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int
     if (nq < 0 || nt < 0 || (nq && (!q || !best_idx || !best || !second)) || (nt && !t))
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_best2: bad argument");
     if (nq == 0) return SLAMIT_OK;
+    if (nt > SLAMIT_HAMMING_MAX_TRAIN) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_hamming_best2: more than SLAMIT_HAMMING_MAX_TRAIN train descriptors");
     uint8_t *dq = nullptr, *dt = nullptr;
     int* dout = nullptr;
     hipError_t e = hipMalloc((void**)&dq, (size_t)nq * 32);
