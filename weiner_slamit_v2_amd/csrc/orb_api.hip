@@ -261,7 +261,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
 #define ALLOC(ptr, bytes) if (e == hipSuccess) e = hipMalloc((void**)&(ptr), std::max<size_t>((bytes), 256))
     ALLOC(h->d_levels, sizeof(OrbLevel) * nl);
     ALLOC(h->d_pyr, h->pyr_frame_total * B);
-    ALLOC(h->d_blur, h->blur_frame_total * B);
+    ALLOC(h->d_blur, h->blur_frame_total * B + 256);   // + slack: the descriptor kernel stages whole dwords up to 6 bytes past a row end
     ALLOC(h->d_cand, sizeof(unsigned long long) * h->cand_frame_stride * B);
     ALLOC(h->d_ws_xy, sizeof(uint32_t) * h->cand_frame_stride * B);
     ALLOC(h->d_ws_node, sizeof(uint16_t) * h->cand_frame_stride * B);

@@ -1132,7 +1132,12 @@ __global__ __launch_bounds__(256) void blur_all_kernel(
 // final cv::KeyPoint-shaped record at its level-major position and lane 0 of keypoint 0 of
 // level 0 writes the frame total.
 // --------------------------------------------------------------------------------------------
-__constant__ signed char c_pattern[SLAMIT_ORB_PATTERN_INTS];
+__constant__ __attribute__((aligned(16))) signed char c_pattern[SLAMIT_ORB_PATTERN_INTS];
+#define DESC_KP_PER_WAVE 4
+#define DESC_R 18                 // reach of the rotated pattern
+#define DESC_ROWS (2 * DESC_R + 1)
+#define DESC_PITCH 44             // 37 columns + up to 3 of alignment, in whole dwords
+#define DESC_LOADS 7              // ceil(37 * 11 / 64) dwords per lane and keypoint
 
 __global__ __launch_bounds__(256) void describe_kernel(
     const OrbLevel* __restrict__ levels, int nlevels,
@@ -1141,7 +1146,7 @@ __global__ __launch_bounds__(256) void describe_kernel(
     slamit_kp* __restrict__ out_kps, uint8_t* __restrict__ out_desc, int out_cap,
     int* __restrict__ out_n) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_KP_PER_WAVE;
     const int level = blockIdx.y, frame = blockIdx.z;
     const OrbLevel& L = levels[level];
     const int* counts = kp_count + frame * nlevels;
@@ -1151,36 +1156,84 @@ __global__ __launch_bounds__(256) void describe_kernel(
         if (l < level) offset += c;
         total += c;
     }
-    if (level == 0 && i == 0 && lane == 0) out_n[frame] = min(total, out_cap);
-    if (i >= counts[level]) return;
-    const OrbLevelKp kp = lkp[L.kp_off + (size_t)frame * kp_frame_stride + i];
-    const int o = offset + i;
-    if (o >= out_cap) return;
-
-    const float a = kp.cs, b = kp.sn;  // a = cos, b = sin   (ORBextractor.cc:117-118; computed by ic_angle_kernel)
-    const uint8_t* img = blur + L.blur_off + (size_t)frame * L.blur_bytes;
-    const int step = L.stride;
-    const uint8_t* center = img + (size_t)kp.y * step + kp.x;
-    unsigned nib = 0;
+    if (level == 0 && i0 == 0 && lane == 0) out_n[frame] = min(total, out_cap);
+    const int count = counts[level];
+    if (i0 >= count) return;
+    // the lane's four tests (8 pattern points) are the same for every keypoint: loaded once per wave, and the
+    // keypoints of a wave are processed with all their loads in flight together (the kernel is gather-latency bound)
+    const int4 pw = reinterpret_cast<const int4*>(c_pattern)[lane];
+    const int pt[4] = {pw.x, pw.y, pw.z, pw.w};
+    float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const signed char* p = &c_pattern[(lane * 4 + t) * 4];
-        float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
-        int r0 = slamit_round_f(x0 * b + y0 * a), c0 = slamit_round_f(x0 * a - y0 * b);
-        int r1 = slamit_round_f(x1 * b + y1 * a), c1 = slamit_round_f(x1 * a - y1 * b);
-        int t0 = center[r0 * step + c0], t1 = center[r1 * step + c1];
-        nib |= (unsigned)(t0 < t1) << t;
+        px0[t] = (float)(signed char)(pt[t] & 0xFF); py0[t] = (float)(signed char)((pt[t] >> 8) & 0xFF);
+        px1[t] = (float)(signed char)((pt[t] >> 16) & 0xFF); py1[t] = (float)(signed char)((pt[t] >> 24) & 0xFF);
     }
-    unsigned other = __shfl_xor(nib, 1, WAVE);
-    if ((lane & 1) == 0)
-        out_desc[((size_t)frame * out_cap + o) * SLAMIT_DESC_BYTES + (lane >> 1)] = (uint8_t)(nib | (other << 4));
-    if (lane == 0) {
-        slamit_kp k;
-        float fx = (float)kp.x, fy = (float)kp.y;
-        if (level != 0) { fx *= L.scale; fy *= L.scale; }  // ORBextractor.cc:1126-1132
-        k.x = fx; k.y = fy; k.size = L.patch_size; k.angle = kp.angle; k.response = kp.response;
-        k.octave = level; k.class_id = -1;
-        out_kps[(size_t)frame * out_cap + o] = k;
+    const uint8_t* img = blur + L.blur_off + (size_t)frame * L.blur_bytes;
+    const unsigned step = (unsigned)L.stride;
+    const OrbLevelKp* KP = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
+    OrbLevelKp kp[DESC_KP_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < DESC_KP_PER_WAVE; ++k) kp[k] = KP[min(i0 + k, count - 1)];
+    // The rotated pattern reaches 18 px from the keypoint (max |point| = 18.4): the 37 x 37 patch is staged in LDS
+    // with row-contiguous aligned dword loads (a byte gather straight from the plane touches a different cache
+    // line per row and is bound by the L1 tag rate), then the 8 taps per lane are LDS byte reads.
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][DESC_KP_PER_WAVE][DESC_ROWS * DESC_PITCH];
+    const int wv = threadIdx.x >> 6;
+    int lrow[DESC_LOADS], lcol[DESC_LOADS];
+#pragma unroll
+    for (int it = 0; it < DESC_LOADS; ++it) {
+        const int idx = lane + 64 * it;
+        lrow[it] = (int)(((unsigned)idx * 5958u) >> 16);   // idx / 11 for idx < 448
+        lcol[it] = idx - lrow[it] * (DESC_PITCH / 4);
+    }
+    uint32_t ld[DESC_KP_PER_WAVE][DESC_LOADS];
+#pragma unroll
+    for (int k = 0; k < DESC_KP_PER_WAVE; ++k) {
+        const unsigned base = (unsigned)(kp[k].y - DESC_R) * step + (unsigned)((kp[k].x - DESC_R) & ~3);
+#pragma unroll
+        for (int it = 0; it < DESC_LOADS; ++it) {
+            const int row = min(lrow[it], DESC_ROWS - 1);
+            ld[k][it] = *reinterpret_cast<const uint32_t*>(img + (base + (unsigned)row * step + 4u * (unsigned)lcol[it]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DESC_KP_PER_WAVE; ++k)
+#pragma unroll
+        for (int it = 0; it < DESC_LOADS; ++it)
+            if (lrow[it] < DESC_ROWS) *reinterpret_cast<uint32_t*>(&s_patch[wv][k][lrow[it] * DESC_PITCH + 4 * lcol[it]]) = ld[k][it];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int tv0[DESC_KP_PER_WAVE][4], tv1[DESC_KP_PER_WAVE][4];
+#pragma unroll
+    for (int k = 0; k < DESC_KP_PER_WAVE; ++k) {
+        const float a = kp[k].cs, b = kp[k].sn;  // a = cos, b = sin   (ORBextractor.cc:117-118; computed by ic_angle_kernel)
+        const uint8_t* center = &s_patch[wv][k][DESC_R * DESC_PITCH + DESC_R + ((kp[k].x - DESC_R) & 3)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int r0 = slamit_round_f(px0[t] * b + py0[t] * a), c0 = slamit_round_f(px0[t] * a - py0[t] * b);
+            int r1 = slamit_round_f(px1[t] * b + py1[t] * a), c1 = slamit_round_f(px1[t] * a - py1[t] * b);
+            tv0[k][t] = center[r0 * DESC_PITCH + c0]; tv1[k][t] = center[r1 * DESC_PITCH + c1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DESC_KP_PER_WAVE; ++k) {
+        const int i = i0 + k, o = offset + i;
+        unsigned nib = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) nib |= (unsigned)(tv0[k][t] < tv1[k][t]) << t;
+        unsigned other = __shfl_xor(nib, 1, WAVE);
+        if (i >= count || o >= out_cap) continue;
+        if ((lane & 1) == 0)
+            out_desc[((size_t)frame * out_cap + o) * SLAMIT_DESC_BYTES + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+        if (lane == 0) {
+            slamit_kp kk;
+            float fx = (float)kp[k].x, fy = (float)kp[k].y;
+            if (level != 0) { fx *= L.scale; fy *= L.scale; }  // ORBextractor.cc:1126-1132
+            kk.x = fx; kk.y = fy; kk.size = L.patch_size; kk.angle = kp[k].angle; kk.response = kp[k].response;
+            kk.octave = level; kk.class_id = -1;
+            out_kps[(size_t)frame * out_cap + o] = kk;
+        }
     }
 }
 
@@ -1353,7 +1406,7 @@ void orbk_blur(hipStream_t st, const OrbLevel* levels, int nlevels, int total_ti
 void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,
                    const OrbLevelKp* lkp, size_t kp_frame_stride, const int* kp_count, slamit_kp* out_kps,
                    uint8_t* out_desc, int out_cap, int* out_n, int max_kp, int nframes) {
-    hipLaunchKernelGGL(describe_kernel, dim3((max_kp + 3) / 4, nlevels, nframes), dim3(256), 0, st, levels,
+    hipLaunchKernelGGL(describe_kernel, dim3((max_kp + 4 * DESC_KP_PER_WAVE - 1) / (4 * DESC_KP_PER_WAVE), nlevels, nframes), dim3(256), 0, st, levels,
                        nlevels, blur, lkp, kp_frame_stride, kp_count, out_kps, out_desc, out_cap, out_n);
 }
 
