@@ -202,6 +202,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         step(k)
+    if world > 1:
+        gather.flush()   # the last step's summary is part of the timed work
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -211,6 +213,8 @@ def main():
     # per-stage breakdown: a separate, untimed pass with events around every stage
     for k in range(args.warmup + args.steps, args.warmup + args.steps + 5):
         step(k)
+    if world > 1:
+        gather.flush()
     torch.cuda.synchronize(dev)
     all_stages = ext.profile(0)
 

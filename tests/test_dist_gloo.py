@@ -23,14 +23,22 @@ def _worker(rank, world, port, q):
         per_rank = 4
         mine = shard.weak_streams(per_rank, world, rank)
         g = shard.SummaryGather(per_rank, 2, torch.device("cpu"), world)
-        for step in range(3):
-            for i, s in enumerate(mine):  # pretend: stream s produced 1000+s keypoints, s matches at this step
-                g.local[i, 0] = 1000 + s
-                g.local[i, 1] = s * 10 + step
-            allv = g.step()
+        def check(allv, step):
             assert allv.shape == (world * per_rank, 2)
             assert allv[:, 0].tolist() == [1000 + s for s in range(world * per_rank)]
             assert allv[:, 1].tolist() == [s * 10 + step for s in range(world * per_rank)]
+
+        for step in range(4):
+            for i, s in enumerate(mine):  # pretend: stream s produced 1000+s keypoints, s matches at this step
+                g.local[i, 0] = 1000 + s
+                g.local[i, 1] = s * 10 + step
+            prev = g.step()               # pipelined by one step: returns the summary of step - 1
+            if step == 0:
+                assert prev is None
+            else:
+                check(prev, step - 1)
+        check(g.flush(), 3)
+        assert g.flush() is None
         dist.barrier()
         t = shard.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
         assert t == float(world)

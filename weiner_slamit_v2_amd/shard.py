@@ -25,17 +25,42 @@ def weak_streams(per_rank, world, rank):
 
 
 class SummaryGather:
-    """Gathers a small int32 summary (rows = this rank's frames) from all ranks each step."""
+    """Gathers a small int32 summary (rows = this rank's frames) from all ranks each step.
+
+    Pipelined by one step: step() launches the all_gather of what the caller just wrote into `local` asynchronously
+    (on the backend's own stream, ordered after the caller's stream) and returns the result of the PREVIOUS step's
+    gather, so the collective's latency overlaps the next step's kernels instead of sitting on the compute stream.
+    `local` / the gathered tensors are double-buffered; flush() returns the newest result."""
 
     def __init__(self, rows, cols, device, world):
         self.world = world
-        self.local = torch.zeros((rows, cols), dtype=torch.int32, device=device)
-        self.all = torch.zeros((world * rows, cols), dtype=torch.int32, device=device) if world > 1 else self.local
+        self._loc = [torch.zeros((rows, cols), dtype=torch.int32, device=device) for _ in range(2)]
+        self._all = [torch.zeros((world * rows, cols), dtype=torch.int32, device=device) for _ in range(2)] if world > 1 else self._loc
+        self._k = 0
+        self._pending = None
+        self.local = self._loc[0]
 
     def step(self):
+        """Publishes `local`; returns the fleet summary of the previous step (None on the first call)."""
+        prev = self.flush() if (self._pending is not None or self.world == 1 and self._k > 0) else None
+        cur = self._k & 1
         if self.world > 1:
-            dist.all_gather_into_tensor(self.all, self.local)
-        return self.all
+            self._pending = (dist.all_gather_into_tensor(self._all[cur], self._loc[cur], async_op=True), self._all[cur])
+        else:
+            self._pending = (None, self._loc[cur])
+        self._k += 1
+        self.local = self._loc[self._k & 1]
+        return prev
+
+    def flush(self):
+        """Waits for the gather in flight (stream-ordered on GPU backends) and returns its result."""
+        if self._pending is None:
+            return None
+        work, out = self._pending
+        if work is not None:
+            work.wait()
+        self._pending = None
+        return out
 
 
 def max_over_ranks(value, device, world):
