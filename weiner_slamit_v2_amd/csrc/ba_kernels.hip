@@ -370,20 +370,29 @@ __device__ __forceinline__ void ldlt_factor_diag(double* Dg, double* s_invd, con
     }
 }
 
-// rows below (and the rhs row): w_k = a_k - sum_{m<k} w_m L11[k][m]   (w = L*d), row in registers
+// rows below (and the rhs row): w = a L11^-T (w = L*d), row in registers.  RIGHT-looking: once w_k is final, the
+// 31-k updates w_m -= w_k L11[m][k] are independent of each other, so the dependent chain is 32 long instead of the
+// 496 of the dot-product form (which ran at one FMA + LDS read per ~45 cycles).
 __device__ __forceinline__ void ldlt_rows(double* Wd, const double* Dg, int rows, int tid) {
     for (int r = tid; r < rows; r += LD_THREADS) {
         double* wrow = Wd + r * LD_P;
         double w[LD_NB];
 #pragma unroll
         for (int k = 0; k < LD_NB; ++k) w[k] = wrow[k];
+        // software-pipelined: column k+1 of L11 is read from LDS while the updates with column k run
+        double lc[LD_NB], ln[LD_NB];
 #pragma unroll
-        for (int k = 1; k < LD_NB; ++k) {
-            double a = w[k];
+        for (int m = 1; m < LD_NB; ++m) lc[m] = Dg[m * LD_P];
 #pragma unroll
-            for (int m = 0; m < k; ++m) a -= w[m] * Dg[k * LD_P + m];
-            w[k] = a;
-            __builtin_amdgcn_sched_barrier(0);  // keep the 496 LDS reads from being hoisted (spills)
+        for (int k = 0; k < LD_NB - 1; ++k) {
+#pragma unroll
+            for (int m = k + 2; m < LD_NB; ++m) ln[m] = Dg[m * LD_P + k + 1];
+            const double wk = w[k];
+#pragma unroll
+            for (int m = k + 1; m < LD_NB; ++m) w[m] -= wk * lc[m];
+            __builtin_amdgcn_sched_barrier(0);  // keeps the reads of later columns from being hoisted (spills)
+#pragma unroll
+            for (int m = k + 2; m < LD_NB; ++m) lc[m] = ln[m];
         }
 #pragma unroll
         for (int k = 1; k < LD_NB; ++k) wrow[k] = w[k];
@@ -491,21 +500,31 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
         // lower-triangular tile list: t -> (rt, ct), ct <= min(rt, CT-1); waves take 4 tiles at a time
         int ntile = 0;
         for (int rt = 0; rt < RT; ++rt) ntile += min(rt + 1, CT);
+        // software pipeline over a wave's groups of 4 tiles: the C tiles of group g+1 are fetched from L2 while the
+        // MFMAs of group g run (a group's loads are a ~1.5k-cycle round trip, its 32 MFMAs about as long)
+        double4_t nxt[4];
+        int nrt[4], nct[4];
+        auto fetch = [&](int t0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int t = t0 + q, rt = 0;
+                if (t >= ntile) { nrt[q] = -1; nct[q] = 0; nxt[q] = (double4_t){0, 0, 0, 0}; continue; }
+                while (t >= min(rt + 1, CT)) { t -= min(rt + 1, CT); ++rt; }
+                nrt[q] = rt; nct[q] = t;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = 16 * rt + (lane >> 4) + 4 * g, c = 16 * t + (lane & 15);
+                    nxt[q][g] = (r < rows && c < below && c <= r) ? S[(size_t)(base + r) * N + base + c] : 0.0;
+                }
+            }
+        };
+        if (4 * wv < ntile) fetch(4 * wv);
         for (int t0 = 4 * wv; t0 < ntile; t0 += 4 * (LD_THREADS / 64)) {
             double4_t acc[4];
             int trt[4], tct[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int t = t0 + q, rt = 0;
-                if (t >= ntile) { trt[q] = -1; tct[q] = 0; acc[q] = (double4_t){0, 0, 0, 0}; continue; }
-                while (t >= min(rt + 1, CT)) { t -= min(rt + 1, CT); ++rt; }
-                trt[q] = rt; tct[q] = t;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int r = 16 * rt + (lane >> 4) + 4 * g, c = 16 * t + (lane & 15);
-                    acc[q][g] = (r < rows && c < below && c <= r) ? S[(size_t)(base + r) * N + base + c] : 0.0;
-                }
-            }
+            for (int q = 0; q < 4; ++q) { acc[q] = nxt[q]; trt[q] = nrt[q]; tct[q] = nct[q]; }
+            if (t0 + 4 * (LD_THREADS / 64) < ntile) fetch(t0 + 4 * (LD_THREADS / 64));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rt = trt[q] < 0 ? 0 : trt[q], ct = tct[q];
@@ -542,20 +561,49 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     // earlier unknown i < jb takes y_i -= sum_m L[jb+m][i] * x_m, reading ROWS of L (coalesced).
     double* xs = Wd;                 // n doubles
     for (int i = tid; i < n; i += LD_THREADS) xs[i] = S[(size_t)n * N + i];
-    __syncthreads();
-    for (int jb = ((n - 1) / LD_NB) * LD_NB; jb >= 0; jb -= LD_NB) {
-        const int nb = min(LD_NB, n - jb);
-        if (wv == 0) ldlt_back_block(S, N, xs, jb, nb, lane);
-        __syncthreads();
-        for (int i = tid; i < jb; i += LD_THREADS) {
-            double acc = xs[i];
-            double lv[LD_NB];
+    // L is final now, so nothing a block needs depends on x: wavefront 0 fetches the NEXT block's L11 columns, and
+    // every thread the next block's L rows, while the current block is being solved / applied.
+    const int jb_last = ((n - 1) / LD_NB) * LD_NB;
+    double col[LD_NB], lv[LD_NB];
+    auto fetch_col = [&](int jb) {
+        const int nb = min(LD_NB, n - jb), k = lane;
 #pragma unroll
-            for (int m = 0; m < LD_NB; ++m) lv[m] = (m < nb) ? S[(size_t)(jb + m) * N + i] : 0.0;
+        for (int m = 0; m < LD_NB; ++m) col[m] = (k < nb && m < nb && m > k) ? S[(size_t)(jb + m) * N + jb + k] : 0.0;
+    };
+    auto fetch_rows = [&](int jb) {   // rows jb .. jb+nb-1 of L at column tid (columns >= LD_THREADS: plain loop below)
+        const int nb = min(LD_NB, n - jb);
+#pragma unroll
+        for (int m = 0; m < LD_NB; ++m) lv[m] = (m < nb && tid < jb) ? S[(size_t)(jb + m) * N + tid] : 0.0;
+    };
+    if (wv == 0) fetch_col(jb_last);
+    fetch_rows(jb_last);
+    __syncthreads();
+    for (int jb = jb_last; jb >= 0; jb -= LD_NB) {
+        const int nb = min(LD_NB, n - jb);
+        if (wv == 0) {
+            const int k = lane;
+            double v = (k < nb) ? xs[jb + k] : 0.0;
+#pragma unroll
+            for (int m = LD_NB - 1; m >= 0; --m) {
+                const double xm = readlane_d(v, m);   // final once every higher index has been applied
+                if (m < nb && k < m) v -= col[m] * xm;
+            }
+            if (k < nb) xs[jb + k] = v;
+            if (jb >= LD_NB) fetch_col(jb - LD_NB);
+        }
+        __syncthreads();
+        if (tid < jb) {
+            double acc = xs[tid];
 #pragma unroll
             for (int m = 0; m < LD_NB; ++m) acc -= lv[m] * xs[jb + m];
+            xs[tid] = acc;
+        }
+        for (int i = tid + LD_THREADS; i < jb; i += LD_THREADS) {   // systems wider than the workgroup
+            double acc = xs[i];
+            for (int m = 0; m < nb; ++m) acc -= S[(size_t)(jb + m) * N + i] * xs[jb + m];
             xs[i] = acc;
         }
+        if (jb >= LD_NB) fetch_rows(jb - LD_NB);
         __syncthreads();
     }
     for (int i = tid; i < n; i += LD_THREADS) W.rhs[i] = xs[i];
