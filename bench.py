@@ -76,6 +76,37 @@ def cpu_baseline(frames_a, frames_b, nfeat=1000, budget_s=12.0, min_frames=16):
                 n, frames_a[0].shape[1], frames_a[0].shape[0], nfeat, el)}
 
 
+def cpu_baseline_all_cores(frames_a, frames_b, nfeat=1000, budget_s=8.0):
+    """SURVEY 8(d)'s second comparator: one oracle instance per host thread (ctypes releases the GIL inside the
+    oracle), every thread running the same extract + match-to-previous loop on its own stream."""
+    import concurrent.futures as cf
+    from oracle import bindings as ob
+
+    ncores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    # a 1-GPU box owns a 16-core share of its host whatever the affinity mask says; SLAMIT_CPU_THREADS overrides
+    ncores = int(os.environ.get("SLAMIT_CPU_THREADS", min(ncores, 16)))
+
+    def worker(w):
+        orc = ob.OrbOracle(nfeat, 1.2, NLEVELS, 20, 7)
+        t0, n, prev, i = time.perf_counter(), 0, None, w
+        while time.perf_counter() - t0 < budget_s:
+            src = frames_a if (i // len(frames_a)) % 2 == 0 else frames_b
+            _, d = orc.extract(src[i % len(frames_a)])
+            if prev is not None:
+                ob.best2(d, prev)
+            prev, n, i = d, n + 1, i + 1
+        return n, time.perf_counter() - t0
+
+    ob.orb_lib()   # build / load once before the threads start
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(ncores) as ex:
+        res = list(ex.map(worker, range(ncores)))
+    el = time.perf_counter() - t0
+    n = sum(r[0] for r in res)
+    return {"value": round(n / el, 2), "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": "%d frames over %d threads (one oracle instance and stream per thread), %.1f s" % (n, ncores, el)}
+
+
 def cpu_baseline_ba(prob):
     """The BA oracle (CPU port pinned to the reference's g2o) on one host core, one window."""
     from oracle import bindings as ob
@@ -113,6 +144,13 @@ def ba_secondary(device, steps, with_cpu=True):
             elb = time.perf_counter() - t1
             entry = {"edges": ne, "value": round(its / el, 1), "ms_per_window": round(1e3 * el / reps, 3),
                      "batch8_value": round(sum(sum(x["stats"]["n_its"]) for x in rb) / elb, 1)}
+            opt.close()
+            opt = api.Optimizer(64, 2048, ne + 64, 64, device)   # also a batch of 64 windows per GPU
+            opt.LocalBundleAdjustmentBatch([prob] * 64)
+            t1 = time.perf_counter()
+            rb = opt.LocalBundleAdjustmentBatch([prob] * 64)
+            elb = time.perf_counter() - t1
+            entry["batch64_value"] = round(sum(sum(x["stats"]["n_its"]) for x in rb) / elb, 1)
             # Schur product: one dense 2 * Npad^2/2 * Kpad flop MFMA launch per LM trial
             if with_cpu:
                 entry["cpu_baseline"] = cpu_baseline_ba(prob)
@@ -265,6 +303,7 @@ def main():
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(fa, fb, NFEAT)
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(fa, fb, NFEAT)
         if not args.no_ba:
             out["secondary"] = ba_secondary(dev.index, args.steps, with_cpu=not args.no_cpu)
         print(json.dumps(out), flush=True)

@@ -497,53 +497,69 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
         STAMP(3);
 #ifndef LD_DIAG_SKIP_TRAIL
         const int RT = rows16 >> 4, CT = (below + 15) >> 4;
-        // lower-triangular tile list: t -> (rt, ct), ct <= min(rt, CT-1); waves take 4 tiles at a time
+        // lower-triangular tile list in row-major order: t -> (rt, ct), ct <= min(rt, CT-1).  Each wave takes a
+        // contiguous run of it, so the A fragments (-w[r][k] / d_k, 8 doubles per lane) are loaded once per row tile
+        // and a tile costs 8 LDS reads (B fragments) + 8 MFMAs; the next tile's C (L2) and B (LDS) are fetched while
+        // the current tile's MFMAs run.
         int ntile = 0;
         for (int rt = 0; rt < RT; ++rt) ntile += min(rt + 1, CT);
-        // software pipeline over a wave's groups of 4 tiles: the C tiles of group g+1 are fetched from L2 while the
-        // MFMAs of group g run (a group's loads are a ~1.5k-cycle round trip, its 32 MFMAs about as long)
-        double4_t nxt[4];
-        int nrt[4], nct[4];
-        auto fetch = [&](int t0) {
+        const int per = (ntile + LD_THREADS / 64 - 1) / (LD_THREADS / 64);
+        int t = wv * per;
+        const int tend = min(ntile, t + per);
+        if (t < tend) {
+            int rt = 0, ct = t;
+            while (ct >= min(rt + 1, CT)) { ct -= min(rt + 1, CT); ++rt; }
+            const int l15 = lane & 15, lk = lane >> 4;
+            double invd8[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int t = t0 + q, rt = 0;
-                if (t >= ntile) { nrt[q] = -1; nct[q] = 0; nxt[q] = (double4_t){0, 0, 0, 0}; continue; }
-                while (t >= min(rt + 1, CT)) { t -= min(rt + 1, CT); ++rt; }
-                nrt[q] = rt; nct[q] = t;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int r = 16 * rt + (lane >> 4) + 4 * g, c = 16 * t + (lane & 15);
-                    nxt[q][g] = (r < rows && c < below && c <= r) ? S[(size_t)(base + r) * N + base + c] : 0.0;
-                }
-            }
-        };
-        if (4 * wv < ntile) fetch(4 * wv);
-        for (int t0 = 4 * wv; t0 < ntile; t0 += 4 * (LD_THREADS / 64)) {
-            double4_t acc[4];
-            int trt[4], tct[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { acc[q] = nxt[q]; trt[q] = nrt[q]; tct[q] = nct[q]; }
-            if (t0 + 4 * (LD_THREADS / 64) < ntile) fetch(t0 + 4 * (LD_THREADS / 64));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rt = trt[q] < 0 ? 0 : trt[q], ct = tct[q];
-#pragma unroll
-                for (int ks = 0; ks < LD_NB; ks += 4) {
-                    const int kk = ks + (lane >> 4);
-                    const double a = -Wd[(16 * rt + (lane & 15)) * LD_P + kk] * s_invd[kk];
-                    const double b = Wd[(16 * ct + (lane & 15)) * LD_P + kk];
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (trt[q] < 0) continue;
+            for (int ks = 0; ks < 8; ++ks) invd8[ks] = s_invd[4 * ks + lk];
+            double af[8], bc[8], bn[8];
+            double4_t cc, cn;
+            int art = -1;
+            auto load_tile = [&](int frt, int fct, double4_t& C, double* B) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int r = 16 * trt[q] + (lane >> 4) + 4 * g, c = 16 * tct[q] + (lane & 15);
-                    if (r < rows && c < below && c <= r) S[(size_t)(base + r) * N + base + c] = acc[q][g];
+                    const int r = 16 * frt + lk + 4 * g, c = 16 * fct + l15;
+#ifdef LD_X_NOMEM
+                    C[g] = 0.0;
+#else
+                    C[g] = (r < rows && c < below && c <= r) ? S[(size_t)(base + r) * N + base + c] : 0.0;
+#endif
                 }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) B[ks] = Wd[(16 * fct + l15) * LD_P + 4 * ks + lk];
+            };
+            load_tile(rt, ct, cc, bc);
+            for (; t < tend; ++t) {
+                if (rt != art) {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) af[ks] = -Wd[(16 * rt + l15) * LD_P + 4 * ks + lk] * invd8[ks];
+                    art = rt;
+                }
+                int nrt = rt, nct = ct + 1;
+                if (nct >= min(rt + 1, CT)) { nrt = rt + 1; nct = 0; }
+                if (t + 1 < tend) load_tile(nrt, nct, cn, bn);
+                double4_t acc = cc;
+#ifdef LD_X_NOMFMA
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc[ks & 3] += af[ks] * bc[ks];
+#else
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bc[ks], acc, 0, 0, 0);
+#endif
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = 16 * rt + lk + 4 * g, c = 16 * ct + l15;
+#ifdef LD_X_NOMEM
+                    if (r == -1) S[c] = acc[g];
+#else
+                    if (r < rows && c < below && c <= r) S[(size_t)(base + r) * N + base + c] = acc[g];
+#endif
+                }
+                cc = cn;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) bc[ks] = bn[ks];
+                rt = nrt; ct = nct;
             }
         }
 #endif
