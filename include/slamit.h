@@ -103,8 +103,8 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
  * (either may be NULL), then switches recording on/off.  Stages: 0 pyramid resize, 1 FAST cells,
  * 2 octree, 3 IC angle, 4 Gaussian blur, 5 rBRIEF + output.  A "call" is one stage of one
  * extract_batch call (the resize stage launches one kernel per level).  enable: 0 off, 1 every stage,
- * 2 only stage 1 (the dominant kernel): an event between two kernels costs a few microseconds of pipeline
- * drain, so a throughput run that still wants the dominant kernel's live duration uses 2. */
+ * n >= 2 only stage 1 (the dominant kernel) on every (n-1)-th extract call: an event between two kernels costs
+ * ~10 us of pipeline drain, so a throughput run that still wants the dominant kernel's live duration samples it. */
 #define SLAMIT_ORB_STAGES 6
 int slamit_orb_profile(slamit_orb* h, int enable, float* stage_ms, int32_t* stage_calls, int nstages);
 

@@ -128,6 +128,7 @@ struct slamit_orb {
     size_t scratch_bytes;
     // optional per-stage hipEvent timing (slamit_orb_profile)
     int prof_on;
+    long prof_call;                       // extract calls since profiling was switched on
     std::vector<hipEvent_t> prof_ev;   // pairs (begin, end)
     std::vector<int> prof_stage;       // stage id of each pair
     // last call (for slamit_orb_level / debug getters)
@@ -425,7 +426,8 @@ int slamit_orb_max_keypoints(const slamit_orb* h) { return h ? h->max_out : 0; }
 enum { ST_RESIZE = 0, ST_FAST, ST_OCTREE, ST_ANGLE, ST_BLUR, ST_DESCRIBE, ST_COUNT };
 
 static void prof_mark(slamit_orb* h, hipStream_t st, int stage, bool begin) {
-    if (!h->prof_on || (h->prof_on == 2 && stage != ST_FAST) || h->prof_ev.size() >= 2 * 16384) return;
+    if (!h->prof_on || h->prof_ev.size() >= 2 * 16384) return;
+    if (h->prof_on >= 2 && (stage != ST_FAST || h->prof_call % (h->prof_on - 1) != 0)) return;   // dominant kernel, sampled
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     hipEventRecord(e, st);
@@ -505,6 +507,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     orbk_describe(st, h->d_levels, nl, h->d_blur, h->d_lkp, h->kp_frame_stride, kp_count, d_kps, d_desc, cap, d_n_out,
                   h->max_kp_level, nframes);
     prof_mark(h, st, ST_DESCRIBE, false);
+    ++h->prof_call;
     HIP_TRY(hipGetLastError());
     h->last_img0 = d_gray; h->last_stride = stride; h->last_frame = frame_stride; h->last_nframes = nframes;
     return SLAMIT_OK;
@@ -565,6 +568,7 @@ int slamit_orb_profile(slamit_orb* h, int enable, float* stage_ms, int32_t* stag
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
     h->prof_ev.clear(); h->prof_stage.clear();
     h->prof_on = enable;
+    h->prof_call = 0;
     return SLAMIT_OK;
 }
 
