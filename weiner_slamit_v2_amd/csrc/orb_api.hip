@@ -328,11 +328,9 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         if (const char* sv = getenv("SLAMIT_PYR_TILE")) { if (sscanf(sv, "%dx%d", &tw, &th) != 2 || tw < 8 || th < 8) tw = th = 0; }
         std::vector<PyrBox> boxes;
         bool okb = true;
-        int first = 0;
-        h->pyr_segs.clear();
-        for (size_t si = 0; si <= cuts.size() && okb; ++si) {
-            const int last = si < cuts.size() ? cuts[si] : nl - 1;
-            slamit_orb::PyrSeg seg;
+        // plans one segment first -> last with regions of tw x th pixels at its last level (0 = 128x96 level-0 pixels)
+        auto plan = [&](int first, int last, int tw, int th, slamit_orb::PyrSeg& seg) -> bool {
+            bool ok = true;
             seg.first = first; seg.last = last; seg.box_off = (int)boxes.size();
             const OrbLevel& LL = h->levels[last];
             const int GX = tw ? std::max(1, (LL.w + tw - 1) / tw) : std::max(1, (p->width + 127) / 128);
@@ -340,19 +338,19 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
             seg.nregions = GX * GY;
             boxes.resize(boxes.size() + (size_t)GX * GY * nl);
             size_t capA = 16, capB = 16;
-            for (int gy = 0; gy < GY && okb; ++gy)
-                for (int gx = 0; gx < GX && okb; ++gx) {
+            for (int gy = 0; gy < GY && ok; ++gy)
+                for (int gx = 0; gx < GX && ok; ++gx) {
                     PyrBox* B = &boxes[seg.box_off + ((size_t)gy * GX + gx) * nl];
                     for (int l = first; l <= last; ++l) {
                         const OrbLevel& L = h->levels[l];
                         B[l].ox0 = (int16_t)((long)gx * L.w / GX); B[l].ox1 = (int16_t)((long)(gx + 1) * L.w / GX);
                         B[l].oy0 = (int16_t)((long)gy * L.h / GY); B[l].oy1 = (int16_t)((long)(gy + 1) * L.h / GY);
                         if (l == first) { B[l].ox0 = B[l].ox1 = B[l].oy0 = B[l].oy1 = 0; }  // the segment's source is only read
-                        else if (B[l].ox1 <= B[l].ox0 || B[l].oy1 <= B[l].oy0) okb = false;
+                        else if (B[l].ox1 <= B[l].ox0 || B[l].oy1 <= B[l].oy0) ok = false;
                     }
                     B[last].nx0 = B[last].ox0; B[last].nx1 = B[last].ox1;
                     B[last].ny0 = B[last].oy0; B[last].ny1 = B[last].oy1;
-                    for (int l = last; l > first && okb; --l) {
+                    for (int l = last; l > first && ok; --l) {
                         const int sw = h->levels[l - 1].w, sh = h->levels[l - 1].h;
                         int sx0 = XO[l][B[l].nx0], sx1 = std::min(XO[l][B[l].nx1 - 1] + 1, sw - 1) + 1;
                         int sy0 = std::min(std::max(YO[l][B[l].ny0], 0), sh - 1);
@@ -365,15 +363,23 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
                         B[l - 1].nx0 = (int16_t)sx0; B[l - 1].nx1 = (int16_t)sx1; B[l - 1].ny0 = (int16_t)sy0; B[l - 1].ny1 = (int16_t)sy1;
                     }
                     for (int l = first; l <= last; ++l) {
-                        if (l > first && (B[l].nx1 - B[l].nx0 > 256 || B[l].ny1 - B[l].ny0 > 256)) okb = false;  // <= 4 columns per lane, row tables of 256
+                        if (l > first && (B[l].nx1 - B[l].nx0 > 256 || B[l].ny1 - B[l].ny0 > 256)) ok = false;  // <= 4 columns per lane, row tables of 256
                         size_t bytes = (size_t)(((B[l].nx1 - B[l].nx0) + 3) & ~3) * (B[l].ny1 - B[l].ny0);
                         if ((l - first) & 1) capB = std::max(capB, bytes); else capA = std::max(capA, bytes);
                     }
                 }
             seg.bufA = (int)round_up(capA, 16);
             seg.smem = seg.bufA + (int)round_up(capB, 16);
-            if (seg.smem > 150 * 1024) okb = false;
+            if (seg.smem > 150 * 1024) ok = false;
             seg.threads = tw && (size_t)tw * th <= 64 * 48 ? 256 : 512;
+            return ok;
+        };
+        int first = 0;
+        h->pyr_segs.clear();
+        for (size_t si = 0; si <= cuts.size() && okb; ++si) {
+            const int last = si < cuts.size() ? cuts[si] : nl - 1;
+            slamit_orb::PyrSeg seg;
+            okb = plan(first, last, tw, th, seg);
             h->pyr_segs.push_back(seg);
             first = last;
         }
