@@ -345,28 +345,52 @@ __device__ __forceinline__ double fast_recip(double d) {
     return x;
 }
 
-__device__ __forceinline__ void ldlt_factor_diag(double* Dg, double* s_invd, const unsigned char* s_pr,
-                                                 const unsigned char* s_pc, const short* s_off, int nb, int tid,
-                                                 int* s_fail) {
-    // Column k is never written once step k starts (updates touch columns > k), so the unit-L entries
-    // are produced at the very end from the untouched (L*d) columns and a step needs ONE barrier.
-    for (int k = 0; k < nb; ++k) {
-        const double d = Dg[k * LD_P + k];
-        const bool bad = (d == 0.0 || !(fabs(d) <= DBL_MAX));
-        const double invd = bad ? 0.0 : fast_recip(d);
-        const int p = s_off[k + 1] + tid;
+__device__ __forceinline__ void ldlt_factor_diag(double* Dg, double* s_invd, double* s_corr, double* s_dval,
+                                                 const unsigned char* s_pr, const unsigned char* s_pc, const short* s_off,
+                                                 int nb, int tid, int* s_fail) {
+    // TWO columns per step (16 barriers per block instead of 32): with d0 = a[k][k], f = a[k+1][k] / d0 and
+    // d1 = a[k+1][k+1] - a[k+1][k] f, every pair (r, c), c >= k+2, takes the rank-2 update
+    //     a[r][c] -= a[r][k] a[c][k] / d0 + a'[r] a'[c] / d1,   a'[x] = a[x][k+1] - a[x][k] f
+    // Columns k and k+1 themselves are never written inside the loop (their final L*d values are a[.][k] and a'[.]),
+    // so one barrier per step is enough; the unit-L entries are produced at the end from the untouched columns.
+    for (int k = 0; k < nb; k += 2) {
+        const bool two = k + 1 < nb;
+        const double d0 = Dg[k * LD_P + k];
+        const bool bad0 = (d0 == 0.0 || !(fabs(d0) <= DBL_MAX));
+        const double inv0 = bad0 ? 0.0 : fast_recip(d0);
+        const double l10 = two ? Dg[(k + 1) * LD_P + k] : 0.0;
+        const double f = l10 * inv0;
+        const double d1 = two ? Dg[(k + 1) * LD_P + k + 1] - l10 * f : 1.0;
+        const bool bad1 = two && (d1 == 0.0 || !(fabs(d1) <= DBL_MAX));
+        const double inv1 = (two && !bad1) ? fast_recip(d1) : 0.0;
+        const int p = s_off[k + 2] + tid;
         if (p < LD_PAIRS) {
             const int r = s_pr[p], c = s_pc[p];
-            if (r < nb) Dg[r * LD_P + c] -= Dg[r * LD_P + k] * Dg[c * LD_P + k] * invd;
+            if (r < nb) {
+                const double ark = Dg[r * LD_P + k], ack = Dg[c * LD_P + k];
+                const double ar1 = Dg[r * LD_P + k + 1] - ark * f, ac1 = Dg[c * LD_P + k + 1] - ack * f;
+                Dg[r * LD_P + c] -= ark * ack * inv0 + ar1 * ac1 * inv1;
+            }
         }
-        if (tid == 0) { s_invd[k] = invd; if (bad) *s_fail = 1; }
+        if (tid == 0) {
+            s_invd[k] = inv0;
+            if (two) { s_invd[k + 1] = inv1; s_corr[k + 1] = f; s_dval[k + 1] = d1; }
+            if (bad0 || bad1) *s_fail = 1;
+        }
         __syncthreads();
     }
     for (int k = nb + tid; k < LD_NB; k += LD_THREADS) s_invd[k] = 0.0;
-    // scale the strictly-lower part: L[r][c] = (L d)[r][c] / d_c
-    for (int i = tid; i < LD_NB * LD_NB; i += LD_THREADS) {
-        const int r = i >> 5, c = i & 31;
-        if (r < nb && c < r) Dg[r * LD_P + c] *= s_invd[c];
+    __syncthreads();
+    // unit-L entries and the diagonal of the odd columns: thread -> row r, column pair (c, c+1), c even
+    for (int i = tid; i < LD_NB * (LD_NB / 2); i += LD_THREADS) {
+        const int r = i >> 4, c = (i & 15) * 2;
+        if (r >= nb) continue;
+        const double a = Dg[r * LD_P + c], b2 = Dg[r * LD_P + c + 1];
+        if (r > c) Dg[r * LD_P + c] = a * s_invd[c];
+        if (c + 1 < nb) {
+            if (r > c + 1) Dg[r * LD_P + c + 1] = (b2 - a * s_corr[c + 1]) * s_invd[c + 1];
+            else if (r == c + 1) Dg[r * LD_P + r] = s_dval[c + 1];
+        }
     }
 }
 
@@ -424,9 +448,9 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     double* Dg = sm;                      // LD_NB x LD_P: diagonal block (unit L below, D on the diagonal)
     double* Wd = Dg + LD_NB * LD_P;       // (rows below + rhs row, padded to 16) x LD_P: L21 * D
     __shared__ int s_fail;
-    __shared__ double s_invd[LD_NB];
+    __shared__ double s_invd[LD_NB], s_corr[LD_NB], s_dval[LD_NB];
     __shared__ unsigned char s_pr[LD_PAIRS], s_pc[LD_PAIRS];
-    __shared__ short s_off[LD_NB + 1];
+    __shared__ short s_off[LD_NB + 2];
     if (tid == 0) {
         s_fail = 0;
         int p = 0;
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
             s_off[c] = (short)p;
             for (int r = c; r < LD_NB; ++r) { s_pr[p] = (unsigned char)r; s_pc[p] = (unsigned char)c; ++p; }
         }
-        s_off[LD_NB] = (short)p;
+        s_off[LD_NB] = (short)p; s_off[LD_NB + 1] = (short)p;
     }
     if (n == 0) { if (tid == 0) st->ok2 = 1; return; }
 #ifdef BA_DIAG_STAMPS
@@ -477,7 +501,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
         }
         __syncthreads();
         STAMP(0);
-        ldlt_factor_diag(Dg, s_invd, s_pr, s_pc, s_off, nb, tid, &s_fail);
+        ldlt_factor_diag(Dg, s_invd, s_corr, s_dval, s_pr, s_pc, s_off, nb, tid, &s_fail);
         STAMP(1);
         __syncthreads();
         if (s_fail) break;
