@@ -194,6 +194,40 @@ int slamit_guided_search(int device, const slamit_frame_view* frame, const slami
                          const slamit_search_rule* rule, int32_t* match_kp, int32_t* nmatches, int32_t* best_dist,
                          int32_t* best_level, int32_t* second_dist, int32_t* second_level);
 
+/* ---- Frame epilogue -------------------------------------------------------
+ * What Frame's constructors do right after the extractor: Frame::UndistortKeyPoints (src/Frame.cc:529-559, through
+ * cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK)) and Frame::AssignFeaturesToGrid (:336-357, PosInGrid
+ * :505-517), fused so that keypoints never leave the GPU between extraction and the guided search.
+ * cv::undistortPoints is OpenCV's (absent from the reference tree): restated from the published cvUndistortPoints,
+ * parity unpinned (oracle/orb_oracle.cc).  k1 == 0 leaves the keypoints untouched like Frame.cc:531-535. */
+typedef struct slamit_camera {
+    float fx, fy, cx, cy;      /* mK */
+    float k1, k2, p1, p2, k3;  /* mDistCoef (k3 = 0 for a 4-coefficient model) */
+} slamit_camera;
+
+#define SLAMIT_FRAME_GRID_COLS 64   /* FRAME_GRID_COLS, include/Frame.h:41 */
+#define SLAMIT_FRAME_GRID_ROWS 48   /* FRAME_GRID_ROWS, include/Frame.h:40 */
+#define SLAMIT_FRAME_GRID_CELLS (SLAMIT_FRAME_GRID_COLS * SLAMIT_FRAME_GRID_ROWS)
+#define SLAMIT_FRAME_MAX_KP 30000
+
+/* cv::undistortPoints(xy, xy, K, D, Mat(), K) on n points (what Frame::ComputeImageBounds feeds the four image
+ * corners to, Frame.cc:561-590).  No k1 == 0 shortcut here: that belongs to Frame::UndistortKeyPoints. */
+int slamit_undistort_points(int device, const slamit_camera* cam, const float* xy_in, int n, float* xy_out);
+
+/* kps_un[i] = kps[i] with the undistorted pt (mvKeysUn); the grid mGrid[x][y] as CSR: the indices of cell
+ * c = x * 48 + y are cell_items[cell_start[c] .. cell_start[c+1]) in keypoint (push_back) order, cell_start has
+ * SLAMIT_FRAME_GRID_CELLS + 1 entries, cell_start[last] = number of keypoints inside the grid.
+ * min_x/min_y/inv_w/inv_h = mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv. */
+int slamit_frame_finish(int device, const slamit_camera* cam, const slamit_kp* kps, int n, float min_x, float min_y,
+                        float inv_w, float inv_h, slamit_kp* kps_un, int32_t* cell_start, int32_t* cell_items);
+
+/* Same for a batch of frames resident in HBM in the layout slamit_orb_extract_batch_dev writes (frame f: d_kps +
+ * f * cap, d_n[f] keypoints); d_cell_start is [nframes][SLAMIT_FRAME_GRID_CELLS + 1], d_cell_items [nframes][cap].
+ * Asynchronous on `stream`. */
+int slamit_frame_finish_batch_dev(int device, const slamit_camera* cam, const slamit_kp* d_kps, const int32_t* d_n, int cap,
+                                  int nframes, float min_x, float min_y, float inv_w, float inv_h, slamit_kp* d_kps_un,
+                                  int32_t* d_cell_start, int32_t* d_cell_items, void* stream);
+
 /* Full distance matrix (nq x nt, uint16), the batched form of DescriptorDistance. */
 int slamit_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out);
 

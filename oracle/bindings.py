@@ -70,6 +70,9 @@ def orb_lib():
         L.orb_oracle_guided_search.argtypes = [C.c_int, _f32p, _i32p, _u8p, _u8p, C.c_float, C.c_float, C.c_float, C.c_float,
                                                C.c_int, _f32p, _i32p, _i32p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_float,
                                                _i32p, _i32p]
+        L.orb_oracle_undistort.argtypes = [_f32p, _f32p, C.c_int, _f32p]
+        L.orb_oracle_frame_finish.argtypes = [_f32p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                              _i32p, _i32p]
         _orb = L
     return _orb
 
@@ -250,6 +253,29 @@ def normalize_search(frame, queries):
              valid=np.ascontiguousarray(queries.get("valid", np.ones(m)), np.uint8),
              takes=np.ascontiguousarray(queries.get("takes", np.ones(m)), np.uint8))
     return f, q
+
+
+def undistort(cam9, xy):
+    """cv::undistortPoints(xy, K, D, R = I, P = K) restated (see orb_oracle.cc); cam9 = fx fy cx cy k1 k2 p1 p2 k3."""
+    cam9 = np.ascontiguousarray(cam9, np.float32)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    if len(xy):
+        orb_lib().orb_oracle_undistort(_ptr(cam9, _f32p), _ptr(xy, _f32p), len(xy), _ptr(out, _f32p))
+    return out
+
+
+def frame_finish(cam9, kps, min_x, min_y, inv_w, inv_h):
+    """Frame::UndistortKeyPoints + AssignFeaturesToGrid: returns (kps_un, cell_start[3073], cell_items)."""
+    cam9 = np.ascontiguousarray(cam9, np.float32)
+    kps = np.ascontiguousarray(kps)
+    n = len(kps)
+    un = np.zeros(max(n, 1), KP_DTYPE)
+    start, items = np.zeros(64 * 48 + 1, np.int32), np.zeros(max(n, 1), np.int32)
+    m = orb_lib().orb_oracle_frame_finish(_ptr(cam9, _f32p), kps.ctypes.data_as(C.c_void_p), n, float(np.float32(min_x)),
+                                          float(np.float32(min_y)), float(np.float32(inv_w)), float(np.float32(inv_h)),
+                                          un.ctypes.data_as(C.c_void_p), _ptr(start, _i32p), _ptr(items, _i32p))
+    return un[:n], start, items[:m]
 
 
 def matrix(q, t):

@@ -922,3 +922,55 @@ extern "C" int orb_oracle_guided_search(int n, const float* kp_xy, const int32_t
 }
 
 
+
+// ---- Frame::UndistortKeyPoints / ComputeImageBounds / AssignFeaturesToGrid ---------------------------------------
+// cv::undistortPoints(src, dst, K, D, Mat(), K) (called at Frame.cc:548, :572) is OpenCV (2.4.9 here), not in the
+// reference tree: restated from the published cvUndistortPoints — normalise, 5 fixed-point iterations of the inverse
+// Brown model in double, re-project with P = K (R = I).  PARITY UNPINNED like the other OpenCV primitives.
+// Frame::UndistortKeyPoints returns the input untouched when k1 == 0 (Frame.cc:531-535).
+extern "C" void orb_oracle_undistort(const float* cam9 /*fx fy cx cy k1 k2 p1 p2 k3*/, const float* xy_in, int n, float* xy_out) {
+    const double fx = cam9[0], fy = cam9[1], cx = cam9[2], cy = cam9[3];
+    const double k[8] = {cam9[4], cam9[5], cam9[6], cam9[7], cam9[8], 0., 0., 0.};
+    const double ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; i++) {
+        double x = xy_in[2 * i], y = xy_in[2 * i + 1];
+        const double x0 = x = (x - cx) * ifx, y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        // RR = P * R = K: xx = fx x + 0 y + cx, ww = 1 / (0 x + 0 y + 1)
+        const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+        xy_out[2 * i] = (float)(xx * ww);
+        xy_out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+// Frame::UndistortKeyPoints (Frame.cc:529-559) + Frame::AssignFeaturesToGrid (:336-357): kps_un = kps with the
+// undistorted pt; mGrid[x][y] as CSR over cells x * 48 + y, indices in push_back (= keypoint) order.
+extern "C" int orb_oracle_frame_finish(const float* cam9, const slamit_kp* kps, int n, float minx, float miny, float invw, float invh,
+                                       slamit_kp* kps_un, int32_t* cell_start /*[64*48+1]*/, int32_t* cell_items /*[n]*/) {
+    std::vector<float> in(2 * (size_t)std::max(n, 1)), out(2 * (size_t)std::max(n, 1));
+    for (int i = 0; i < n; i++) { in[2 * i] = kps[i].x; in[2 * i + 1] = kps[i].y; }
+    if (cam9[4] == 0.0f) out = in;
+    else orb_oracle_undistort(cam9, in.data(), n, out.data());
+    for (int i = 0; i < n; i++) { kps_un[i] = kps[i]; kps_un[i].x = out[2 * i]; kps_un[i].y = out[2 * i + 1]; }
+    FrameGrid* g = new FrameGrid;
+    for (int i = 0; i < n; i++) {
+        int gx, gy;
+        if (pos_in_grid(kps_un[i].x, kps_un[i].y, minx, miny, invw, invh, gx, gy)) g->cell[gx][gy].push_back(i);
+    }
+    int m = 0;
+    for (int x = 0; x < kGridCols; x++)
+        for (int y = 0; y < kGridRows; y++) {
+            cell_start[x * kGridRows + y] = m;
+            for (size_t j = 0; j < g->cell[x][y].size(); j++) cell_items[m++] = g->cell[x][y][j];
+        }
+    cell_start[kGridCols * kGridRows] = m;
+    delete g;
+    return m;
+}

@@ -467,3 +467,57 @@ def test_guided_search_matches_model(seed, n, m, crowd):
         assert np.array_equal(got[2], exp[2])
     if n and m and not crowd:
         assert got[1] > m // 4
+
+
+# ---- Frame epilogue: undistort + grid -----------------------------------------------------------------
+
+CAM_REF = [526.69, 540.36, 313.07, 238.39, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314]   # Tracking.cc:77-101
+
+
+def test_undistort_inverts_the_brown_model():
+    """The restated cv::undistortPoints: distort(undistort(p)) == p to the accuracy 5 fixed-point iterations give."""
+    rs = np.random.RandomState(2)
+    xy = np.stack([rs.uniform(0, 640, 500), rs.uniform(0, 480, 500)], 1).astype(np.float32)
+    u = ob.undistort(CAM_REF, xy).astype(np.float64)
+    fx, fy, cx, cy, k1, k2, p1, p2, k3 = CAM_REF
+    x, y = (u[:, 0] - cx) / fx, (u[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    cd = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    back = np.stack([(x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)) * fx + cx, (y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y) * fy + cy], 1)
+    err = np.abs(back - xy).max(1)
+    centre = np.hypot(xy[:, 0] - cx, xy[:, 1] - cy) < 150
+    assert err[centre].max() < 1e-3 and err.max() < 0.05
+    # principal point is a fixed point; zero distortion is the identity up to float rounding
+    assert np.allclose(ob.undistort(CAM_REF, [[cx, cy]]), [[cx, cy]], atol=1e-4)
+    assert np.abs(ob.undistort(CAM_REF[:4] + [0, 0, 0, 0, 0], xy) - xy).max() < 1e-4
+
+
+def test_frame_finish_grid_is_the_reference_grid():
+    rs = np.random.RandomState(3)
+    n = 1200
+    kps = np.zeros(n, ob.KP_DTYPE)
+    kps["x"], kps["y"] = rs.uniform(16, 624, n).astype(np.float32), rs.uniform(16, 464, n).astype(np.float32)
+    kps["octave"], kps["angle"], kps["response"] = rs.randint(0, 8, n), rs.uniform(0, 360, n), rs.randint(7, 200, n)
+    kps["x"][:3], kps["y"][:3] = [640, 640, 0], [480, 0, 480]      # image corners: round() lands on column 64 / row 48
+    c = ob.undistort(CAM_REF, [[0, 0], [640, 0], [0, 480], [640, 480]])
+    min_x, max_x, min_y, max_y = min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0]), min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1])
+    inv_w, inv_h = np.float32(64) / np.float32(max_x - min_x), np.float32(48) / np.float32(max_y - min_y)
+    un, start, items = ob.frame_finish(CAM_REF, kps, min_x, min_y, inv_w, inv_h)
+    assert np.array_equal(np.stack([un["x"], un["y"]], 1), ob.undistort(CAM_REF, np.stack([kps["x"], kps["y"]], 1)))
+    for f in ("octave", "angle", "response", "size", "class_id"):
+        assert np.array_equal(un[f], kps[f])
+    # independent statement of AssignFeaturesToGrid
+    f32 = np.float32
+    v = (un["x"] - f32(min_x)) * f32(inv_w)
+    w = (un["y"] - f32(min_y)) * f32(inv_h)
+    gx = np.where(v >= 0, np.floor(v + f32(0.5)), np.ceil(v - f32(0.5))).astype(int)
+    gy = np.where(w >= 0, np.floor(w + f32(0.5)), np.ceil(w - f32(0.5))).astype(int)
+    ok = (gx >= 0) & (gx < 64) & (gy >= 0) & (gy < 48)
+    assert start[-1] == ok.sum() == len(items) and 0 < (~ok).sum() < n      # the corner keypoints fall off the grid
+    for cell in np.unique(gx[ok] * 48 + gy[ok])[::37]:
+        want = np.nonzero(ok & (gx * 48 + gy == cell))[0]
+        assert np.array_equal(items[start[cell]:start[cell + 1]], want)
+    assert (np.diff(start) >= 0).all()
+    # k1 == 0: keypoints pass through untouched (Frame.cc:531)
+    un0, _, _ = ob.frame_finish(CAM_REF[:4] + [0, 0.1, 0, 0, 0], kps, 0, 0, 0.1, 0.1)
+    assert np.array_equal(un0, kps)

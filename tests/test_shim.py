@@ -286,3 +286,35 @@ def test_shim_search_by_projection_last_frame(tmp_path):
                 nm -= 1
     assert r[1] == nm
     assert np.array_equal(r[2:], owner)
+
+
+@pytest.mark.gpu
+def test_shim_frame_ops(tmp_path):
+    """FrameOps::ComputeImageBounds + UndistortAndAssign on a mock Frame == the oracle's Frame epilogue."""
+    from oracle import bindings as ob
+
+    _build()
+    cam = [526.69, 540.36, 313.07, 238.39, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+    rs = np.random.RandomState(12)
+    n = 900
+    kps = np.zeros(n, ob.KP_DTYPE)
+    kps["x"], kps["y"] = rs.uniform(16, 624, n).astype(np.float32), rs.uniform(16, 464, n).astype(np.float32)
+    kps["octave"], kps["angle"], kps["size"] = rs.randint(0, 8, n), rs.uniform(0, 360, n), 31.0
+    kps["x"][:2], kps["y"][:2] = [640, 0], [480, 0]
+    pin, pout = tmp_path / "f.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(struct.pack("<iii", n, 640, 480) + np.asarray(cam, np.float32).tobytes() + kps.tobytes())
+    subprocess.check_call([EXE, "frame", str(pin), str(pout)])
+    raw = open(pout, "rb").read()
+    assert struct.unpack_from("<i", raw, 0)[0] == 0
+    b = np.frombuffer(raw, np.float32, 6, 4)
+    c = ob.undistort(cam, [[0, 0], [640, 0], [0, 480], [640, 480]])
+    want = [min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0]), min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1])]
+    assert np.array_equal(b[:4], np.asarray(want, np.float32))
+    assert b[4] == np.float32(64) / np.float32(b[1] - b[0]) and b[5] == np.float32(48) / np.float32(b[3] - b[2])
+    un = np.frombuffer(raw, ob.KP_DTYPE, n, 28)
+    ou, os_, oi = ob.frame_finish(cam, kps, b[0], b[2], b[4], b[5])
+    assert np.array_equal(un.view(np.uint8), ou.view(np.uint8))
+    counts = np.frombuffer(raw, np.int32, 64 * 48, 28 + 28 * n)
+    assert np.array_equal(counts, np.diff(os_))
+    items = np.frombuffer(raw, np.int32, int(counts.sum()), 28 + 28 * n + 4 * 64 * 48)
+    assert np.array_equal(items, oi)

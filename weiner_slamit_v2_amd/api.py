@@ -70,6 +70,11 @@ class SearchRule(C.Structure):
     _fields_ = [("th_dist", C.c_int32), ("use_ratio", C.c_int32), ("nnratio", C.c_float)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("k1", C.c_float),
+                ("k2", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("k3", C.c_float)]
+
+
 class PoseProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("pose", C.c_void_p), ("intr", C.c_void_p), ("xw", C.c_void_p),
                 ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p)]
@@ -86,7 +91,8 @@ EXPORTS = [
     "slamit_orb_create", "slamit_orb_destroy", "slamit_orb_tables", "slamit_orb_max_keypoints",
     "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
     "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
-    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
+    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_undistort_points", "slamit_frame_finish",
+    "slamit_frame_finish_batch_dev", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
     "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
 ]
 
@@ -126,6 +132,10 @@ def lib():
         L.slamit_distinctive_batch.argtypes = [vp, vp, i32, vp, vp]
         L.slamit_guided_search.argtypes = [i32, C.POINTER(FrameView), C.POINTER(SearchQueries), C.POINTER(SearchRule),
                                            vp, vp, vp, vp, vp, vp]
+        f32 = C.c_float
+        L.slamit_undistort_points.argtypes = [i32, C.POINTER(Camera), vp, i32, vp]
+        L.slamit_frame_finish.argtypes = [i32, C.POINTER(Camera), vp, i32, f32, f32, f32, f32, vp, vp, vp]
+        L.slamit_frame_finish_batch_dev.argtypes = [i32, C.POINTER(Camera), vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp]
         if hasattr(L, "slamit_ba_create"):
             L.slamit_ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
             L.slamit_ba_destroy.argtypes = [vp]
@@ -280,6 +290,56 @@ class ORBextractor:
         _check(lib().slamit_orb_debug_candidates(self._h, frame, level, _np_ptr(out), n.value, C.byref(n)),
                "debug_candidates")
         return out[:n.value]
+
+
+GRID_COLS, GRID_ROWS = 64, 48   # FRAME_GRID_COLS / FRAME_GRID_ROWS (include/Frame.h:40-41)
+
+
+class Frame:
+    """The part of ORB_SLAM2::Frame's constructor that follows the extractor (src/Frame.cc:84-117): image bounds,
+    UndistortKeyPoints, AssignFeaturesToGrid.  cam9 = fx fy cx cy k1 k2 p1 p2 k3."""
+
+    @staticmethod
+    def undistort_points(cam9, xy, device=0):
+        cam = Camera(*[float(v) for v in cam9])
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.zeros_like(xy)
+        _check(lib().slamit_undistort_points(device, C.byref(cam), _np_ptr(xy), len(xy), _np_ptr(out)), "slamit_undistort_points")
+        return out
+
+    @staticmethod
+    def ComputeImageBounds(cam9, cols, rows, device=0):
+        """(mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv), Frame.cc:561-590, :113-118."""
+        f32 = np.float32
+        if f32(cam9[4]) != 0:
+            m = Frame.undistort_points(cam9, [[0, 0], [cols, 0], [0, rows], [cols, rows]], device)
+            b = (min(m[0, 0], m[2, 0]), max(m[1, 0], m[3, 0]), min(m[0, 1], m[1, 1]), max(m[2, 1], m[3, 1]))
+        else:
+            b = (f32(0), f32(cols), f32(0), f32(rows))
+        b = tuple(f32(v) for v in b)
+        return b + (f32(GRID_COLS) / f32(b[1] - b[0]), f32(GRID_ROWS) / f32(b[3] - b[2]))
+
+    @staticmethod
+    def finish(cam9, kps, min_x, min_y, inv_w, inv_h, device=0):
+        """UndistortKeyPoints + AssignFeaturesToGrid: (mvKeysUn, cell_start[3073], cell_items)."""
+        cam = Camera(*[float(v) for v in cam9])
+        kps = np.ascontiguousarray(kps)
+        n = len(kps)
+        un = np.zeros(max(n, 1), KP_DTYPE)
+        start, items = np.zeros(GRID_COLS * GRID_ROWS + 1, np.int32), np.zeros(max(n, 1), np.int32)
+        _check(lib().slamit_frame_finish(device, C.byref(cam), _np_ptr(kps), n, float(min_x), float(min_y), float(inv_w),
+                                         float(inv_h), _np_ptr(un), _np_ptr(start), _np_ptr(items)), "slamit_frame_finish")
+        return un[:n], start, items[:start[-1]]
+
+    @staticmethod
+    def finish_batch_dev(cam9, d_kps, d_n, min_x, min_y, inv_w, inv_h, d_kps_un, d_cell_start, d_cell_items, device=0, stream=None):
+        """torch tensors in the extractor's layout: d_kps (B, cap, 7) float32 view of cv::KeyPoint records."""
+        cam = Camera(*[float(v) for v in cam9])
+        b, cap = d_kps.shape[0], d_kps.shape[1]
+        _check(lib().slamit_frame_finish_batch_dev(device, C.byref(cam), d_kps.data_ptr(), d_n.data_ptr(), cap, b, float(min_x),
+                                                   float(min_y), float(inv_w), float(inv_h), d_kps_un.data_ptr(),
+                                                   d_cell_start.data_ptr(), d_cell_items.data_ptr(), stream),
+               "slamit_frame_finish_batch_dev")
 
 
 class ORBmatcher:

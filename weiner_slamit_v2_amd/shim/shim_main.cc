@@ -6,6 +6,7 @@
 //     shim_test ba    <problem.bin> <out.bin>
 //     shim_test pose  <problem.bin> <out.bin>
 //     shim_test search <problem.bin> <out.bin>
+//     shim_test frame <problem.bin> <out.bin>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -19,6 +20,7 @@
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
 #include "Optimizer.h"
+#include "FrameOps.h"
 
 using namespace ORB_SLAM2;
 
@@ -369,6 +371,54 @@ static int run_search(int argc, char** argv) {
     return 0;
 }
 
+// ---- Frame epilogue: mock Frame with the members FrameOps.h documents -----------------------------------
+struct MockEpiFrame {
+    int N;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    cv::Mat mK, mDistCoef;
+    std::vector<std::size_t> mGrid[SLAMIT_FRAME_GRID_COLS][SLAMIT_FRAME_GRID_ROWS];
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+};
+float MockEpiFrame::mnMinX, MockEpiFrame::mnMaxX, MockEpiFrame::mnMinY, MockEpiFrame::mnMaxY;
+float MockEpiFrame::mfGridElementWidthInv, MockEpiFrame::mfGridElementHeightInv;
+
+// problem.bin: int32 n cols rows ; float cam[9] ; slamit_kp kps[n]
+// out.bin: int32 status ; float bounds[6] ; slamit_kp kps_un[n] ; int32 counts[64*48] ; int32 items[sum counts]
+static int run_frame(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<unsigned char> raw = slurp(argv[2]);
+    Reader R{raw.data()};
+    const int n = R.get<int>(), cols = R.get<int>(), rows = R.get<int>();
+    const float* cam = R.arr<float>(9);
+    const cv::KeyPoint* kps = R.arr<cv::KeyPoint>(n);
+    MockEpiFrame F;
+    F.N = n;
+    F.mvKeys.assign(kps, kps + n);
+    F.mK = cv::Mat::zeros(3, 3, CV_32F);
+    F.mK.at<float>(0, 0) = cam[0]; F.mK.at<float>(1, 1) = cam[1]; F.mK.at<float>(0, 2) = cam[2]; F.mK.at<float>(1, 2) = cam[3];
+    F.mK.at<float>(2, 2) = 1.f;
+    F.mDistCoef = cv::Mat(5, 1, CV_32F);
+    for (int i = 0; i < 5; ++i) F.mDistCoef.at<float>(i, 0) = cam[4 + i];
+    cv::Mat im(rows, cols, CV_8U);
+    FrameOps::ComputeImageBounds(F, im);
+    int status = FrameOps::LastStatus();
+    if (status == 0) { FrameOps::UndistortAndAssign(F); status = FrameOps::LastStatus(); }
+    if (status != 0) fprintf(stderr, "frame failed: %s\n", slamit_last_error());
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(&status, 4, 1, f);
+    const float b[6] = {MockEpiFrame::mnMinX, MockEpiFrame::mnMaxX, MockEpiFrame::mnMinY, MockEpiFrame::mnMaxY,
+                        MockEpiFrame::mfGridElementWidthInv, MockEpiFrame::mfGridElementHeightInv};
+    fwrite(b, 4, 6, f);
+    fwrite(F.mvKeysUn.data(), sizeof(cv::KeyPoint), F.mvKeysUn.size(), f);
+    for (int x = 0; x < SLAMIT_FRAME_GRID_COLS; ++x)
+        for (int y = 0; y < SLAMIT_FRAME_GRID_ROWS; ++y) { int c = (int)F.mGrid[x][y].size(); fwrite(&c, 4, 1, f); }
+    for (int x = 0; x < SLAMIT_FRAME_GRID_COLS; ++x)
+        for (int y = 0; y < SLAMIT_FRAME_GRID_ROWS; ++y)
+            for (size_t j = 0; j < F.mGrid[x][y].size(); ++j) { int v = (int)F.mGrid[x][y][j]; fwrite(&v, 4, 1, f); }
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
@@ -377,5 +427,6 @@ int main(int argc, char** argv) {
     if (mode == "ba") return run_ba(argc, argv);
     if (mode == "pose") return run_pose(argc, argv);
     if (mode == "search") return run_search(argc, argv);
+    if (mode == "frame") return run_frame(argc, argv);
     return 2;
 }
