@@ -971,28 +971,36 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
         off[j] = v * stride + u; wu[j] = u; wv[j] = v;
     }
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
-        const int i = i0 + k;
-        if (i >= count) break;
-        OrbLevelKp* kp = lkp + L.kp_off + (size_t)frame * kp_frame_stride + i;
-        const uint8_t* center = src + (size_t)kp->y * stride + kp->x;
-        int val[12];
+    // all the wave's keypoints at once: their 12 x IC_KP_PER_WAVE byte loads are in flight together, and the
+    // atan2 / sincos tail (~150 instructions) runs ONCE with keypoint k on lane k instead of once per keypoint on lane 0
+    OrbLevelKp* kp0 = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
+    int val[IC_KP_PER_WAVE][12];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) val[j] = center[off[j]];   // 12 independent loads in flight
+    for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
+        const int i = min(i0 + k, count - 1);
+        const uint8_t* center = src + ((unsigned)kp0[i].y * (unsigned)stride + (unsigned)kp0[i].x);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) val[k][j] = center[off[j]];
+    }
+    int my10 = 0, my01 = 0;
+#pragma unroll
+    for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
         int m10 = 0, m01 = 0;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) { m10 += wu[j] * val[j]; m01 += wv[j] * val[j]; }
+        for (int j = 0; j < 12; ++j) { m10 += wu[j] * val[k][j]; m01 += wv[j] * val[k][j]; }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             m10 += __shfl_xor(m10, d, WAVE);
             m01 += __shfl_xor(m01, d, WAVE);
         }
-        if (lane == 0) {
-            const float ang = slamit_fast_atan2((float)m01, (float)m10);
-            float sn, cs;
-            slamit_sincosf(ang * factorPI, &sn, &cs);   // a = cos, b = sin of computeOrbDescriptor, once per keypoint
-            kp->angle = ang; kp->cs = cs; kp->sn = sn;
-        }
+        if (lane == k) { my10 = m10; my01 = m01; }
+    }
+    if (lane < IC_KP_PER_WAVE && i0 + lane < count) {
+        const float ang = slamit_fast_atan2((float)my01, (float)my10);
+        float sn, cs;
+        slamit_sincosf(ang * factorPI, &sn, &cs);   // a = cos, b = sin of computeOrbDescriptor, once per keypoint
+        OrbLevelKp* kp = kp0 + i0 + lane;
+        kp->angle = ang; kp->cs = cs; kp->sn = sn;
     }
 }
 
