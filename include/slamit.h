@@ -228,6 +228,32 @@ int slamit_frame_finish_batch_dev(int device, const slamit_camera* cam, const sl
                                   int nframes, float min_x, float min_y, float inv_w, float inv_h, slamit_kp* d_kps_un,
                                   int32_t* d_cell_start, int32_t* d_cell_items, void* stream);
 
+/* The same for a batch of frames whose data is resident in HBM (one wavefront walks each frame's queries, all frames
+ * in parallel): keypoints in the layout slamit_frame_finish_batch_dev writes, everything else [nframes][cap] strided.
+ * A window may hold at most SLAMIT_SEARCH_BATCH_CAND keypoints; a frame that exceeds it reports d_nmatches = -1. */
+#define SLAMIT_SEARCH_BATCH_CAND 128
+typedef struct slamit_search_batch {
+    int32_t nframes, kp_cap, q_cap;
+    const int32_t* d_n;            /* [nframes] keypoints per frame */
+    const slamit_kp* d_kps_un;     /* [nframes][kp_cap] (pt and octave are read) */
+    const uint8_t* d_desc;         /* [nframes][kp_cap][32] */
+    const uint8_t* d_kp_taken;     /* [nframes][kp_cap] */
+    float min_x, min_y, inv_w, inv_h;
+    const int32_t* d_m;            /* [nframes] queries per frame */
+    const float* d_uvr;            /* [nframes][q_cap][3] */
+    const int32_t* d_level_min;    /* [nframes][q_cap] */
+    const int32_t* d_level_max;
+    const uint8_t* d_qdesc;        /* [nframes][q_cap][32] */
+    const uint8_t* d_valid;        /* [nframes][q_cap] */
+    const uint8_t* d_takes;        /* [nframes][q_cap] */
+} slamit_search_batch;
+size_t slamit_guided_search_workspace(int nframes, int q_cap);
+/* d_match_kp [nframes][q_cap], d_nmatches [nframes], d_out4 [nframes][q_cap][4] or NULL (best dist / level, second
+ * dist / level).  Asynchronous on `stream`. */
+int slamit_guided_search_batch_dev(int device, const slamit_search_batch* batch, const slamit_search_rule* rule,
+                                   int32_t* d_match_kp, int32_t* d_nmatches, int32_t* d_out4, void* d_workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* Full distance matrix (nq x nt, uint16), the batched form of DescriptorDistance. */
 int slamit_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out);
 

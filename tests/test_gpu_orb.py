@@ -308,3 +308,55 @@ def test_guided_search_on_extracted_frames():
     assert gn > 50
     won = gm[gm >= 0]
     assert len(np.unique(won)) == len(won)        # a keypoint is handed out once
+
+
+def _search_batch_tensors(problems, kp_cap, q_cap):
+    import torch
+
+    B = len(problems)
+    kps = np.zeros((B, kp_cap), api.KP_DTYPE)
+    t = dict(n=np.zeros(B, np.int32), desc=np.zeros((B, kp_cap, 32), np.uint8), kp_taken=np.zeros((B, kp_cap), np.uint8),
+             m=np.zeros(B, np.int32), uvr=np.zeros((B, q_cap, 3), np.float32), level_min=np.zeros((B, q_cap), np.int32),
+             level_max=np.zeros((B, q_cap), np.int32), qdesc=np.zeros((B, q_cap, 32), np.uint8), valid=np.zeros((B, q_cap), np.uint8),
+             takes=np.ones((B, q_cap), np.uint8))
+    for i, (f, q) in enumerate(problems):
+        n, m = len(f["kp_xy"]), len(q["uvr"])
+        t["n"][i], t["m"][i] = n, m
+        kps["x"][i, :n], kps["y"][i, :n], kps["octave"][i, :n] = f["kp_xy"][:, 0], f["kp_xy"][:, 1], f["kp_octave"]
+        t["desc"][i, :n], t["kp_taken"][i, :n] = f["desc"], f["kp_taken"]
+        t["uvr"][i, :m], t["level_min"][i, :m], t["level_max"][i, :m] = q["uvr"], q["level_min"], q["level_max"]
+        t["qdesc"][i, :m], t["valid"][i, :m], t["takes"][i, :m] = q["desc"], q["valid"], q["takes"]
+    d = {k: torch.from_numpy(v).cuda() for k, v in t.items()}
+    d["kps_un"] = torch.from_numpy(kps.view(np.float32).reshape(B, kp_cap, 7)).cuda()
+    d["match_kp"] = torch.full((B, q_cap), -7, dtype=torch.int32, device="cuda")
+    d["nmatches"] = torch.full((B,), -7, dtype=torch.int32, device="cuda")
+    d["out4"] = torch.zeros((B, q_cap, 4), dtype=torch.int32, device="cuda")
+    d["workspace"] = torch.zeros(api.ORBmatcher.guided_search_workspace(B, q_cap), dtype=torch.uint8, device="cuda")
+    return d
+
+
+def test_guided_search_batch_dev():
+    """Frames of different sizes in one launch (one wavefront resolves each frame), data resident on the device."""
+    import torch
+
+    shapes = [(1500, 600, False), (300, 900, True), (0, 10, False), (5, 0, False), (2500, 400, False), (1000, 1000, False)]
+    problems = [synth.synth_search(n, m, 40 + i, th=6.0 if crowd else 3.0, crowd=crowd) for i, (n, m, crowd) in enumerate(shapes)]
+    bounds = tuple(problems[0][0][k] for k in ("min_x", "min_y", "inv_w", "inv_h"))
+    d = _search_batch_tensors(problems, 2560, 1024)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for use_ratio, th in ((True, 100), (False, 100)):
+        api.ORBmatcher.guided_search_batch_dev(d, bounds, th, use_ratio, 0.8, stream=s.cuda_stream)
+        s.synchronize()
+        nm = d["nmatches"].cpu().numpy()
+        for i, (f, q) in enumerate(problems):
+            om, on, o4 = ob.guided_search(f, q, th, use_ratio, 0.8)
+            m = len(q["uvr"])
+            if i == 1:   # crowded windows: more than SLAMIT_SEARCH_BATCH_CAND candidates -> the frame reports -1
+                assert nm[i] == -1
+                continue
+            assert nm[i] == on
+            assert np.array_equal(d["match_kp"][i, :m].cpu().numpy(), om) and np.array_equal(d["out4"][i, :m].cpu().numpy(), o4)
+    with pytest.raises(api.SlamitError):   # workspace too small
+        d2 = dict(d, workspace=d["workspace"][:1024])
+        api.ORBmatcher.guided_search_batch_dev(d2, bounds)

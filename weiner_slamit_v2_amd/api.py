@@ -70,6 +70,14 @@ class SearchRule(C.Structure):
     _fields_ = [("th_dist", C.c_int32), ("use_ratio", C.c_int32), ("nnratio", C.c_float)]
 
 
+class SearchBatch(C.Structure):
+    _fields_ = [("nframes", C.c_int32), ("kp_cap", C.c_int32), ("q_cap", C.c_int32), ("d_n", C.c_void_p),
+                ("d_kps_un", C.c_void_p), ("d_desc", C.c_void_p), ("d_kp_taken", C.c_void_p), ("min_x", C.c_float),
+                ("min_y", C.c_float), ("inv_w", C.c_float), ("inv_h", C.c_float), ("d_m", C.c_void_p), ("d_uvr", C.c_void_p),
+                ("d_level_min", C.c_void_p), ("d_level_max", C.c_void_p), ("d_qdesc", C.c_void_p), ("d_valid", C.c_void_p),
+                ("d_takes", C.c_void_p)]
+
+
 class Camera(C.Structure):
     _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("k1", C.c_float),
                 ("k2", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("k3", C.c_float)]
@@ -91,7 +99,7 @@ EXPORTS = [
     "slamit_orb_create", "slamit_orb_destroy", "slamit_orb_tables", "slamit_orb_max_keypoints",
     "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
     "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
-    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_undistort_points", "slamit_frame_finish",
+    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_guided_search_workspace", "slamit_guided_search_batch_dev", "slamit_undistort_points", "slamit_frame_finish",
     "slamit_frame_finish_batch_dev", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
     "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
 ]
@@ -132,6 +140,9 @@ def lib():
         L.slamit_distinctive_batch.argtypes = [vp, vp, i32, vp, vp]
         L.slamit_guided_search.argtypes = [i32, C.POINTER(FrameView), C.POINTER(SearchQueries), C.POINTER(SearchRule),
                                            vp, vp, vp, vp, vp, vp]
+        L.slamit_guided_search_workspace.argtypes = [i32, i32]
+        L.slamit_guided_search_workspace.restype = sz
+        L.slamit_guided_search_batch_dev.argtypes = [i32, C.POINTER(SearchBatch), C.POINTER(SearchRule), vp, vp, vp, vp, sz, vp]
         f32 = C.c_float
         L.slamit_undistort_points.argtypes = [i32, C.POINTER(Camera), vp, i32, vp]
         L.slamit_frame_finish.argtypes = [i32, C.POINTER(Camera), vp, i32, f32, f32, f32, f32, vp, vp, vp]
@@ -421,6 +432,27 @@ class ORBmatcher:
                                           _np_ptr(out4[0]), _np_ptr(out4[1]), _np_ptr(out4[2]), _np_ptr(out4[3])),
                "slamit_guided_search")
         return match[:m], nm.value, out4[:, :m].T.copy()
+
+    @staticmethod
+    def guided_search_batch_dev(t, bounds, th_dist=100, use_ratio=True, nnratio=0.8, device=0, stream=None):
+        """Batched device form.  t: dict of torch CUDA tensors n (B) i32, kps_un (B, kp_cap, 7) f32 view of cv::KeyPoint,
+        desc (B, kp_cap, 32) u8, kp_taken (B, kp_cap) u8, m (B) i32, uvr (B, q_cap, 3) f32, level_min / level_max
+        (B, q_cap) i32, qdesc (B, q_cap, 32) u8, valid / takes (B, q_cap) u8, match_kp (B, q_cap) i32, nmatches (B) i32,
+        out4 (B, q_cap, 4) i32 or None, workspace (bytes,) u8.  bounds = (min_x, min_y, inv_w, inv_h)."""
+        b, kp_cap, q_cap = t["kps_un"].shape[0], t["kps_un"].shape[1], t["uvr"].shape[1]
+        sb = SearchBatch(b, kp_cap, q_cap, t["n"].data_ptr(), t["kps_un"].data_ptr(), t["desc"].data_ptr(), t["kp_taken"].data_ptr(),
+                         float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), t["m"].data_ptr(), t["uvr"].data_ptr(),
+                         t["level_min"].data_ptr(), t["level_max"].data_ptr(), t["qdesc"].data_ptr(), t["valid"].data_ptr(),
+                         t["takes"].data_ptr())
+        rule = SearchRule(int(th_dist), int(bool(use_ratio)), float(nnratio))
+        out4 = t.get("out4")
+        _check(lib().slamit_guided_search_batch_dev(device, C.byref(sb), C.byref(rule), t["match_kp"].data_ptr(), t["nmatches"].data_ptr(),
+                                                    out4.data_ptr() if out4 is not None else None, t["workspace"].data_ptr(),
+                                                    t["workspace"].numel(), stream), "slamit_guided_search_batch_dev")
+
+    @staticmethod
+    def guided_search_workspace(nframes, q_cap):
+        return int(lib().slamit_guided_search_workspace(nframes, q_cap))
 
     def match(self, q, t, th=None):
         """All-pairs match with the reference's acceptance rule: best <= th and best < nnratio*second
