@@ -301,11 +301,11 @@ def main():
             "stage_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in all_stages.items()},
             "match_ms_per_step": round(match_ms, 4),
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # CPU comparators: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(fa, fb, NFEAT)
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(fa, fb, NFEAT)
-        if not args.no_ba:
+        if not args.no_ba and world == 1:
             out["secondary"] = ba_secondary(dev.index, args.steps, with_cpu=not args.no_cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
