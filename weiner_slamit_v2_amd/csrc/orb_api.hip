@@ -36,7 +36,6 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, unsigned long long* cand,
                size_t cand_frame_stride, int* cand_count, int iniTh, int minTh, int max_wcell, int max_hcell, int nframes);
 size_t orbk_octree_smem(int node_cap);
-size_t orbk_octree_static_smem();
 hipError_t orbk_octree_prepare(int node_cap);
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
                  size_t cand_frame_stride, const int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
@@ -252,7 +251,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         h->levels[l].plane_bytes = h->pyr_frame_total;   // stride between frames of the same level
         h->levels[l].blur_bytes = h->blur_frame_total;
     }
-    if (orbk_octree_smem(h->node_cap) + orbk_octree_static_smem() > 160 * 1024 - 1024) {
+    if (orbk_octree_smem(h->node_cap) > 160 * 1024 - 1024) {
         orb_free(h);
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: nfeatures too large for the LDS octree");
     }

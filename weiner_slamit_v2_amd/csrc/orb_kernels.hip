@@ -647,9 +647,12 @@ extern "C" int slamit_diag_oct(unsigned long long* out) { return (int)hipMemcpyF
 #ifndef OCT_THREADS
 #define OCT_THREADS 512
 #endif
-#ifndef OCT_LDS_KEYS
-#define OCT_LDS_KEYS 10240   // candidates of one (frame, level) that fit the LDS key arrays (6 bytes each); more -> HBM workspace
-#endif
+__host__ __device__ inline size_t orbk_octree_node_bytes(int node_cap) {
+    return ((size_t)node_cap * (8 + 2 * 8 + 2 * 4 + 4 * 4 + 5 * 4 + 4 + 4) + 64 + 15) & ~(size_t)15;
+}
+#define OCT_LDS_KEYS_MAX 10240   // LDS key arrays hold at most this many candidates of one (frame, level), 6 bytes each
+#define OCT_LDS_KEYS_MIN 2048
+#define OCT_LDS_BUDGET (78 * 1024)   // per workgroup, so that two fit a CU
 
 // XY / ND: per-candidate position and current node, in LDS when the list fits (LK) and in the HBM workspace otherwise.
 template <int NT, bool LK>
@@ -902,12 +905,12 @@ __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
     const int* __restrict__ cand_count,
     uint32_t* __restrict__ ws_xy, uint16_t* __restrict__ ws_node,
     OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, int* __restrict__ kp_count,
-    int node_cap, int level_override /* -1: blockIdx.x */) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int node_cap, int key_cap, int level_override /* -1: blockIdx.x */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // node arrays | k_xy[key_cap] | k_nd[key_cap]
     __shared__ int wave_tmp[OCT_THREADS / 64];
     __shared__ int s_vars[4];
-    __shared__ uint32_t k_xy[OCT_LDS_KEYS];
-    __shared__ uint16_t k_nd[OCT_LDS_KEYS];
+    uint32_t* k_xy = reinterpret_cast<uint32_t*>(smem + orbk_octree_node_bytes(node_cap));
+    uint16_t* k_nd = reinterpret_cast<uint16_t*>(k_xy + key_cap);
     const int level = level_override >= 0 ? level_override : blockIdx.x;
     const int frame = blockIdx.y;
     const OrbLevel& L = levels[level];
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
         if (threadIdx.x == 0) kp_count[kidx] = 0;
         return;
     }
-    if (n_keys <= OCT_LDS_KEYS)
+    if (n_keys <= key_cap)
         octree_body<OCT_THREADS, true>(L, K, n_keys, k_xy, k_nd, OUT, &kp_count[kidx], smem, node_cap, wave_tmp, s_vars);
     else
         octree_body<OCT_THREADS, false>(L, K, n_keys, ws_xy + L.cand_off + (size_t)frame * cand_frame_stride,
@@ -1378,10 +1381,12 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
                            sc_rows, kp_cap);
 }
 
-size_t orbk_octree_smem(int node_cap) {   // dynamic part (node arrays); the kernel adds 6 * OCT_LDS_KEYS bytes of static LDS
-    return (size_t)node_cap * (8 + 2 * 8 + 2 * 4 + 4 * 4 + 5 * 4 + 4 + 4) + 64;
+// candidates kept in LDS: as many as fit beside the node arrays in half a CU's LDS (lists above that use the HBM workspace)
+int orbk_octree_key_cap(int node_cap) {
+    const long room = (long)OCT_LDS_BUDGET - (long)orbk_octree_node_bytes(node_cap);
+    return (int)std::min<long>(OCT_LDS_KEYS_MAX, std::max<long>(OCT_LDS_KEYS_MIN, room / 6)) & ~7;
 }
-size_t orbk_octree_static_smem() { return (size_t)OCT_LDS_KEYS * 6 + 256; }
+size_t orbk_octree_smem(int node_cap) { return orbk_octree_node_bytes(node_cap) + (size_t)orbk_octree_key_cap(node_cap) * 6; }
 
 hipError_t orbk_octree_prepare(int node_cap) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel),
@@ -1395,7 +1400,7 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
     dim3 grid(level_override >= 0 ? 1 : nlevels, nframes);
     hipLaunchKernelGGL(octree_kernel, grid, dim3(OCT_THREADS), orbk_octree_smem(node_cap), st, levels, nlevels, cand,
                        cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
-                       level_override);
+                       orbk_octree_key_cap(node_cap), level_override);
 }
 
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0,
