@@ -243,28 +243,42 @@ extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, cons
     if (F->n > SLAMIT_SEARCH_MAX_KP) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_guided_search: more than SLAMIT_SEARCH_MAX_KP keypoints");
     HIP_TRY(hipSetDevice(device));
     const int n = F->n, m = Q->m, cap = std::min(std::max(n, 1), SLAMIT_SEARCH_MAX_CAND);
-    // keypoints as {x, y, octave} records
-    std::vector<uint32_t> rec(3 * (size_t)std::max(n, 1));
-    for (int i = 0; i < n; ++i) {
-        memcpy(&rec[3 * (size_t)i], &F->kp_xy[2 * i], 8);
-        rec[3 * (size_t)i + 2] = (uint32_t)F->kp_octave[i];
-    }
-    // one slab: keypoints | queries | candidate lists | outputs
+    // One pinned staging block and one device slab per host thread, kept between calls (a Tracking thread makes this
+    // call every frame: a fresh hipMalloc + nine pageable copies cost more than the search itself).  Layout of both:
+    // inputs (keypoint records | descriptors | taken | queries ...) first, then outputs; the candidate lists and
+    // tentative pairs live only on the device.
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_kp = take(12 * (size_t)n), o_kd = take(32 * (size_t)n), o_tk = take((size_t)n);
     const size_t o_uvr = take(12 * (size_t)m), o_l0 = take(4 * (size_t)m), o_l1 = take(4 * (size_t)m), o_qd = take(32 * (size_t)m), o_va = take((size_t)m), o_tq = take((size_t)m);
-    const size_t o_cand = take(8 * (size_t)m * cap), o_cn = take(4 * (size_t)m), o_te = take(16 * (size_t)m), o_mk = take(4 * (size_t)m), o_o4 = take(16 * (size_t)m), o_nm = take(4);
-    uint8_t* d = nullptr;
-    hipError_t e = hipMalloc((void**)&d, off);
-#define UP(o, src, bytes) if (e == hipSuccess && (bytes)) e = hipMemcpy(d + (o), (src), (bytes), hipMemcpyHostToDevice)
-    UP(o_kp, rec.data(), 12 * (size_t)n); UP(o_kd, F->desc, 32 * (size_t)n); UP(o_tk, F->kp_taken, (size_t)n);
-    UP(o_uvr, Q->uvr, 12 * (size_t)m); UP(o_l0, Q->level_min, 4 * (size_t)m); UP(o_l1, Q->level_max, 4 * (size_t)m);
-    UP(o_qd, Q->desc, 32 * (size_t)m); UP(o_va, Q->valid, (size_t)m);
-    if (Q->takes) { UP(o_tq, Q->takes, (size_t)m); } else if (e == hipSuccess) e = hipMemset(d + o_tq, 1, (size_t)m);
-#undef UP
-    std::vector<int> mk(m), o4(4 * (size_t)m);
-    int nm = 0;
+    const size_t in_bytes = off;
+    const size_t o_mk = take(4 * (size_t)m), o_o4 = take(16 * (size_t)m), o_nm = take(4);
+    const size_t io_bytes = off;
+    const size_t o_cand = take(8 * (size_t)m * cap), o_cn = take(4 * (size_t)m), o_te = take(16 * (size_t)m);
+    struct Scratch { int device; uint8_t* host; size_t host_bytes; uint8_t* dev; size_t dev_bytes; hipStream_t st; };
+    static thread_local Scratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    if (S.device != device || S.host_bytes < io_bytes || S.dev_bytes < off) {
+        if (S.st) hipStreamSynchronize(S.st);
+        if (S.host) hipHostFree(S.host);
+        if (S.dev) hipFree(S.dev);
+        S.host = nullptr; S.dev = nullptr; S.host_bytes = S.dev_bytes = 0; S.device = device;
+        if (!S.st) HIP_TRY(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void**)&S.host, io_bytes + io_bytes / 2, hipHostMallocDefault));
+        S.host_bytes = io_bytes + io_bytes / 2;
+        HIP_TRY(hipMalloc((void**)&S.dev, off + off / 2));
+        S.dev_bytes = off + off / 2;
+    }
+    uint8_t* hb = S.host;
+    uint8_t* d = S.dev;
+    for (int i = 0; i < n; ++i) {   // keypoints as {x, y, octave} records
+        memcpy(hb + o_kp + 12 * (size_t)i, &F->kp_xy[2 * i], 8);
+        memcpy(hb + o_kp + 12 * (size_t)i + 8, &F->kp_octave[i], 4);
+    }
+    memcpy(hb + o_kd, F->desc, 32 * (size_t)n); memcpy(hb + o_tk, F->kp_taken, (size_t)n);
+    memcpy(hb + o_uvr, Q->uvr, 12 * (size_t)m); memcpy(hb + o_l0, Q->level_min, 4 * (size_t)m); memcpy(hb + o_l1, Q->level_max, 4 * (size_t)m);
+    memcpy(hb + o_qd, Q->desc, 32 * (size_t)m); memcpy(hb + o_va, Q->valid, (size_t)m);
+    if (Q->takes) memcpy(hb + o_tq, Q->takes, (size_t)m); else memset(hb + o_tq, 1, (size_t)m);
+    hipError_t e = hipMemcpyAsync(d, hb, in_bytes, hipMemcpyHostToDevice, S.st);
     if (e == hipSuccess) {
         SearchDev D;
         D.nframes = 1; D.kp_cap = std::max(n, 1); D.q_cap = m; D.cand_cap = cap;
@@ -275,17 +289,18 @@ extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, cons
         D.cand = (unsigned long long*)(d + o_cand); D.cand_n = (int*)(d + o_cn); D.tent = (unsigned long long*)(d + o_te);
         D.th_dist = rule->th_dist; D.use_ratio = rule->use_ratio; D.nnratio = rule->nnratio;
         D.match_kp = (int*)(d + o_mk); D.out4 = (int*)(d + o_o4); D.nmatches = (int*)(d + o_nm);
-        search_launch(0, D, m);
+        search_launch(S.st, D, m);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(mk.data(), d + o_mk, 4 * (size_t)m, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(o4.data(), d + o_o4, 16 * (size_t)m, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(&nm, d + o_nm, 4, hipMemcpyDeviceToHost);
-    hipFree(d);
+    if (e == hipSuccess) e = hipMemcpyAsync(hb + in_bytes, d + in_bytes, io_bytes - in_bytes, hipMemcpyDeviceToHost, S.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S.st);
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_guided_search");
+    int nm = 0;
+    memcpy(&nm, hb + o_nm, 4);
     if (nm < 0) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_guided_search: a window holds more than SLAMIT_SEARCH_MAX_CAND keypoints");
-    memcpy(match_kp, mk.data(), 4 * (size_t)m);
+    memcpy(match_kp, hb + o_mk, 4 * (size_t)m);
     *nmatches = nm;
+    const int* o4 = reinterpret_cast<const int*>(hb + o_o4);
     for (int q = 0; q < m; ++q) {
         if (best_dist) best_dist[q] = o4[4 * (size_t)q];
         if (best_level) best_level[q] = o4[4 * (size_t)q + 1];
