@@ -179,9 +179,13 @@ typedef struct slamit_search_queries {
 } slamit_search_queries;
 
 typedef struct slamit_search_rule {
-    int32_t th_dist;           /* accept iff bestDist <= th_dist (TH_HIGH = 100) */
+    int32_t th_dist;           /* accept iff bestDist <= th_dist (TH_HIGH = 100, TH_LOW = 50) */
     int32_t use_ratio;         /* 1: also reject when bestLevel == bestLevel2 && bestDist > nnratio * bestDist2 */
     float nnratio;
+    /* ORBmatcher::Fuse's per-candidate gate (src/ORBmatcher.cc:925-936): with e2 = (u - kp.x)^2 + (v - kp.y)^2 a
+     * candidate is skipped when e2 * inv_level_sigma2[kp.octave] > chi2_gate (5.99).  chi2_gate <= 0: no gate. */
+    float chi2_gate;
+    float inv_level_sigma2[16];
 } slamit_search_rule;
 
 /* match_kp[q] = index of the keypoint the query took, or -1; *nmatches = number of accepted queries.

@@ -69,7 +69,7 @@ def orb_lib():
         L.orb_oracle_distinctive.argtypes = [_u8p, _i32p, C.c_int, _i32p, _i32p]
         L.orb_oracle_guided_search.argtypes = [C.c_int, _f32p, _i32p, _u8p, _u8p, C.c_float, C.c_float, C.c_float, C.c_float,
                                                C.c_int, _f32p, _i32p, _i32p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_float,
-                                               _i32p, _i32p]
+                                               C.c_float, _f32p, _i32p, _i32p]
         L.orb_oracle_undistort.argtypes = [_f32p, _f32p, C.c_int, _f32p]
         L.orb_oracle_frame_finish.argtypes = [_f32p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                               _i32p, _i32p]
@@ -223,7 +223,7 @@ def distinctive(desc, offsets):
     return idx[:n], med[:n]
 
 
-def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8):
+def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8, chi2_gate=0.0, inv_level_sigma2=None):
     """Frame grid + GetFeaturesInArea + the SearchByProjection loop (see weiner_slamit_v2_amd.api.guided_search
     for the dict layouts).  Returns (match_kp, nmatches, out4[m,4] = best dist/level, second dist/level)."""
     f, q = normalize_search(frame, queries)
@@ -234,8 +234,17 @@ def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8):
         n, _ptr(f["kp_xy"], _f32p), _ptr(f["kp_octave"], _i32p), _ptr(f["desc"]), _ptr(f["kp_taken"]),
         f["min_x"], f["min_y"], f["inv_w"], f["inv_h"], m, _ptr(q["uvr"], _f32p), _ptr(q["level_min"], _i32p),
         _ptr(q["level_max"], _i32p), _ptr(q["desc"]), _ptr(q["valid"]), _ptr(q["takes"]), int(th_dist), int(bool(use_ratio)),
-        float(np.float32(nnratio)), _ptr(match, _i32p), _ptr(out4, _i32p))
+        float(np.float32(nnratio)), float(np.float32(chi2_gate)), _ptr(_sig16(inv_level_sigma2), _f32p), _ptr(match, _i32p),
+        _ptr(out4, _i32p))
     return match[:m], nm, out4[:m]
+
+
+def _sig16(v):
+    out = np.ones(16, np.float32)
+    if v is not None:
+        v = np.asarray(v, np.float32)
+        out[:len(v)] = v[:16]
+    return out
 
 
 def normalize_search(frame, queries):

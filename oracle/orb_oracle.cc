@@ -880,7 +880,7 @@ extern "C" int orb_oracle_guided_search(int n, const float* kp_xy, const int32_t
                                         const uint8_t* kp_taken, float minx, float miny, float invw, float invh, int m,
                                         const float* uvr, const int32_t* lmin, const int32_t* lmax, const uint8_t* qdesc,
                                         const uint8_t* valid, const uint8_t* takes, int th_dist, int use_ratio, float nnratio,
-                                        int32_t* match_kp, int32_t* out4) {
+                                        float chi2_gate, const float* inv_level_sigma2, int32_t* match_kp, int32_t* out4) {
     FrameGrid* g = new FrameGrid;
     for (int i = 0; i < n; i++) {
         int gx, gy;
@@ -899,6 +899,11 @@ extern "C" int orb_oracle_guided_search(int n, const float* kp_xy, const int32_t
         for (size_t j = 0; j < vIndices.size(); j++) {
             const int idx = vIndices[j];
             if (has_mp[idx]) continue;
+            if (chi2_gate > 0.f) {   // ORBmatcher::Fuse (ORBmatcher.cc:925-936, mono branch): reprojection gate per candidate
+                const float ex = uvr[3 * q] - kp_xy[2 * idx], ey = uvr[3 * q + 1] - kp_xy[2 * idx + 1];
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[kp_octave[idx] & 15] > chi2_gate) continue;
+            }
             const int dist = descriptor_distance(qdesc + 32 * (size_t)q, kp_desc + 32 * (size_t)idx);
             if (dist < bestDist) {
                 bestDist2 = bestDist; bestDist = dist;

@@ -360,3 +360,13 @@ def test_guided_search_batch_dev():
     with pytest.raises(api.SlamitError):   # workspace too small
         d2 = dict(d, workspace=d["workspace"][:1024])
         api.ORBmatcher.guided_search_batch_dev(d2, bounds)
+
+
+def test_guided_search_fuse_gate():
+    frame, queries = synth.synth_search(1500, 800, 9, th=3.0)
+    frame = dict(frame, kp_taken=np.zeros(1500, np.uint8))
+    queries = dict(queries, takes=np.zeros(800, np.uint8))
+    sig = (1.0 / (np.float32(1.2) ** np.arange(16, dtype=np.float32)) ** 2).astype(np.float32)
+    gm, gn, g4 = api.ORBmatcher.guided_search(frame, queries, 50, False, 0.6, chi2_gate=5.99, inv_level_sigma2=sig)
+    om, on, o4 = ob.guided_search(frame, queries, 50, False, 0.6, 5.99, sig)
+    assert np.array_equal(gm, om) and gn == on and np.array_equal(g4, o4) and gn > 0

@@ -378,7 +378,7 @@ def test_distinctive_descriptor_definition():
 
 # ---- guided search (Frame grid + GetFeaturesInArea + SearchByProjection loop) ---------------------
 
-def _search_model(frame, queries, th_dist, use_ratio, nnratio):
+def _search_model(frame, queries, th_dist, use_ratio, nnratio, chi2_gate=0.0, inv_sigma2=None):
     """Independent numpy statement of the loop: candidates in cell-major (x, then y) order, inside a
     cell by keypoint index; strict '<' best/second; taken marks carried forward."""
     f, q = ob.normalize_search(frame, queries)
@@ -407,6 +407,10 @@ def _search_model(frame, queries, th_dist, use_ratio, nnratio):
         if hi >= 0:
             ok &= octv <= hi
         ok &= (np.abs(xy[:, 0] - x) < r) & (np.abs(xy[:, 1] - y) < r)
+        if chi2_gate > 0:   # ORBmatcher::Fuse's reprojection gate
+            ex, ey = x - xy[:, 0], y - xy[:, 1]
+            e2 = ex * ex + ey * ey
+            ok &= ~(e2 * np.asarray(inv_sigma2, np.float32)[octv & 15] > f32(chi2_gate))
         cand = np.nonzero(ok)[0]
         if len(cand) == 0:
             continue
@@ -521,3 +525,18 @@ def test_frame_finish_grid_is_the_reference_grid():
     # k1 == 0: keypoints pass through untouched (Frame.cc:531)
     un0, _, _ = ob.frame_finish(CAM_REF[:4] + [0, 0.1, 0, 0, 0], kps, 0, 0, 0.1, 0.1)
     assert np.array_equal(un0, kps)
+
+
+def test_guided_search_with_fuse_gate_matches_model():
+    """ORBmatcher::Fuse's candidate loop: level window, chi2 5.99 reprojection gate, best only, TH_LOW, nothing taken."""
+    frame, queries = synth.synth_search(1500, 800, 9, th=3.0)
+    frame = dict(frame, kp_taken=np.zeros(1500, np.uint8))
+    queries = dict(queries, takes=np.zeros(800, np.uint8))
+    sig = (1.0 / (np.float32(1.2) ** np.arange(16, dtype=np.float32)) ** 2).astype(np.float32)
+    got = ob.guided_search(frame, queries, 50, False, 0.6, 5.99, sig)
+    exp = _search_model(frame, queries, 50, False, 0.6, 5.99, sig)
+    assert np.array_equal(got[0], exp[0]) and got[1] == exp[1] and np.array_equal(got[2], exp[2])
+    nogate = ob.guided_search(frame, queries, 50, False, 0.6)
+    assert 0 < got[1] < nogate[1]            # the gate removes matches that the plain window would accept
+    won = got[0][got[0] >= 0]
+    assert len(np.unique(won)) < len(won)    # nothing is taken: several map points may pick one keypoint

@@ -318,3 +318,108 @@ def test_shim_frame_ops(tmp_path):
     assert np.array_equal(counts, np.diff(os_))
     items = np.frombuffer(raw, np.int32, int(counts.sum()), 28 + 28 * n + 4 * 64 * 48)
     assert np.array_equal(items, oi)
+
+
+@pytest.mark.gpu
+def test_shim_fuse(tmp_path):
+    """ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th) through the template + mock types: projection and checks on the
+    host, the gated window search on the device, Replace / AddObservation bookkeeping in order."""
+    from oracle import bindings as ob
+    from weiner_slamit_v2_amd import synth
+
+    _build()
+    f32 = np.float32
+    rs = np.random.RandomState(21)
+    n, m, th = 1400, 900, 3.0
+    frame, _ = synth.synth_search(n, 4, 33)
+    scale = (f32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    invsig = (f32(1) / (scale * scale)).astype(np.float32)
+    fx, fy, cx, cy = f32(526.69), f32(540.36), f32(313.07), f32(238.39)
+    Rc, tc = synth.se3_exp(np.array([0.02, -0.01, 0.03, 0.1, -0.05, 0.02]))
+    Rc, tc = Rc.astype(np.float32), tc.astype(np.float32)
+    Ow = (-(Rc.astype(np.float64).T @ tc.astype(np.float64))).astype(np.float32)
+    src = rs.randint(0, n, m)
+    depth = rs.uniform(2, 8, m)
+    px = frame["kp_xy"][src].astype(np.float64) + rs.normal(0, 1.2, (m, 2))
+    pc = np.stack([(px[:, 0] - cx) / fx * depth, (px[:, 1] - cy) / fy * depth, depth], 1)
+    pc[::40] *= -1                                   # behind the camera
+    pos = ((pc - tc.astype(np.float64)) @ Rc.astype(np.float64)).astype(np.float32)
+    PO = pos.astype(np.float32) - Ow
+    d3 = np.sqrt((PO.astype(np.float64) ** 2).sum(1)).astype(np.float32)
+    normal = (PO / np.maximum(d3[:, None], 1e-6)).astype(np.float32)
+    normal[::17] *= -1                               # viewing angle check fails
+    maxd, mind = (d3 * f32(1.5)).astype(np.float32), (d3 * f32(0.6)).astype(np.float32)
+    mind[::23] = d3[::23] * f32(1.2)                 # outside the scale-invariance range
+    level = np.clip(frame["kp_octave"][src] + rs.randint(0, 2, m), 0, 7).astype(np.int32)
+    nobs = rs.randint(1, 6, m).astype(np.int32)
+    bad = (rs.rand(m) < 0.05).astype(np.int32)
+    inkf = (rs.rand(m) < 0.05).astype(np.int32)
+    isnull = (rs.rand(m) < 0.03).astype(np.int32)
+    kf_state = np.where(rs.rand(n) < 0.4, rs.randint(1, 7, n), 0).astype(np.int32)   # k-1 observations of the KF's own point
+    qdesc = frame["desc"][src].copy()
+    flip = rs.randint(0, 256, (m, 30))
+    for j in range(m):
+        for b in flip[j, :rs.randint(0, 30)]:
+            qdesc[j, b >> 3] ^= np.uint8(1 << (b & 7))
+    bounds = np.array([frame["min_x"], 645.1, frame["min_y"], 483.9, frame["inv_w"], frame["inv_h"]], np.float32)
+    blob = struct.pack("<iif", n, m, th) + Rc.tobytes() + tc.tobytes() + Ow.tobytes() + np.array([fx, fy, cx, cy], np.float32).tobytes()
+    blob += bounds.tobytes() + scale.tobytes() + invsig.tobytes()
+    blob += frame["kp_xy"].astype(np.float32).tobytes() + frame["kp_octave"].astype(np.int32).tobytes() + kf_state.tobytes() + frame["desc"].tobytes()
+    blob += pos.tobytes() + normal.tobytes() + maxd.tobytes() + mind.tobytes() + level.tobytes() + nobs.tobytes() + bad.tobytes()
+    blob += inkf.tobytes() + isnull.tobytes() + qdesc.tobytes()
+    pin, pout = tmp_path / "f.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "fuse", str(pin), str(pout)])
+    r = np.fromfile(pout, np.int32)
+    assert r[0] == 0
+    # expected: the reference's float arithmetic step by step (ORBmatcher.cc:851-895)
+    X, Y, Z = pos[:, 0], pos[:, 1], pos[:, 2]
+    xc = ((Rc[0, 0] * X + Rc[0, 1] * Y) + Rc[0, 2] * Z) + tc[0]
+    yc = ((Rc[1, 0] * X + Rc[1, 1] * Y) + Rc[1, 2] * Z) + tc[1]
+    zc = ((Rc[2, 0] * X + Rc[2, 1] * Y) + Rc[2, 2] * Z) + tc[2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        invz = f32(1) / zc
+    u, v = fx * (xc * invz) + cx, fy * (yc * invz) + cy
+    PO = np.stack([X - Ow[0], Y - Ow[1], Z - Ow[2]], 1)
+    dist3D = np.sqrt((PO.astype(np.float64) ** 2).sum(1)).astype(np.float32)
+    dot = (PO.astype(np.float64) * normal.astype(np.float64)).sum(1)
+    ok = (isnull == 0) & (bad == 0) & (inkf == 0) & ~(zc < 0) & (u >= bounds[0]) & (u < bounds[1]) & (v >= bounds[2]) & (v < bounds[3])
+    ok &= ~((dist3D < mind) | (dist3D > maxd)) & ~(dot < 0.5 * dist3D.astype(np.float64))
+    keep = np.nonzero(ok)[0]
+    assert 200 < len(keep) < m
+    q = dict(uvr=np.stack([u, v, f32(th) * scale[level]], 1)[keep], level_min=level[keep] - 1, level_max=level[keep], desc=qdesc[keep],
+             takes=np.zeros(len(keep), np.uint8))
+    match, _, _ = ob.guided_search(dict(frame, kp_taken=np.zeros(n, np.uint8)), q, 50, False, 0.6, 5.99, invsig)
+    # the bookkeeping of ORBmatcher.cc:955-976, in order
+    owner = np.where(kf_state > 0, -2, -1).astype(np.int64)
+    own_obs = kf_state - 1
+    own_bad = np.zeros(n, bool)
+    p_bad, p_inkf, p_nobs = bad.astype(bool).copy(), inkf.astype(bool).copy(), nobs.copy()
+    added, replaced, own_replaced = np.full(m, -1), np.full(m, -1), np.full(n, -1)
+    nfused = 0
+    for k, j in enumerate(keep):
+        bi = match[k]
+        if bi < 0 or p_bad[j] or p_inkf[j]:
+            continue
+        if owner[bi] == -2:                      # the keyframe's own point sits there
+            if not own_bad[bi]:
+                if own_obs[bi] > p_nobs[j]:
+                    replaced[j], p_bad[j] = -2, True
+                else:
+                    own_replaced[bi], own_bad[bi] = j, True
+        elif owner[bi] >= 0:                     # a map point added earlier in this call
+            o = owner[bi]
+            if not p_bad[o]:
+                if p_nobs[o] > p_nobs[j]:
+                    replaced[j], p_bad[j] = o, True
+                else:
+                    replaced[o], p_bad[o] = j, True
+        else:
+            added[j], p_inkf[j], owner[bi] = bi, True, j
+            p_nobs[j] += 1
+        nfused += 1
+    assert r[1] == nfused and nfused > 100
+    per = r[2:2 + 3 * m].reshape(m, 3)
+    assert np.array_equal(per[:, 0], added) and np.array_equal(per[:, 1], replaced) and np.array_equal(per[:, 2], p_bad.astype(np.int32))
+    assert np.array_equal(r[2 + 3 * m:2 + 3 * m + n], owner)
+    assert np.array_equal(r[2 + 3 * m + n:], own_replaced)

@@ -67,7 +67,16 @@ class SearchQueries(C.Structure):
 
 
 class SearchRule(C.Structure):
-    _fields_ = [("th_dist", C.c_int32), ("use_ratio", C.c_int32), ("nnratio", C.c_float)]
+    _fields_ = [("th_dist", C.c_int32), ("use_ratio", C.c_int32), ("nnratio", C.c_float), ("chi2_gate", C.c_float),
+                ("inv_level_sigma2", C.c_float * 16)]
+
+
+def _search_rule(th_dist, use_ratio, nnratio, chi2_gate=0.0, inv_level_sigma2=None):
+    sig = [1.0] * 16
+    if inv_level_sigma2 is not None:
+        for i, v in enumerate(list(inv_level_sigma2)[:16]):
+            sig[i] = float(v)
+    return SearchRule(int(th_dist), int(bool(use_ratio)), float(nnratio), float(chi2_gate), (C.c_float * 16)(*sig))
 
 
 class SearchBatch(C.Structure):
@@ -397,7 +406,7 @@ class ORBmatcher:
         return idx[:n], med[:n]
 
     @staticmethod
-    def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8, device=0):
+    def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8, device=0, chi2_gate=0.0, inv_level_sigma2=None):
         """The loop body of ORBmatcher::SearchByProjection (ORBmatcher.cc:47-131, :1332-1474) for all
         queries in order: window query over the frame grid, best/second Hamming, accept, mark taken.
         frame: dict kp_xy (n,2) f32, kp_octave (n) i32, desc (n,32) u8, kp_taken (n) u8, min_x, min_y,
@@ -424,7 +433,7 @@ class ORBmatcher:
                        frame["min_x"], frame["min_y"], frame["inv_w"], frame["inv_h"])
         sq = SearchQueries(m, _np_ptr(uvr), _np_ptr(q["level_min"]), _np_ptr(q["level_max"]), _np_ptr(q["desc"]),
                            _np_ptr(q["valid"]), _np_ptr(q["takes"]))
-        rule = SearchRule(int(th_dist), int(bool(use_ratio)), float(nnratio))
+        rule = _search_rule(th_dist, use_ratio, nnratio, chi2_gate, inv_level_sigma2)
         match = np.full(max(m, 1), -1, np.int32)
         out4 = np.zeros((4, max(m, 1)), np.int32)
         nm = C.c_int32(0)
@@ -434,7 +443,8 @@ class ORBmatcher:
         return match[:m], nm.value, out4[:, :m].T.copy()
 
     @staticmethod
-    def guided_search_batch_dev(t, bounds, th_dist=100, use_ratio=True, nnratio=0.8, device=0, stream=None):
+    def guided_search_batch_dev(t, bounds, th_dist=100, use_ratio=True, nnratio=0.8, device=0, stream=None, chi2_gate=0.0,
+                                inv_level_sigma2=None):
         """Batched device form.  t: dict of torch CUDA tensors n (B) i32, kps_un (B, kp_cap, 7) f32 view of cv::KeyPoint,
         desc (B, kp_cap, 32) u8, kp_taken (B, kp_cap) u8, m (B) i32, uvr (B, q_cap, 3) f32, level_min / level_max
         (B, q_cap) i32, qdesc (B, q_cap, 32) u8, valid / takes (B, q_cap) u8, match_kp (B, q_cap) i32, nmatches (B) i32,
@@ -444,7 +454,7 @@ class ORBmatcher:
                          float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), t["m"].data_ptr(), t["uvr"].data_ptr(),
                          t["level_min"].data_ptr(), t["level_max"].data_ptr(), t["qdesc"].data_ptr(), t["valid"].data_ptr(),
                          t["takes"].data_ptr())
-        rule = SearchRule(int(th_dist), int(bool(use_ratio)), float(nnratio))
+        rule = _search_rule(th_dist, use_ratio, nnratio, chi2_gate, inv_level_sigma2)
         out4 = t.get("out4")
         _check(lib().slamit_guided_search_batch_dev(device, C.byref(sb), C.byref(rule), t["match_kp"].data_ptr(), t["nmatches"].data_ptr(),
                                                     out4.data_ptr() if out4 is not None else None, t["workspace"].data_ptr(),

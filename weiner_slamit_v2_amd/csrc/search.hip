@@ -44,6 +44,7 @@ struct SearchDev {
     int* cand_n;                // [nframes][q_cap] (may exceed cand_cap: overflow)
     unsigned long long* tent;   // [nframes][q_cap][2]: the two smallest keys among the candidates not taken ON ENTRY
     int th_dist, use_ratio; float nnratio;
+    float chi2_gate; float inv_sigma2[16];   // Fuse's reprojection gate (chi2_gate <= 0: off)
     int* match_kp; int* out4;   // [nframes][q_cap], [nframes][q_cap][4] (best_dist, best_level, second_dist, second_level) or null
     int* nmatches;              // [nframes]; -1 = a window of this frame held more than cand_cap keypoints
 };
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(256) void search_candidates_kernel(SearchDev D) {
             const float distx = px - x, disty = py - y;
             hit = ingrid && posX >= nMinCellX && posX <= nMaxCellX && posY >= nMinCellY && posY <= nMaxCellY && lev &&
                   fabsf(distx) < r && fabsf(disty) < r;
+            if (hit && D.chi2_gate > 0.f) {   // ORBmatcher::Fuse, ORBmatcher.cc:925-936 (mono branch)
+                const float e2 = distx * distx + disty * disty;
+                if (e2 * D.inv_sigma2[oct & 15] > D.chi2_gate) hit = false;
+            }
             if (hit) {
                 const uint4* T = reinterpret_cast<const uint4*>(KD + 32 * (size_t)i);
                 const uint4 t0 = T[0], t1 = T[1];
@@ -288,6 +293,7 @@ extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, cons
         D.uvr = (const float*)(d + o_uvr); D.lmin = (const int*)(d + o_l0); D.lmax = (const int*)(d + o_l1); D.qdesc = d + o_qd; D.valid = d + o_va; D.takes = d + o_tq;
         D.cand = (unsigned long long*)(d + o_cand); D.cand_n = (int*)(d + o_cn); D.tent = (unsigned long long*)(d + o_te);
         D.th_dist = rule->th_dist; D.use_ratio = rule->use_ratio; D.nnratio = rule->nnratio;
+        D.chi2_gate = rule->chi2_gate; memcpy(D.inv_sigma2, rule->inv_level_sigma2, sizeof(D.inv_sigma2));
         D.match_kp = (int*)(d + o_mk); D.out4 = (int*)(d + o_o4); D.nmatches = (int*)(d + o_nm);
         search_launch(S.st, D, m);
         e = hipGetLastError();
@@ -340,6 +346,7 @@ extern "C" int slamit_guided_search_batch_dev(int device, const slamit_search_ba
     D.tent = D.cand + nq * SLAMIT_SEARCH_BATCH_CAND;
     D.cand_n = reinterpret_cast<int*>(D.tent + 2 * nq);
     D.th_dist = rule->th_dist; D.use_ratio = rule->use_ratio; D.nnratio = rule->nnratio;
+    D.chi2_gate = rule->chi2_gate; memcpy(D.inv_sigma2, rule->inv_level_sigma2, sizeof(D.inv_sigma2));
     D.match_kp = d_match_kp; D.out4 = d_out4; D.nmatches = d_nmatches;
     search_launch((hipStream_t)stream, D, B->q_cap);
     HIP_TRY(hipGetLastError());

@@ -66,7 +66,20 @@ public:
     template <class FrameT>
     int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono);
 
-    // The device call both templates make.  kp_taken / queries are in the order the reference visits them.
+    // LocalMapping::SearchInNeighbors' projection fuse (ORBmatcher.cc:829-979), mono.  Projection, depth / viewing-angle
+    // checks and the Replace / AddObservation bookkeeping are host code; the per-point window query with the level and
+    // reprojection (chi2 5.99) gates and the nearest-descriptor choice of ALL points is one device call (no keypoint is
+    // "taken" here: the choices are independent).  Additional members:
+    //   KeyFrame : GetRotation(), GetTranslation(), GetCameraCenter(), fx, fy, cx, cy, IsInImage(u, v), mfLogScaleFactor,
+    //              mvScaleFactors, mvInvLevelSigma2, mvKeysUn, mvuRight, mDescriptors, GetMapPoint(idx), AddMapPoint(pMP, idx),
+    //              mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv
+    //   MapPoint : isBad(), IsInKeyFrame(pKF), GetWorldPos(), GetMaxDistanceInvariance(), GetMinDistanceInvariance(),
+    //              GetNormal(), PredictScale(dist, logScaleFactor), GetDescriptor(), Observations(), Replace(p),
+    //              AddObservation(pKF, idx)
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0);
+
+    // The device call the templates make.  kp_taken / queries are in the order the reference visits them.
     struct GuidedQueries {
         std::vector<float> uvr;
         std::vector<int32_t> lmin, lmax;
@@ -82,7 +95,8 @@ public:
     };
     static bool GuidedSearch(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& descriptors,
                              const std::vector<uint8_t>& kpTaken, float minX, float minY, float invW, float invH,
-                             const GuidedQueries& q, int thDist, bool useRatio, float nnratio, std::vector<int>& matchKp);
+                             const GuidedQueries& q, int thDist, bool useRatio, float nnratio, std::vector<int>& matchKp,
+                             float chi2Gate = 0.f, const std::vector<float>* invLevelSigma2 = nullptr);
     static int LastStatus();
 
     static const int TH_LOW;
@@ -207,6 +221,74 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame
                 }
     }
     return nmatches;
+}
+
+template <class KeyFrameT, class MapPointT>
+int ORBmatcher::Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th) {
+    const cv::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
+    float R[3][3], t[3], O[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) R[r][c] = Rcw.template at<float>(r, c);
+        t[r] = tcw.template at<float>(r, 0); O[r] = Ow.template at<float>(r, 0);
+    }
+    const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy;
+    const int n = (int)pKF->mvKeysUn.size();
+    for (int i = 0; i < n; ++i)
+        if (pKF->mvuRight[i] >= 0) { setStatus(-2 /*SLAMIT_ERR_ARG*/); return 0; }   // stereo keypoints: not on this path
+    GuidedQueries q;
+    std::vector<MapPointT*> who;
+    for (size_t i = 0; i < vpMapPoints.size(); i++) {
+        MapPointT* pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        const cv::Mat p3Dw = pMP->GetWorldPos();
+        const float X = p3Dw.template at<float>(0, 0), Y = p3Dw.template at<float>(1, 0), Z = p3Dw.template at<float>(2, 0);
+        const float xc = R[0][0] * X + R[0][1] * Y + R[0][2] * Z + t[0];
+        const float yc = R[1][0] * X + R[1][1] * Y + R[1][2] * Z + t[1];
+        const float zc = R[2][0] * X + R[2][1] * Y + R[2][2] * Z + t[2];
+        if (zc < 0.0f) continue;   // depth must be positive
+        const float invz = 1 / zc;
+        const float x = xc * invz, y = yc * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+        const float PO[3] = {X - O[0], Y - O[1], Z - O[2]};
+        const float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);   // cv::norm: double accumulation
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const cv::Mat Pn = pMP->GetNormal();
+        const double dot = (double)PO[0] * Pn.template at<float>(0, 0) + (double)PO[1] * Pn.template at<float>(1, 0) + (double)PO[2] * Pn.template at<float>(2, 0);
+        if (dot < 0.5 * dist3D) continue;   // viewing angle below 60 degrees
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF->mfLogScaleFactor);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        q.add(u, v, radius, nPredictedLevel - 1, nPredictedLevel, pMP->GetDescriptor(), false);
+        who.push_back(pMP);
+    }
+    std::vector<int> matchKp;
+    const std::vector<uint8_t> none((size_t)n, 0);
+    if (!GuidedSearch(pKF->mvKeysUn, pKF->mDescriptors, none, pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv,
+                      pKF->mfGridElementHeightInv, q, TH_LOW, false, mfNNratio, matchKp, 5.99f, &pKF->mvInvLevelSigma2))
+        return 0;
+    int nFused = 0;
+    for (size_t k = 0; k < who.size(); ++k) {
+        const int bestIdx = matchKp[k];
+        if (bestIdx < 0) continue;
+        MapPointT* pMP = who[k];
+        // the reference tests these at the top of each iteration, i.e. AFTER the Replace / AddObservation calls of the
+        // earlier map points: re-test here (the device's choices do not depend on them)
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) {
+                if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                else pMPinKF->Replace(pMP);
+            }
+        } else {
+            pMP->AddObservation(pKF, bestIdx);
+            pKF->AddMapPoint(pMP, bestIdx);
+        }
+        nFused++;
+    }
+    return nFused;
 }
 
 }  // namespace ORB_SLAM2

@@ -7,6 +7,7 @@
 //     shim_test pose  <problem.bin> <out.bin>
 //     shim_test search <problem.bin> <out.bin>
 //     shim_test frame <problem.bin> <out.bin>
+//     shim_test fuse <problem.bin> <out.bin>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -419,6 +420,103 @@ static int run_frame(int argc, char** argv) {
     return 0;
 }
 
+// ---- Fuse: mock KeyFrame / MapPoint with the members ORBmatcher.h documents ---------------------------------
+struct MockFuseKF;
+struct MockFusePoint {
+    int id, nobs, level;
+    bool bad, inKF;
+    float maxd, mind;
+    cv::Mat pos, normal, desc;
+    MockFusePoint* replacedBy;
+    int addedAt;
+    MockFusePoint() : id(-1), nobs(0), level(0), bad(false), inKF(false), maxd(0), mind(0), replacedBy(0), addedAt(-1) {}
+    bool isBad() { return bad; }
+    bool IsInKeyFrame(MockFuseKF*) { return inKF; }
+    cv::Mat GetWorldPos() { return pos.clone(); }
+    cv::Mat GetNormal() { return normal.clone(); }
+    cv::Mat GetDescriptor() { return desc.clone(); }
+    float GetMaxDistanceInvariance() { return maxd; }
+    float GetMinDistanceInvariance() { return mind; }
+    int PredictScale(const float&, const float&) { return level; }   // the caller's method: the mock returns a stored level
+    int Observations() { return nobs; }
+    void Replace(MockFusePoint* p) { replacedBy = p; bad = true; }
+    void AddObservation(MockFuseKF*, size_t idx) { addedAt = (int)idx; inKF = true; ++nobs; }
+};
+struct MockFuseKF {
+    cv::Mat R, t, O, mDescriptors;
+    float fx, fy, cx, cy, mfLogScaleFactor;
+    float mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2, mvuRight;
+    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<MockFusePoint*> mps;
+    cv::Mat GetRotation() { return R.clone(); }
+    cv::Mat GetTranslation() { return t.clone(); }
+    cv::Mat GetCameraCenter() { return O.clone(); }
+    bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
+    MockFusePoint* GetMapPoint(size_t idx) { return mps[idx]; }
+    void AddMapPoint(MockFusePoint* p, size_t idx) { mps[idx] = p; }
+};
+
+// problem.bin: int32 n m ; float th ; float R[9] t[3] O[3] ; float intr[4] ; float bounds[6] (minx maxx miny maxy invw invh) ;
+//   float scale[8] invsig[8] ; keypoints: float xy[2n], int32 octave[n], int32 kf_state[n] (0 none, k>0: own point with k-1
+//   observations), u8 desc[32n] ; map points: float pos[3m] normal[3m] maxd[m] mind[m], int32 level[m] nobs[m] bad[m] inkf[m]
+//   null[m], u8 desc[32m]
+// out.bin: int32 status nFused ; per map point int32 addedAt, replacedBy (-1 none, -2 a keyframe-own point, else id), bad ;
+//   per keypoint int32 owner (-1 none, -2 own, else map point id)
+static int run_fuse(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<unsigned char> raw = slurp(argv[2]);
+    Reader Rd{raw.data()};
+    const int n = Rd.get<int>(), m = Rd.get<int>();
+    const float th = Rd.get<float>();
+    const float* Rv = Rd.arr<float>(9); const float* tv = Rd.arr<float>(3); const float* Ov = Rd.arr<float>(3);
+    const float* intr = Rd.arr<float>(4); const float* b = Rd.arr<float>(6);
+    const float* scale = Rd.arr<float>(8); const float* invsig = Rd.arr<float>(8);
+    const float* xy = Rd.arr<float>(2 * (size_t)n); const int* oct = Rd.arr<int>(n); const int* kfs = Rd.arr<int>(n);
+    const unsigned char* kd = Rd.arr<unsigned char>(32 * (size_t)n);
+    const float* pos = Rd.arr<float>(3 * (size_t)m); const float* nrm = Rd.arr<float>(3 * (size_t)m);
+    const float* maxd = Rd.arr<float>(m); const float* mind = Rd.arr<float>(m);
+    const int* level = Rd.arr<int>(m); const int* nobs = Rd.arr<int>(m); const int* bad = Rd.arr<int>(m); const int* inkf = Rd.arr<int>(m);
+    const int* isnull = Rd.arr<int>(m);
+    const unsigned char* md = Rd.arr<unsigned char>(32 * (size_t)m);
+    MockFuseKF KF;
+    KF.R = cv::Mat(3, 3, CV_32F); KF.t = cv::Mat(3, 1, CV_32F); KF.O = cv::Mat(3, 1, CV_32F);
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) KF.R.at<float>(r, c) = Rv[3 * r + c]; KF.t.at<float>(r, 0) = tv[r]; KF.O.at<float>(r, 0) = Ov[r]; }
+    KF.fx = intr[0]; KF.fy = intr[1]; KF.cx = intr[2]; KF.cy = intr[3]; KF.mfLogScaleFactor = 0.18232f;
+    KF.mnMinX = b[0]; KF.mnMaxX = b[1]; KF.mnMinY = b[2]; KF.mnMaxY = b[3]; KF.mfGridElementWidthInv = b[4]; KF.mfGridElementHeightInv = b[5];
+    KF.mvScaleFactors.assign(scale, scale + 8); KF.mvInvLevelSigma2.assign(invsig, invsig + 8);
+    KF.mvuRight.assign(n, -1.f); KF.mvKeysUn.resize(n); KF.mps.assign(n, (MockFusePoint*)0);
+    KF.mDescriptors = cv::Mat(n, 32, CV_8U);
+    std::vector<MockFusePoint> own(n), pts(m);
+    for (int i = 0; i < n; ++i) {
+        KF.mvKeysUn[i] = cv::KeyPoint(xy[2 * i], xy[2 * i + 1], 31.f, -1.f, 0, oct[i]);
+        memcpy(KF.mDescriptors.ptr(i), kd + 32 * (size_t)i, 32);
+        if (kfs[i] > 0) { own[i].id = -2; own[i].nobs = kfs[i] - 1; KF.mps[i] = &own[i]; }
+    }
+    std::vector<MockFusePoint*> vp(m);
+    for (int j = 0; j < m; ++j) {
+        MockFusePoint& p = pts[j];
+        p.id = j; p.nobs = nobs[j]; p.level = level[j]; p.bad = bad[j] != 0; p.inKF = inkf[j] != 0; p.maxd = maxd[j]; p.mind = mind[j];
+        p.pos = mat_from(pos + 3 * (size_t)j, 3); p.normal = mat_from(nrm + 3 * (size_t)j, 3);
+        p.desc = cv::Mat(1, 32, CV_8U); memcpy(p.desc.ptr(0), md + 32 * (size_t)j, 32);
+        vp[j] = isnull[j] ? (MockFusePoint*)0 : &p;
+    }
+    ORBmatcher matcher(0.6f, true);
+    const int nf = matcher.Fuse(&KF, vp, th);
+    const int status = ORBmatcher::LastStatus();
+    if (status != 0) fprintf(stderr, "fuse failed: %s\n", slamit_last_error());
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(&status, 4, 1, f); fwrite(&nf, 4, 1, f);
+    for (int j = 0; j < m; ++j) {
+        int a = pts[j].addedAt, r = pts[j].replacedBy ? pts[j].replacedBy->id : -1, bd = pts[j].bad ? 1 : 0;
+        fwrite(&a, 4, 1, f); fwrite(&r, 4, 1, f); fwrite(&bd, 4, 1, f);
+    }
+    for (int i = 0; i < n; ++i) { int o = KF.mps[i] ? KF.mps[i]->id : -1; fwrite(&o, 4, 1, f); }
+    for (int i = 0; i < n; ++i) { int r = own[i].replacedBy ? own[i].replacedBy->id : -1; fwrite(&r, 4, 1, f); }
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
@@ -428,5 +526,6 @@ int main(int argc, char** argv) {
     if (mode == "pose") return run_pose(argc, argv);
     if (mode == "search") return run_search(argc, argv);
     if (mode == "frame") return run_frame(argc, argv);
+    if (mode == "fuse") return run_fuse(argc, argv);
     return 2;
 }
