@@ -44,7 +44,8 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0, size_t img0_stride,
                    size_t img0_frame, const uint8_t* pyr, OrbLevelKp* lkp, size_t kp_frame_stride,
                    const int* kp_count, int max_kp, int nframes);
-void orbk_blur(hipStream_t st, const OrbLevel* levels, int nlevels, int total_tiles, const uint8_t* img0,
+int orbk_blur_tiles(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out);
+void orbk_blur(hipStream_t st, const OrbLevel* levels, const uint32_t* d_tiles, int total_tiles, const uint8_t* img0,
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes);
 void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,
                    const OrbLevelKp* lkp, size_t kp_frame_stride, const int* kp_count, slamit_kp* out_kps,
@@ -104,6 +105,7 @@ struct slamit_orb {
     unsigned long long* d_cand;
     uint32_t* d_ws_xy;
     uint16_t* d_ws_node;
+    uint32_t* d_blur_tiles;   // blur strip table (orbk_blur_tiles), blur_tiles entries of 4 words
     uint32_t* d_cells;   // FAST cell table (orbk_fast_cells), fast_cells entries of 8 words
     int fast_cells;
     int* d_counts;  // cand_count [max_batch][nlevels][ORB_CC_PAD] then kp_count [max_batch][nlevels]
@@ -140,7 +142,7 @@ static void orb_free(slamit_orb* h) {
     if (!h) return;
     hipSetDevice(h->device);
     hipFree(h->d_levels); hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cand); hipFree(h->d_ws_xy);
-    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
+    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_blur_tiles); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
     hipFree(h->d_out_desc); hipFree(h->d_out_n); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
@@ -283,6 +285,10 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         h->fast_cells = empty ? 0 : orbk_fast_cells(h->levels.data(), nl, cells);
         ALLOC(h->d_cells, sizeof(uint32_t) * std::max<size_t>(cells.size(), 8));
         if (e == hipSuccess && !cells.empty()) e = hipMemcpy(h->d_cells, cells.data(), sizeof(uint32_t) * cells.size(), hipMemcpyHostToDevice);
+        std::vector<uint32_t> bt;
+        h->blur_tiles = empty ? 0 : orbk_blur_tiles(h->levels.data(), nl, bt);
+        ALLOC(h->d_blur_tiles, sizeof(uint32_t) * std::max<size_t>(bt.size(), 4));
+        if (e == hipSuccess && !bt.empty()) e = hipMemcpy(h->d_blur_tiles, bt.data(), sizeof(uint32_t) * bt.size(), hipMemcpyHostToDevice);
     }
     bool rows4_ok = true;
     for (int l = 1; l < nl && e == hipSuccess && !empty; ++l) {
@@ -505,7 +511,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     prof_mark(h, st, ST_ANGLE, false);
     // K6: blur every level
     prof_mark(h, st, ST_BLUR, true);
-    orbk_blur(st, h->d_levels, nl, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
+    orbk_blur(st, h->d_levels, h->d_blur_tiles, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
     prof_mark(h, st, ST_BLUR, false);
     // K7: descriptors + output records
     prof_mark(h, st, ST_DESCRIBE, true);

@@ -1046,7 +1046,7 @@ __device__ __forceinline__ uint32_t blur_fetch(const uint8_t* S, unsigned sstrid
 }
 
 __global__ __launch_bounds__(256) void blur_all_kernel(
-    const OrbLevel* __restrict__ levels, int nlevels,
+    const OrbLevel* __restrict__ levels, const uint4* __restrict__ tiles,
     const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
     __shared__ __attribute__((aligned(16))) uint8_t in[22][72];
@@ -1055,15 +1055,10 @@ __global__ __launch_bounds__(256) void blur_all_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t rp[11][64];
     const int tid = threadIdx.x;
     const int frame = blockIdx.y;
-    int level = 0;
-    while (level + 1 < nlevels && (int)blockIdx.x >= levels[level + 1].blur_tile_base) ++level;
+    const uint4 tt = tiles[blockIdx.x];   // host-built (orbk_blur_tiles): level, strip origin -- no level search, no division
+    const int level = (int)tt.x, bx = (int)tt.y, by0 = (int)tt.z;
     const OrbLevel& L = levels[level];
-    const int t = blockIdx.x - L.blur_tile_base;
-    const int tx = (L.w + 63) >> 6;
-    const int ty = t / tx;
-    const int bx = (t - ty * tx) * 64, by0 = ty * (16 * BLUR_STEPS);
     const int w = L.w, h = L.h;
-    if (by0 >= h) return;
     const uint8_t* S;
     size_t sstride;
     if (level == 0) { S = img0 + (size_t)frame * img0_frame; sstride = img0_stride; }
@@ -1410,10 +1405,19 @@ void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const ui
                        nlevels, img0, img0_stride, img0_frame, pyr, lkp, kp_frame_stride, kp_count);
 }
 
-void orbk_blur(hipStream_t st, const OrbLevel* levels, int nlevels, int total_tiles, const uint8_t* img0,
+// Strip table of blur_all_kernel: (level, bx, by0, 0) for every 64 x 64 strip of every level, level-major
+int orbk_blur_tiles(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out) {
+    out.clear();
+    for (int l = 0; l < nlevels; ++l)
+        for (int by = 0; by < host_levels[l].h; by += 16 * BLUR_STEPS)
+            for (int bx = 0; bx < host_levels[l].w; bx += 64) { const uint32_t t[4] = {(uint32_t)l, (uint32_t)bx, (uint32_t)by, 0u}; out.insert(out.end(), t, t + 4); }
+    return (int)(out.size() / 4);
+}
+
+void orbk_blur(hipStream_t st, const OrbLevel* levels, const uint32_t* d_tiles, int total_tiles, const uint8_t* img0,
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes) {
-    hipLaunchKernelGGL(blur_all_kernel, dim3(total_tiles, nframes), dim3(256), 0, st, levels, nlevels, img0, img0_stride,
-                       img0_frame, pyr, blur);
+    hipLaunchKernelGGL(blur_all_kernel, dim3(total_tiles, nframes), dim3(256), 0, st, levels, reinterpret_cast<const uint4*>(d_tiles), img0,
+                       img0_stride, img0_frame, pyr, blur);
 }
 
 void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,
