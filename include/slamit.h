@@ -186,6 +186,15 @@ typedef struct slamit_search_rule {
      * candidate is skipped when e2 * inv_level_sigma2[kp.octave] > chi2_gate (5.99).  chi2_gate <= 0: no gate. */
     float chi2_gate;
     float inv_level_sigma2[16];
+    /* mode 0: the SearchByProjection / Fuse loop described above.
+     * mode 1: ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:409-474): instead of the taken flag a keypoint
+     *   carries the distance of its current match; a candidate is skipped when that distance is <= the query's
+     *   distance to it (:448); accept iff bestDist <= th_dist && bestDist < (float)bestDist2 * nnratio (bestDist2 =
+     *   INT_MAX without a second candidate); an accepted query takes the keypoint over from the query that held it,
+     *   whose match_kp entry goes back to -1.  kp_taken / takes / use_ratio / chi2_gate are ignored.  best_level then
+ *   reports the keypoint a query was matched to AT ITS OWN TURN (-1 if it was not accepted), which a later take-over
+ *   does not reset: the reference bins exactly those into its rotation histogram (:467-477). */
+    int32_t mode;
 } slamit_search_rule;
 
 /* match_kp[q] = index of the keypoint the query took, or -1; *nmatches = number of accepted queries.

@@ -70,6 +70,8 @@ def orb_lib():
         L.orb_oracle_guided_search.argtypes = [C.c_int, _f32p, _i32p, _u8p, _u8p, C.c_float, C.c_float, C.c_float, C.c_float,
                                                C.c_int, _f32p, _i32p, _i32p, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_float,
                                                C.c_float, _f32p, _i32p, _i32p]
+        L.orb_oracle_search_init.argtypes = [C.c_int, _i32p, _u8p, _f32p, C.c_int, _f32p, _i32p, _u8p, C.c_float, C.c_float, C.c_float,
+                                             C.c_float, C.c_int, C.c_float, C.c_int, _i32p, _i32p]
         L.orb_oracle_undistort.argtypes = [_f32p, _f32p, C.c_int, _f32p]
         L.orb_oracle_frame_finish.argtypes = [_f32p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                               _i32p, _i32p]
@@ -262,6 +264,25 @@ def normalize_search(frame, queries):
              valid=np.ascontiguousarray(queries.get("valid", np.ones(m)), np.uint8),
              takes=np.ascontiguousarray(queries.get("takes", np.ones(m)), np.uint8))
     return f, q
+
+
+def search_for_initialization(f1, prev_xy, f2, window=100, nnratio=0.9, th_low=50):
+    """ORBmatcher::SearchForInitialization's matching loop: f1 / f2 dicts with kp_octave, desc (f2 also kp_xy, min_x, min_y,
+    inv_w, inv_h); prev_xy (n1, 2) = vbPrevMatched.  Returns (vnMatches12, nmatches, accepted-at-turn) before the
+    rotation-histogram filter."""
+    o1 = np.ascontiguousarray(f1["kp_octave"], np.int32)
+    d1 = np.ascontiguousarray(f1["desc"], np.uint8).reshape(-1, 32)
+    pv = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+    x2 = np.ascontiguousarray(f2["kp_xy"], np.float32).reshape(-1, 2)
+    o2 = np.ascontiguousarray(f2["kp_octave"], np.int32)
+    d2 = np.ascontiguousarray(f2["desc"], np.uint8).reshape(-1, 32)
+    m12 = np.full(max(len(o1), 1), -1, np.int32)
+    acc = np.full(max(len(o1), 1), -1, np.int32)
+    nm = orb_lib().orb_oracle_search_init(len(o1), _ptr(o1, _i32p), _ptr(d1), _ptr(pv, _f32p), len(o2), _ptr(x2, _f32p), _ptr(o2, _i32p),
+                                          _ptr(d2), float(np.float32(f2["min_x"])), float(np.float32(f2["min_y"])),
+                                          float(np.float32(f2["inv_w"])), float(np.float32(f2["inv_h"])), int(window),
+                                          float(np.float32(nnratio)), int(th_low), _ptr(m12, _i32p), _ptr(acc, _i32p))
+    return m12[:len(o1)], nm, acc[:len(o1)]
 
 
 def undistort(cam9, xy):

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <limits.h>
 
 #include <algorithm>
 #include <list>
@@ -978,4 +979,48 @@ extern "C" int orb_oracle_frame_finish(const float* cam9, const slamit_kp* kps, 
     cell_start[kGridCols * kGridRows] = m;
     delete g;
     return m;
+}
+
+// ORBmatcher::SearchForInitialization (ORBmatcher.cc:409-474): the matching loop, without the rotation histogram
+// (:476-518, host logic in the shim).  F1 keypoints above level 0 are skipped; window = windowSize at level 0 of F2;
+// vMatchedDistance gates candidates; an accepted match takes the keypoint over from an earlier query.
+extern "C" int orb_oracle_search_init(int n1, const int32_t* kp1_octave, const uint8_t* desc1, const float* prev_xy, int n2,
+                                      const float* kp2_xy, const int32_t* kp2_octave, const uint8_t* desc2, float minx, float miny,
+                                      float invw, float invh, int windowSize, float nnratio, int th_low, int32_t* vnMatches12,
+                                      int32_t* accepted /* bestIdx2 at the query's own turn, -1 if none (what :467-477 bins) */) {
+    FrameGrid* g = new FrameGrid;
+    for (int i = 0; i < n2; i++) {
+        int gx, gy;
+        if (pos_in_grid(kp2_xy[2 * i], kp2_xy[2 * i + 1], minx, miny, invw, invh, gx, gy)) g->cell[gx][gy].push_back(i);
+    }
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) { vnMatches12[i] = -1; accepted[i] = -1; }
+    std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+    std::vector<int> vIndices2;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = kp1_octave[i1];
+        if (level1 > 0) continue;
+        features_in_area(*g, kp2_xy, kp2_octave, minx, miny, invw, invh, prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)windowSize, level1, level1, vIndices2);
+        if (vIndices2.empty()) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (size_t j = 0; j < vIndices2.size(); j++) {
+            const int i2 = vIndices2[j];
+            const int dist = descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= th_low) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                accepted[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+            }
+        }
+    }
+    delete g;
+    return nmatches;
 }

@@ -370,3 +370,12 @@ def test_guided_search_fuse_gate():
     gm, gn, g4 = api.ORBmatcher.guided_search(frame, queries, 50, False, 0.6, chi2_gate=5.99, inv_level_sigma2=sig)
     om, on, o4 = ob.guided_search(frame, queries, 50, False, 0.6, 5.99, sig)
     assert np.array_equal(gm, om) and gn == on and np.array_equal(g4, o4) and gn > 0
+
+
+@pytest.mark.parametrize("n,seed,window", [(900, 1, 40), (2000, 2, 100), (300, 3, 10), (64, 4, 1000)])
+def test_search_for_initialization_mode(n, seed, window):
+    """Guided-search mode 1 == ORBmatcher::SearchForInitialization's loop (matched-distance gate, take-over)."""
+    f1, prev, f2 = synth.synth_init_pair(n, seed)
+    gm, gn, gacc = api.ORBmatcher.search_for_initialization(f1, prev, f2, window, 0.9, 50)
+    om, on, oacc = ob.search_for_initialization(f1, prev, f2, window, 0.9, 50)
+    assert np.array_equal(gm, om) and gn == on and np.array_equal(gacc, oacc)

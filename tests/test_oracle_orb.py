@@ -540,3 +540,49 @@ def test_guided_search_with_fuse_gate_matches_model():
     assert 0 < got[1] < nogate[1]            # the gate removes matches that the plain window would accept
     won = got[0][got[0] >= 0]
     assert len(np.unique(won)) < len(won)    # nothing is taken: several map points may pick one keypoint
+
+
+def test_search_for_initialization_matches_model():
+    """ORBmatcher.cc:409-474 restated vs an independent numpy statement (matched-distance gate, take-over)."""
+    f1, prev, f2 = synth.synth_init_pair(900, 1)
+    m12, nm, acc = ob.search_for_initialization(f1, prev, f2, 40, 0.9, 50)
+    # model
+    f32 = np.float32
+    xy, o2 = np.asarray(f2["kp_xy"], f32), np.asarray(f2["kp_octave"])
+    minx, miny, iw, ih = f32(f2["min_x"]), f32(f2["min_y"]), f32(f2["inv_w"]), f32(f2["inv_h"])
+    v, w = (xy[:, 0] - minx) * iw, (xy[:, 1] - miny) * ih
+    gx = np.where(v >= 0, np.floor(v + f32(0.5)), np.ceil(v - f32(0.5))).astype(int)
+    gy = np.where(w >= 0, np.floor(w + f32(0.5)), np.ceil(w - f32(0.5))).astype(int)
+    ingrid = (gx >= 0) & (gx < 64) & (gy >= 0) & (gy < 48)
+    n1, n2 = len(f1["kp_octave"]), len(xy)
+    md, m21 = np.full(n2, 2 ** 31 - 1, np.int64), np.full(n2, -1)
+    e12, eacc, enm = np.full(n1, -1), np.full(n1, -1), 0
+    for i1 in range(n1):
+        if f1["kp_octave"][i1] > 0:
+            continue
+        x, y, r = f32(prev[i1, 0]), f32(prev[i1, 1]), f32(40)
+        cx0, cx1 = max(0, int(np.floor((x - minx - r) * iw))), min(63, int(np.ceil((x - minx + r) * iw)))
+        cy0, cy1 = max(0, int(np.floor((y - miny - r) * ih))), min(47, int(np.ceil((y - miny + r) * ih)))
+        if cx0 >= 64 or cx1 < 0 or cy0 >= 48 or cy1 < 0:
+            continue
+        ok = ingrid & (gx >= cx0) & (gx <= cx1) & (gy >= cy0) & (gy <= cy1) & (o2 == 0) & (np.abs(xy[:, 0] - x) < r) & (np.abs(xy[:, 1] - y) < r)
+        cand = np.nonzero(ok)[0]
+        if len(cand) == 0:
+            continue
+        cand = cand[np.lexsort((cand, gy[cand], gx[cand]))]
+        d = np.unpackbits(f2["desc"][cand] ^ f1["desc"][i1][None], axis=1).sum(1)
+        live = md[cand] > d
+        cand, d = cand[live], d[live]
+        if len(cand) == 0:
+            continue
+        order = np.argsort(d, kind="stable")
+        b, bd = cand[order[0]], int(d[order[0]])
+        sd = int(d[order[1]]) if len(order) > 1 else 2 ** 31 - 1
+        if bd <= 50 and f32(bd) < f32(sd) * f32(0.9):
+            if m21[b] >= 0:
+                e12[m21[b]] = -1
+                enm -= 1
+            e12[i1], eacc[i1], m21[b], md[b] = b, b, i1, bd
+            enm += 1
+    assert np.array_equal(m12, e12) and nm == enm and np.array_equal(acc, eacc)
+    assert nm > 100 and (acc >= 0).sum() > nm          # some matches were taken over

@@ -423,3 +423,59 @@ def test_shim_fuse(tmp_path):
     assert np.array_equal(per[:, 0], added) and np.array_equal(per[:, 1], replaced) and np.array_equal(per[:, 2], p_bad.astype(np.int32))
     assert np.array_equal(r[2 + 3 * m:2 + 3 * m + n], owner)
     assert np.array_equal(r[2 + 3 * m + n:], own_replaced)
+
+
+@pytest.mark.gpu
+def test_shim_search_for_initialization(tmp_path):
+    """ORBmatcher::SearchForInitialization through the template: device matching loop (mode 1), host rotation histogram
+    over the matches accepted at their own turn, vbPrevMatched update."""
+    from oracle import bindings as ob
+    from weiner_slamit_v2_amd import synth
+
+    _build()
+    f32 = np.float32
+    f1, prev, f2 = synth.synth_init_pair(1200, 7)
+    n1, n2, window, nnratio = len(f1["kp_octave"]), len(f2["kp_octave"]), 40, 0.9
+    m12, nm, acc = ob.search_for_initialization(f1, prev, f2, window, nnratio, 50)
+    # angles: one dominant rotation (12 degrees) for 80 % of the accepted matches
+    rs = np.random.RandomState(3)
+    a2 = f2["angle"].astype(np.float32)
+    a1 = f1["angle"].astype(np.float32).copy()
+    hit = np.nonzero(acc >= 0)[0]
+    a1[hit] = ((a2[acc[hit]] + np.where(rs.rand(len(hit)) < 0.8, 12.0, rs.uniform(0, 360, len(hit)))) % 360.0).astype(np.float32)
+    bounds = np.array([f2["min_x"], 645.1, f2["min_y"], 483.9, f2["inv_w"], f2["inv_h"]], np.float32)
+    blob = struct.pack("<iiif", n1, n2, window, nnratio) + bounds.tobytes()
+    blob += f1["kp_octave"].astype(np.int32).tobytes() + a1.tobytes() + prev.astype(np.float32).tobytes() + f1["desc"].tobytes()
+    blob += f2["kp_xy"].astype(np.float32).tobytes() + f2["kp_octave"].astype(np.int32).tobytes() + a2.tobytes() + f2["desc"].tobytes()
+    pin, pout = tmp_path / "i.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "init", str(pin), str(pout)])
+    raw = open(pout, "rb").read()
+    status, got_nm = struct.unpack_from("<ii", raw, 0)
+    got12 = np.frombuffer(raw, np.int32, n1, 8)
+    got_prev = np.frombuffer(raw, np.float32, 2 * n1, 8 + 4 * n1).reshape(n1, 2)
+    assert status == 0
+    # expected: histogram over `acc` in i1 order (ORBmatcher.cc:467-477), three maxima, prune, update prev
+    hist = [[] for _ in range(30)]
+    factor = f32(1.0) / f32(30)
+    for i1 in hit:
+        rot = f32(a1[i1] - a2[acc[i1]])
+        if rot < 0:
+            rot = f32(rot + f32(360))
+        b = int(np.floor(f32(rot * factor) + f32(0.5)))
+        hist[0 if b == 30 else b].append(i1)
+    sizes = [len(h) for h in hist]
+    order = sorted(range(30), key=lambda i: -sizes[i])
+    assert sizes[order[0]] > 100 and sizes[order[1]] < 0.1 * sizes[order[0]], "test premise: one dominant rotation bin"
+    e12, enm = m12.copy(), nm
+    for i in range(30):
+        if i != order[0]:
+            for i1 in hist[i]:
+                if e12[i1] >= 0:
+                    e12[i1] = -1
+                    enm -= 1
+    assert got_nm == enm and np.array_equal(got12, e12)
+    eprev = prev.astype(np.float32).copy()
+    ok = e12 >= 0
+    eprev[ok] = f2["kp_xy"][e12[ok]]
+    assert np.array_equal(got_prev, eprev)

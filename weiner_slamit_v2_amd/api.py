@@ -68,15 +68,15 @@ class SearchQueries(C.Structure):
 
 class SearchRule(C.Structure):
     _fields_ = [("th_dist", C.c_int32), ("use_ratio", C.c_int32), ("nnratio", C.c_float), ("chi2_gate", C.c_float),
-                ("inv_level_sigma2", C.c_float * 16)]
+                ("inv_level_sigma2", C.c_float * 16), ("mode", C.c_int32)]
 
 
-def _search_rule(th_dist, use_ratio, nnratio, chi2_gate=0.0, inv_level_sigma2=None):
+def _search_rule(th_dist, use_ratio, nnratio, chi2_gate=0.0, inv_level_sigma2=None, mode=0):
     sig = [1.0] * 16
     if inv_level_sigma2 is not None:
         for i, v in enumerate(list(inv_level_sigma2)[:16]):
             sig[i] = float(v)
-    return SearchRule(int(th_dist), int(bool(use_ratio)), float(nnratio), float(chi2_gate), (C.c_float * 16)(*sig))
+    return SearchRule(int(th_dist), int(bool(use_ratio)), float(nnratio), float(chi2_gate), (C.c_float * 16)(*sig), int(mode))
 
 
 class SearchBatch(C.Structure):
@@ -406,7 +406,7 @@ class ORBmatcher:
         return idx[:n], med[:n]
 
     @staticmethod
-    def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8, device=0, chi2_gate=0.0, inv_level_sigma2=None):
+    def guided_search(frame, queries, th_dist=100, use_ratio=True, nnratio=0.8, device=0, chi2_gate=0.0, inv_level_sigma2=None, mode=0):
         """The loop body of ORBmatcher::SearchByProjection (ORBmatcher.cc:47-131, :1332-1474) for all
         queries in order: window query over the frame grid, best/second Hamming, accept, mark taken.
         frame: dict kp_xy (n,2) f32, kp_octave (n) i32, desc (n,32) u8, kp_taken (n) u8, min_x, min_y,
@@ -433,7 +433,7 @@ class ORBmatcher:
                        frame["min_x"], frame["min_y"], frame["inv_w"], frame["inv_h"])
         sq = SearchQueries(m, _np_ptr(uvr), _np_ptr(q["level_min"]), _np_ptr(q["level_max"]), _np_ptr(q["desc"]),
                            _np_ptr(q["valid"]), _np_ptr(q["takes"]))
-        rule = _search_rule(th_dist, use_ratio, nnratio, chi2_gate, inv_level_sigma2)
+        rule = _search_rule(th_dist, use_ratio, nnratio, chi2_gate, inv_level_sigma2, mode)
         match = np.full(max(m, 1), -1, np.int32)
         out4 = np.zeros((4, max(m, 1)), np.int32)
         nm = C.c_int32(0)
@@ -463,6 +463,19 @@ class ORBmatcher:
     @staticmethod
     def guided_search_workspace(nframes, q_cap):
         return int(lib().slamit_guided_search_workspace(nframes, q_cap))
+
+    @staticmethod
+    def search_for_initialization(f1, prev_xy, f2, window=100, nnratio=0.9, th_low=50, device=0):
+        """ORBmatcher::SearchForInitialization's matching loop (ORBmatcher.cc:409-474) as guided-search mode 1: queries =
+        F1's level-0 keypoints at vbPrevMatched, window `window`, level [0, 0].  Returns (vnMatches12, nmatches, accepted-at-turn)."""
+        o1 = np.ascontiguousarray(f1["kp_octave"], np.int32)
+        n1 = len(o1)
+        pv = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+        q = dict(uvr=np.concatenate([pv, np.full((n1, 1), float(window), np.float32)], 1), level_min=np.zeros(n1, np.int32),
+                 level_max=np.zeros(n1, np.int32), desc=f1["desc"], valid=(o1 <= 0).astype(np.uint8), takes=np.zeros(n1, np.uint8))
+        frame = dict(f2, kp_taken=np.zeros(len(np.asarray(f2["kp_octave"])), np.uint8))
+        m12, nm, out4 = ORBmatcher.guided_search(frame, q, th_low, False, nnratio, device=device, mode=1)
+        return m12, nm, out4[:, 1].copy()   # the level slot carries the keypoint accepted at the query's own turn
 
     def match(self, q, t, th=None):
         """All-pairs match with the reference's acceptance rule: best <= th and best < nnratio*second

@@ -45,6 +45,7 @@ struct SearchDev {
     unsigned long long* tent;   // [nframes][q_cap][2]: the two smallest keys among the candidates not taken ON ENTRY
     int th_dist, use_ratio; float nnratio;
     float chi2_gate; float inv_sigma2[16];   // Fuse's reprojection gate (chi2_gate <= 0: off)
+    int mode;                                 // 0 taken flags, 1 SearchForInitialization's matched-distance state
     int* match_kp; int* out4;   // [nframes][q_cap], [nframes][q_cap][4] (best_dist, best_level, second_dist, second_level) or null
     int* nmatches;              // [nframes]; -1 = a window of this frame held more than cand_cap keypoints
 };
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void search_candidates_kernel(SearchDev D) {
         if (hit) {
             const int o = count + __popcll(mk & ((1ull << lane) - 1ull));
             if (o < D.cand_cap) out[o] = key;
-            if (!TK[i]) { if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key; }
+            if (D.mode == 1 || !TK[i]) { if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key; }
         }
         count += __popcll(mk);
     }
@@ -230,10 +231,93 @@ __global__ __launch_bounds__(64) void search_resolve_kernel(SearchDev D) {
     if (lane == 0) D.nmatches[f] = overflow ? -1 : nmatches;
 }
 
+// mode 1 (ORBmatcher::SearchForInitialization): the per-keypoint state is the distance of its current match and the query
+// that holds it.  Same speculation: the tentative pair is exact unless one of the two is excluded by the state
+// (matched distance <= this query's distance to it); otherwise the query's candidates are re-scanned with the exclusion.
+__global__ __launch_bounds__(64) void search_resolve_init_kernel(SearchDev D) {
+    extern __shared__ int s_state[];   // md[kp_cap] | m21[kp_cap]
+    const int lane = threadIdx.x, f = blockIdx.x;
+    const int n = D.n_arr ? min(D.n_arr[f], D.kp_cap) : D.n_fixed;
+    const int m = D.m_arr ? min(D.m_arr[f], D.q_cap) : D.m_fixed;
+    int* md = s_state;
+    int* m21 = s_state + D.kp_cap;
+    for (int i = lane; i < n; i += 64) { md[i] = 0x7FFFFFFF; m21[i] = -1; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long NONE = ~0ull;
+    const size_t q0 = (size_t)f * D.q_cap;
+    int nmatches = 0, overflow = 0;
+    for (int qb = 0; qb < m; qb += 64) {
+        const int qj = qb + lane;
+        const bool live = qj < m;
+        unsigned long long tb = NONE, ts = NONE;
+        int ncq = 0;
+        if (live) { tb = D.tent[2 * (q0 + qj)]; ts = D.tent[2 * (q0 + qj) + 1]; ncq = D.cand_n[q0 + qj]; }
+        overflow |= __ballot(ncq > D.cand_cap) != 0ull;
+        int res = -1, bd = 256, bl = -1, sd = 256, sl = -1;
+        const int jn = min(64, m - qb);
+        for (int j = 0; j < jn; ++j) {
+            unsigned long long best = readlane_u64(tb, j), second = readlane_u64(ts, j);
+            if (best != NONE) {
+                const bool xb = md[KEY_KP(best)] <= (int)(best >> 32);
+                const bool xs = second != NONE && md[KEY_KP(second)] <= (int)(second >> 32);
+                if (xb || xs) {
+                    const size_t qo = q0 + qb + j;
+                    const int nc = min(__builtin_amdgcn_readlane(ncq, j), D.cand_cap);
+                    const unsigned long long* C = D.cand + qo * D.cand_cap;
+                    unsigned long long k1 = NONE, k2 = NONE;
+                    for (int c = lane; c < nc; c += 64) {
+                        const unsigned long long k = C[c];
+                        if (md[KEY_KP(k)] <= (int)(k >> 32)) continue;   // ORBmatcher.cc:448
+                        if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+                    }
+                    best = wave_min_u64(k1);
+                    second = wave_min_u64(k1 == best ? k2 : k1);
+                }
+            }
+            int r_res = -1, r_bd = 256, r_bl = -1, r_sd = 256, r_sl = -1;
+            if (best != NONE) {
+                const int bi = KEY_KP(best);
+                r_bd = (int)(best >> 32); r_bl = -1;
+                float second_f = 2147483648.0f;   // (float)INT_MAX
+                if (second != NONE) { r_sd = (int)(second >> 32); r_sl = KEY_OCT(second); second_f = (float)r_sd; }
+                if (r_bd <= D.th_dist && (float)r_bd < second_f * D.nnratio) {   // ORBmatcher.cc:462-464
+                    const int old = m21[bi];
+                    if (old >= 0) {   // the keypoint changes hands: vnMatches12[vnMatches21[bestIdx2]] = -1
+                        if (old >= qb) { if (lane == old - qb) res = -1; }
+                        else if (lane == 0) D.match_kp[q0 + old] = -1;
+                        --nmatches;
+                    }
+                    r_res = bi;
+                    r_bl = bi;   // mode 1 reports the keypoint accepted AT DECISION TIME in the level slot (levels are all 0
+                                 // here); unlike match_kp it is not reset by a later take-over -- the rotation histogram bins it
+                    if (lane == 0) { m21[bi] = qb + j; md[bi] = r_bd; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    ++nmatches;
+                }
+            }
+            if (lane == j) { res = r_res; bd = r_bd; bl = r_bl; sd = r_sd; sl = r_sl; }
+        }
+        if (live) {
+            const size_t qo = q0 + qj;
+            D.match_kp[qo] = res;
+            if (D.out4) *reinterpret_cast<int4*>(&D.out4[4 * qo]) = make_int4(bd, bl, sd, sl);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // later chunks may reset entries of this one through global memory
+    }
+    if (lane == 0) D.nmatches[f] = overflow ? -1 : nmatches;
+}
+
 static void search_launch(hipStream_t st, const SearchDev& D, int max_m) {
     if (max_m > 0)
         hipLaunchKernelGGL(search_candidates_kernel, dim3((max_m + 3) / 4, D.nframes), dim3(256), 0, st, D);
-    hipLaunchKernelGGL(search_resolve_kernel, dim3(D.nframes), dim3(64), 0, st, D);
+    if (D.mode == 1) {
+        static bool prepared = false;   // 2 x 4 x 8191 bytes of state sit just under the 64 KB default; ask explicitly
+        if (!prepared) { hipFuncSetAttribute(reinterpret_cast<const void*>(search_resolve_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); prepared = true; }
+        hipLaunchKernelGGL(search_resolve_init_kernel, dim3(D.nframes), dim3(64), 2 * sizeof(int) * (size_t)D.kp_cap, st, D);
+    } else
+        hipLaunchKernelGGL(search_resolve_kernel, dim3(D.nframes), dim3(64), 0, st, D);
 }
 
 extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, const slamit_search_queries* Q,
@@ -293,7 +377,8 @@ extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, cons
         D.uvr = (const float*)(d + o_uvr); D.lmin = (const int*)(d + o_l0); D.lmax = (const int*)(d + o_l1); D.qdesc = d + o_qd; D.valid = d + o_va; D.takes = d + o_tq;
         D.cand = (unsigned long long*)(d + o_cand); D.cand_n = (int*)(d + o_cn); D.tent = (unsigned long long*)(d + o_te);
         D.th_dist = rule->th_dist; D.use_ratio = rule->use_ratio; D.nnratio = rule->nnratio;
-        D.chi2_gate = rule->chi2_gate; memcpy(D.inv_sigma2, rule->inv_level_sigma2, sizeof(D.inv_sigma2));
+        D.chi2_gate = rule->mode == 1 ? 0.f : rule->chi2_gate; memcpy(D.inv_sigma2, rule->inv_level_sigma2, sizeof(D.inv_sigma2));
+        D.mode = rule->mode;
         D.match_kp = (int*)(d + o_mk); D.out4 = (int*)(d + o_o4); D.nmatches = (int*)(d + o_nm);
         search_launch(S.st, D, m);
         e = hipGetLastError();
@@ -346,7 +431,8 @@ extern "C" int slamit_guided_search_batch_dev(int device, const slamit_search_ba
     D.tent = D.cand + nq * SLAMIT_SEARCH_BATCH_CAND;
     D.cand_n = reinterpret_cast<int*>(D.tent + 2 * nq);
     D.th_dist = rule->th_dist; D.use_ratio = rule->use_ratio; D.nnratio = rule->nnratio;
-    D.chi2_gate = rule->chi2_gate; memcpy(D.inv_sigma2, rule->inv_level_sigma2, sizeof(D.inv_sigma2));
+    D.chi2_gate = rule->mode == 1 ? 0.f : rule->chi2_gate; memcpy(D.inv_sigma2, rule->inv_level_sigma2, sizeof(D.inv_sigma2));
+    D.mode = rule->mode;
     D.match_kp = d_match_kp; D.out4 = d_out4; D.nmatches = d_nmatches;
     search_launch((hipStream_t)stream, D, B->q_cap);
     HIP_TRY(hipGetLastError());

@@ -53,7 +53,7 @@ void ORBmatcher::setStatus(int rc) { g_status = rc; }
 bool ORBmatcher::GuidedSearch(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& descriptors,
                               const std::vector<uint8_t>& kpTaken, float minX, float minY, float invW, float invH,
                               const GuidedQueries& q, int thDist, bool useRatio, float nnratio, std::vector<int>& matchKp,
-                              float chi2Gate, const std::vector<float>* invLevelSigma2) {
+                              float chi2Gate, const std::vector<float>* invLevelSigma2, int mode, std::vector<int>* acceptedKp) {
     const int n = (int)keysUn.size(), m = q.size();
     matchKp.assign(m, -1);
     g_status = SLAMIT_OK;
@@ -71,9 +71,11 @@ bool ORBmatcher::GuidedSearch(const std::vector<cv::KeyPoint>& keysUn, const cv:
     slamit_search_rule rule;
     rule.th_dist = thDist; rule.use_ratio = useRatio ? 1 : 0; rule.nnratio = nnratio;
     rule.chi2_gate = chi2Gate;
+    rule.mode = mode;
     for (int i = 0; i < 16; ++i) rule.inv_level_sigma2[i] = (invLevelSigma2 && i < (int)invLevelSigma2->size()) ? (*invLevelSigma2)[i] : 1.f;
     int nm = 0;
-    g_status = slamit_guided_search(0, &fv, &sq, &rule, matchKp.data(), &nm, nullptr, nullptr, nullptr, nullptr);
+    if (acceptedKp) acceptedKp->assign(m, -1);
+    g_status = slamit_guided_search(0, &fv, &sq, &rule, matchKp.data(), &nm, nullptr, acceptedKp ? acceptedKp->data() : nullptr, nullptr, nullptr);
     return g_status == SLAMIT_OK;
 }
 

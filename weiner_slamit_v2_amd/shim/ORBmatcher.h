@@ -79,6 +79,13 @@ public:
     template <class KeyFrameT, class MapPointT>
     int Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0);
 
+    // Monocular initialisation's matcher (ORBmatcher.cc:409-524; called from Tracking::MonocularInitialization).  Frame
+    // members as for SearchByProjection.  The matching loop with its matched-distance gate and match take-over is one
+    // device call (guided-search mode 1); the rotation histogram and the vbPrevMatched update are host code.
+    template <class FrameT>
+    int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                int windowSize = 10);
+
     // The device call the templates make.  kp_taken / queries are in the order the reference visits them.
     struct GuidedQueries {
         std::vector<float> uvr;
@@ -96,7 +103,8 @@ public:
     static bool GuidedSearch(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& descriptors,
                              const std::vector<uint8_t>& kpTaken, float minX, float minY, float invW, float invH,
                              const GuidedQueries& q, int thDist, bool useRatio, float nnratio, std::vector<int>& matchKp,
-                             float chi2Gate = 0.f, const std::vector<float>* invLevelSigma2 = nullptr);
+                             float chi2Gate = 0.f, const std::vector<float>* invLevelSigma2 = nullptr, int mode = 0,
+                             std::vector<int>* acceptedKp = nullptr);
     static int LastStatus();
 
     static const int TH_LOW;
@@ -220,6 +228,51 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame
                     nmatches--;
                 }
     }
+    return nmatches;
+}
+
+template <class FrameT>
+int ORBmatcher::SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                        int windowSize) {
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = std::vector<int>(n1, -1);
+    GuidedQueries q;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        q.add(vbPrevMatched[i1].x, vbPrevMatched[i1].y, (float)windowSize, 0, 0, F1.mDescriptors.row(i1), false);
+        if (F1.mvKeysUn[i1].octave > 0) q.valid.back() = 0;   // ORBmatcher.cc:426-428: only level-0 keypoints are matched
+    }
+    std::vector<int> matchKp, acceptedKp;
+    const std::vector<uint8_t> none((size_t)n2, 0);
+    if (!GuidedSearch(F2.mvKeysUn, F2.mDescriptors, none, F2.mnMinX, F2.mnMinY, F2.mfGridElementWidthInv, F2.mfGridElementHeightInv, q,
+                      TH_LOW, false, mfNNratio, matchKp, 0.f, nullptr, 1, &acceptedKp))
+        return 0;
+    int nmatches = 0;
+    for (int i1 = 0; i1 < n1; ++i1) { vnMatches12[i1] = matchKp[i1]; nmatches += matchKp[i1] >= 0; }
+    if (mbCheckOrientation) {
+        // the reference bins a match when it is made (:467-477) -- also the ones a later query takes over, which stay in
+        // their bin (and count for the three maxima) but are skipped by the vnMatches12[idx1] >= 0 test below
+        std::vector<int> rotHist[30];
+        const float factor = 1.0f / HISTO_LENGTH;
+        for (int i1 = 0; i1 < n1; ++i1) {
+            if (acceptedKp[i1] < 0) continue;
+            float rot = F1.mvKeysUn[i1].angle - F2.mvKeysUn[acceptedKp[i1]].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(i1);
+        }
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                const int idx1 = rotHist[i][j];
+                if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; ++i1)   // update prev matched
+        if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt;
     return nmatches;
 }
 

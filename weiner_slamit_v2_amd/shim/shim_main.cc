@@ -8,6 +8,7 @@
 //     shim_test search <problem.bin> <out.bin>
 //     shim_test frame <problem.bin> <out.bin>
 //     shim_test fuse <problem.bin> <out.bin>
+//     shim_test init <problem.bin> <out.bin>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -517,6 +518,43 @@ static int run_fuse(int argc, char** argv) {
     return 0;
 }
 
+// problem.bin: int32 n1 n2 window ; float nnratio ; float bounds[6] ; F1: int32 octave[n1], float angle[n1], float prev[2 n1],
+//   u8 desc[32 n1] ; F2: float xy[2 n2], int32 octave[n2], float angle[n2], u8 desc[32 n2]
+// out.bin: int32 status nmatches ; int32 vnMatches12[n1] ; float prev[2 n1]
+static int run_init(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<unsigned char> raw = slurp(argv[2]);
+    Reader R{raw.data()};
+    const int n1 = R.get<int>(), n2 = R.get<int>(), window = R.get<int>();
+    const float nnratio = R.get<float>();
+    MockSearchFrame::mnMinX = R.get<float>(); MockSearchFrame::mnMaxX = R.get<float>();
+    MockSearchFrame::mnMinY = R.get<float>(); MockSearchFrame::mnMaxY = R.get<float>();
+    MockSearchFrame::mfGridElementWidthInv = R.get<float>(); MockSearchFrame::mfGridElementHeightInv = R.get<float>();
+    const int* o1 = R.arr<int>(n1); const float* a1 = R.arr<float>(n1); const float* prev = R.arr<float>(2 * (size_t)n1);
+    const unsigned char* d1 = R.arr<unsigned char>(32 * (size_t)n1);
+    const float* xy2 = R.arr<float>(2 * (size_t)n2); const int* o2 = R.arr<int>(n2); const float* a2 = R.arr<float>(n2);
+    const unsigned char* d2 = R.arr<unsigned char>(32 * (size_t)n2);
+    MockSearchFrame F1, F2;
+    F1.N = n1; F2.N = n2;
+    F1.mDescriptors = cv::Mat(n1, 32, CV_8U); F2.mDescriptors = cv::Mat(n2, 32, CV_8U);
+    F1.mvKeysUn.resize(n1); F2.mvKeysUn.resize(n2);
+    for (int i = 0; i < n1; ++i) { F1.mvKeysUn[i] = cv::KeyPoint(0.f, 0.f, 31.f, a1[i], 0, o1[i]); memcpy(F1.mDescriptors.ptr(i), d1 + 32 * (size_t)i, 32); }
+    for (int i = 0; i < n2; ++i) { F2.mvKeysUn[i] = cv::KeyPoint(xy2[2 * i], xy2[2 * i + 1], 31.f, a2[i], 0, o2[i]); memcpy(F2.mDescriptors.ptr(i), d2 + 32 * (size_t)i, 32); }
+    std::vector<cv::Point2f> vbPrevMatched(n1);
+    for (int i = 0; i < n1; ++i) vbPrevMatched[i] = cv::Point2f(prev[2 * i], prev[2 * i + 1]);
+    std::vector<int> vnMatches12;
+    ORBmatcher matcher(nnratio, true);
+    const int nm = matcher.SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, window);
+    const int status = ORBmatcher::LastStatus();
+    if (status != 0) fprintf(stderr, "init failed: %s\n", slamit_last_error());
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(&status, 4, 1, f); fwrite(&nm, 4, 1, f);
+    fwrite(vnMatches12.data(), 4, n1, f);
+    for (int i = 0; i < n1; ++i) { fwrite(&vbPrevMatched[i].x, 4, 1, f); fwrite(&vbPrevMatched[i].y, 4, 1, f); }
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
@@ -527,5 +565,6 @@ int main(int argc, char** argv) {
     if (mode == "search") return run_search(argc, argv);
     if (mode == "frame") return run_frame(argc, argv);
     if (mode == "fuse") return run_fuse(argc, argv);
+    if (mode == "init") return run_init(argc, argv);
     return 2;
 }

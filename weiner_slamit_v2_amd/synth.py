@@ -273,3 +273,24 @@ def synth_search(n_kp=1500, m=600, seed=0, width=640, height=480, th=3.0, crowd=
                  inv_w=float(inv_w), inv_h=float(inv_h))
     queries = dict(uvr=uvr, level_min=lmin, level_max=lmax, desc=qdesc, valid=valid, takes=takes)
     return frame, queries
+
+
+def synth_init_pair(n=1500, seed=0):
+    """Two frames for ORBmatcher::SearchForInitialization: F2's keypoints are F1's moved by a few pixels (plus clutter),
+    descriptors a few bits apart, so that several F1 keypoints compete for one F2 keypoint (the take-over path)."""
+    rs = np.random.RandomState(4000 + seed)
+    f2, _ = synth_search(n, 4, 50 + seed)
+    f2 = dict(f2)
+    f2["kp_octave"] = np.where(rs.rand(n) < 0.7, 0, rs.randint(1, 8, n)).astype(np.int32)
+    n1 = n
+    src = rs.randint(0, n, n1)
+    src[n1 // 2:] = src[:n1 - n1 // 2]                      # pairs of F1 keypoints aiming at the same F2 keypoint
+    o1 = np.where(rs.rand(n1) < 0.75, 0, rs.randint(1, 8, n1)).astype(np.int32)
+    prev = (f2["kp_xy"][src] + rs.uniform(-25, 25, (n1, 2))).astype(np.float32)
+    d1 = f2["desc"][src].copy()
+    for j in range(n1):
+        for b in rs.randint(0, 256, rs.randint(0, 45)):
+            d1[j, b >> 3] ^= np.uint8(1 << (b & 7))
+    f1 = dict(kp_octave=o1, desc=d1, angle=rs.uniform(0, 360, n1).astype(np.float32))
+    f2["angle"] = rs.uniform(0, 360, n).astype(np.float32)
+    return f1, prev, f2
