@@ -479,3 +479,85 @@ def test_shim_search_for_initialization(tmp_path):
     ok = e12 >= 0
     eprev[ok] = f2["kp_xy"][e12[ok]]
     assert np.array_equal(got_prev, eprev)
+
+
+@pytest.mark.gpu
+def test_shim_search_by_projection_relocalization(tmp_path):
+    """ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (Tracking::Relocalization)."""
+    from oracle import bindings as ob
+    from weiner_slamit_v2_amd import synth
+
+    _build()
+    f32 = np.float32
+    n, m, th, orbdist = 1500, 1000, 10.0, 100
+    rs = np.random.RandomState(18)
+    frame, _ = synth.synth_search(n, 4, 34)
+    scale = (f32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    fx, fy, cx, cy = f32(520.9), f32(521.0), f32(325.1), f32(249.7)
+    Rc, tc = synth.se3_exp(np.array([-0.02, 0.015, 0.01, 0.05, 0.02, -0.03]))
+    Rc, tc = Rc.astype(np.float32), tc.astype(np.float32)
+    Ow = np.array([-(Rc[0, r] * tc[0]) + -(Rc[1, r] * tc[1]) + -(Rc[2, r] * tc[2]) for r in range(3)], np.float32)
+    src = rs.randint(0, n, m)
+    depth = rs.uniform(2, 8, m)
+    px = frame["kp_xy"][src].astype(np.float64) + rs.uniform(-5, 5, (m, 2))
+    pc = np.stack([(px[:, 0] - cx) / fx * depth, (px[:, 1] - cy) / fy * depth, depth], 1)
+    world = ((pc - tc.astype(np.float64)) @ Rc.astype(np.float64)).astype(np.float32)
+    level = np.clip(frame["kp_octave"][src] + rs.randint(-1, 2, m), 0, 7).astype(np.int32)
+    angle_cur = rs.uniform(0, 360, n).astype(np.float32)
+    kang = ((angle_cur[src] + np.where(rs.rand(m) < 0.8, 12.0, rs.uniform(0, 360, m))) % 360.0).astype(np.float32)
+    has, bad, found = (rs.rand(m) < 0.9).astype(np.int32), (rs.rand(m) < 0.05).astype(np.int32), (rs.rand(m) < 0.1).astype(np.int32)
+    X, Y, Z = world[:, 0], world[:, 1], world[:, 2]
+    PO = np.stack([X - Ow[0], Y - Ow[1], Z - Ow[2]], 1)
+    d3 = np.sqrt((PO.astype(np.float64) ** 2).sum(1)).astype(np.float32)
+    maxd, mind = (d3 * f32(1.4)).astype(np.float32), (d3 * f32(0.7)).astype(np.float32)
+    maxd[::19] = d3[::19] * f32(0.9)
+    qdesc = frame["desc"][src].copy()
+    flip = rs.randint(0, 256, (m, 40))
+    for j in range(m):
+        for b in flip[j, :rs.randint(0, 40)]:
+            qdesc[j, b >> 3] ^= np.uint8(1 << (b & 7))
+    state = np.where(frame["kp_taken"] > 0, 1, np.where(rs.rand(n) < 0.1, 2, 0)).astype(np.int32)
+    Tcw = np.concatenate([Rc.reshape(-1), tc]).astype(np.float32)
+    blob = _search_frame_blob(2, frame, n, m, th, 0.9, scale, angle_cur, state, 645.1, 483.9)
+    blob += Tcw.tobytes() + np.array([fx, fy, cx, cy], np.float32).tobytes() + struct.pack("<i", orbdist)
+    blob += world.tobytes() + kang.tobytes() + maxd.tobytes() + mind.tobytes() + has.tobytes() + bad.tobytes() + found.tobytes() + level.tobytes()
+    blob += qdesc.tobytes()
+    pin, pout = tmp_path / "s.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "search", str(pin), str(pout)])
+    r = np.fromfile(pout, np.int32)
+    assert r[0] == 0
+    xc = ((Rc[0, 0] * X + Rc[0, 1] * Y) + Rc[0, 2] * Z) + tc[0]
+    yc = ((Rc[1, 0] * X + Rc[1, 1] * Y) + Rc[1, 2] * Z) + tc[1]
+    zc = ((Rc[2, 0] * X + Rc[2, 1] * Y) + Rc[2, 2] * Z) + tc[2]
+    invz = (1.0 / zc.astype(np.float64)).astype(np.float32)
+    u, v = (fx * xc) * invz + cx, (fy * yc) * invz + cy
+    ok = (has != 0) & (bad == 0) & (found == 0) & ~(u < f32(frame["min_x"])) & ~(u > f32(645.1)) & ~(v < f32(frame["min_y"])) & ~(v > f32(483.9))
+    ok &= ~((d3 < mind) | (d3 > maxd))
+    keep = np.nonzero(ok)[0]
+    assert 300 < len(keep) < m
+    q = dict(uvr=np.stack([u, v, f32(th) * scale[level]], 1)[keep], level_min=level[keep] - 1, level_max=level[keep] + 1, desc=qdesc[keep])
+    match, nm, _ = ob.guided_search(dict(frame, kp_taken=(state > 0).astype(np.uint8)), q, orbdist, False, 0.9)
+    full = np.full(m, -1, np.int32)
+    full[keep] = match
+    owner = _apply_in_order(n, state, full)
+    hist = [[] for _ in range(30)]
+    factor = f32(1.0) / f32(30)
+    for qi in keep:
+        k = full[qi]
+        if k < 0:
+            continue
+        rot = f32(kang[qi] - angle_cur[k])
+        if rot < 0:
+            rot = f32(rot + f32(360))
+        b = int(np.floor(f32(rot * factor) + f32(0.5)))
+        hist[0 if b == 30 else b].append(k)
+    sizes = [len(h) for h in hist]
+    order = sorted(range(30), key=lambda i: -sizes[i])
+    assert sizes[order[0]] > 100 and sizes[order[1]] < 0.1 * sizes[order[0]], "test premise: one dominant rotation bin"
+    for i in range(30):
+        if i != order[0]:
+            for k in hist[i]:
+                owner[k] = -1
+                nm -= 1
+    assert r[1] == nm and np.array_equal(r[2:], owner)

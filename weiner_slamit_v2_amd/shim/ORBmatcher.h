@@ -79,6 +79,13 @@ public:
     template <class KeyFrameT, class MapPointT>
     int Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0);
 
+    // Tracking::Relocalization's search (ORBmatcher.cc:1476-1603): the map points of a candidate keyframe projected into the
+    // current frame.  Additional members: KeyFrame : GetMapPointMatches(), mvKeysUn ; Frame : mfLogScaleFactor ;
+    // MapPoint : GetMaxDistanceInvariance(), GetMinDistanceInvariance(), PredictScale(dist, logScaleFactor).
+    // SetT is anything with count(MapPoint*) (std::set in the reference).
+    template <class FrameT, class KeyFrameT, class SetT>
+    int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const SetT& sAlreadyFound, const float th, const int ORBdist);
+
     // Monocular initialisation's matcher (ORBmatcher.cc:409-524; called from Tracking::MonocularInitialization).  Frame
     // members as for SearchByProjection.  The matching loop with its matched-distance gate and match take-over is one
     // device call (guided-search mode 1); the rotation histogram and the vbPrevMatched update are host code.
@@ -212,6 +219,76 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame
         nmatches++;
         if (mbCheckOrientation) {
             float rot = LastFrame.mvKeysUn[who[k]].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdx2);
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                    CurrentFrame.mvpMapPoints[rotHist[i][j]] = nullptr;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
+
+template <class FrameT, class KeyFrameT, class SetT>
+int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const SetT& sAlreadyFound, const float th, const int ORBdist) {
+    const int n = (int)CurrentFrame.mvKeysUn.size();
+    std::vector<uint8_t> taken(n, 0);
+    for (int i = 0; i < n; ++i) taken[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;   // :1543: any map point blocks the keypoint
+    float Rcw[3][3], tcw[3], Ow[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) Rcw[r][c] = CurrentFrame.mTcw.template at<float>(r, c);
+        tcw[r] = CurrentFrame.mTcw.template at<float>(r, 3);
+    }
+    for (int r = 0; r < 3; ++r) Ow[r] = -Rcw[0][r] * tcw[0] + -Rcw[1][r] * tcw[1] + -Rcw[2][r] * tcw[2];
+    const auto vpMPs = pKF->GetMapPointMatches();
+    GuidedQueries q;
+    std::vector<int> who;   // index into vpMPs (= keypoint of pKF)
+    for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+        auto* pMP = vpMPs[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+        const cv::Mat x3Dw = pMP->GetWorldPos();
+        const float X = x3Dw.template at<float>(0, 0), Y = x3Dw.template at<float>(1, 0), Z = x3Dw.template at<float>(2, 0);
+        const float xc = Rcw[0][0] * X + Rcw[0][1] * Y + Rcw[0][2] * Z + tcw[0];
+        const float yc = Rcw[1][0] * X + Rcw[1][1] * Y + Rcw[1][2] * Z + tcw[1];
+        const float zc = Rcw[2][0] * X + Rcw[2][1] * Y + Rcw[2][2] * Z + tcw[2];
+        const float invzc = 1.0 / zc;
+        const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+        const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        const float PO[3] = {X - Ow[0], Y - Ow[1], Z - Ow[2]};
+        const float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, CurrentFrame.mfLogScaleFactor);
+        const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+        q.add(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, pMP->GetDescriptor(), true);
+        who.push_back((int)i);
+    }
+    std::vector<int> matchKp;
+    if (!GuidedSearch(CurrentFrame.mvKeysUn, CurrentFrame.mDescriptors, taken, CurrentFrame.mnMinX, CurrentFrame.mnMinY,
+                      CurrentFrame.mfGridElementWidthInv, CurrentFrame.mfGridElementHeightInv, q, ORBdist, false, mfNNratio, matchKp))
+        return 0;
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (size_t k = 0; k < who.size(); ++k) {
+        const int bestIdx2 = matchKp[k];
+        if (bestIdx2 < 0) continue;
+        CurrentFrame.mvpMapPoints[bestIdx2] = vpMPs[who[k]];
+        nmatches++;
+        if (mbCheckOrientation) {
+            float rot = pKF->mvKeysUn[who[k]].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
             if (rot < 0.0) rot += 360.0f;
             int bin = (int)roundf(rot * factor);
             if (bin == HISTO_LENGTH) bin = 0;

@@ -250,8 +250,11 @@ static int run_pose(int argc, char** argv) {
 struct MockTrackPoint {
     bool mbTrackInView, bad;
     int mnTrackScaleLevel, nobs, id;
-    float mTrackViewCos, mTrackProjX, mTrackProjY;
+    float mTrackViewCos, mTrackProjX, mTrackProjY, maxd, mind;
     cv::Mat desc, pos;
+    float GetMaxDistanceInvariance() { return maxd; }
+    float GetMinDistanceInvariance() { return mind; }
+    int PredictScale(const float&, const float&) { return mnTrackScaleLevel; }   // the caller's method: stored level
     bool isBad() { return bad; }
     int Observations() { return nobs; }
     cv::Mat GetDescriptor() { return desc.clone(); }
@@ -264,8 +267,13 @@ struct MockSearchFrame {
     std::vector<MockTrackPoint*> mvpMapPoints;
     std::vector<float> mvuRight, mvScaleFactors;
     std::vector<bool> mvbOutlier;
-    float fx, fy, cx, cy, mb;
+    float fx, fy, cx, cy, mb, mfLogScaleFactor;
     static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+};
+struct MockRelocKF {
+    std::vector<MockTrackPoint*> matches;
+    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<MockTrackPoint*> GetMapPointMatches() { return matches; }
 };
 float MockSearchFrame::mnMinX, MockSearchFrame::mnMaxX, MockSearchFrame::mnMinY, MockSearchFrame::mnMaxY;
 float MockSearchFrame::mfGridElementWidthInv, MockSearchFrame::mfGridElementHeightInv;
@@ -295,6 +303,8 @@ static cv::Mat pose_from(const float* p12) {   // R row-major (9) then t (3)
 //   variant 0 (map points): float proj[2m] viewcos[m] ; int32 level[m] inview[m] bad[m] nobs[m] ; u8 desc[32m]
 //   variant 1 (last frame): float Tcw[12] Tlw[12] intr[5] ; int32 mono ; float world[3m] angle[m] ;
 //                           int32 has[m] outlier[m] octave[m] nobs[m] ; u8 desc[32m]
+//   variant 2 (relocalization, keyframe map points): float Tcw[12] intr[4] ; int32 orbdist ; float world[3m] angle[m] maxd[m]
+//                           mind[m] ; int32 has[m] bad[m] found[m] level[m] ; u8 desc[32m]
 // out.bin: int32 status nmatches ; int32 owner[n] (-1 none, -2 the frame's own earlier point, else query index)
 static int run_search(int argc, char** argv) {
     if (argc < 4) return 2;
@@ -342,6 +352,29 @@ static int run_search(int argc, char** argv) {
         }
         ORBmatcher matcher(nnratio, true);
         nm = matcher.SearchByProjection(F, vp, th);
+    } else if (variant == 2) {
+        const float* Tcw = R.arr<float>(12); const float* intr = R.arr<float>(4);
+        const int orbdist = R.get<int>();
+        const float* world = R.arr<float>(3 * (size_t)m); const float* kang = R.arr<float>(m);
+        const float* maxd = R.arr<float>(m); const float* mind = R.arr<float>(m);
+        const int* has = R.arr<int>(m); const int* bad = R.arr<int>(m); const int* found = R.arr<int>(m); const int* level = R.arr<int>(m);
+        const unsigned char* qd = R.arr<unsigned char>(32 * (size_t)m);
+        F.mTcw = pose_from(Tcw);
+        F.fx = intr[0]; F.fy = intr[1]; F.cx = intr[2]; F.cy = intr[3]; F.mfLogScaleFactor = 0.18232f;
+        MockRelocKF KF;
+        KF.matches.assign(m, (MockTrackPoint*)0); KF.mvKeysUn.resize(m);
+        std::set<MockTrackPoint*> sFound;
+        for (int q = 0; q < m; ++q) {
+            MockTrackPoint& p = mps[q];
+            p.id = q; p.bad = bad[q] != 0; p.mnTrackScaleLevel = level[q]; p.maxd = maxd[q]; p.mind = mind[q]; p.nobs = 1;
+            p.pos = mat_from(world + 3 * (size_t)q, 3);
+            p.desc = cv::Mat(1, 32, CV_8U); memcpy(p.desc.ptr(0), qd + 32 * (size_t)q, 32);
+            KF.mvKeysUn[q] = cv::KeyPoint(0.f, 0.f, 31.f, kang[q], 0, 0);
+            if (has[q]) KF.matches[q] = &p;
+            if (found[q]) sFound.insert(&p);
+        }
+        ORBmatcher matcher(0.9f, true);
+        nm = matcher.SearchByProjection(F, &KF, sFound, th, orbdist);
     } else {
         const float* Tcw = R.arr<float>(12); const float* Tlw = R.arr<float>(12); const float* intr = R.arr<float>(5);
         const int mono = R.get<int>();
