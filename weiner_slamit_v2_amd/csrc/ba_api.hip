@@ -110,7 +110,7 @@ int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int de
     h->max_kf = max_kf; h->max_pt = max_pt; h->max_edge = max_edge; h->max_batch = max_batch;
     h->Npad_max = (int)rup((size_t)6 * max_kf + 1, BA_TILE);
     h->Kpad_max = (int)rup((size_t)3 * max_pt, (size_t)BA_KC * BA_SPLITS);
-    h->n_part = std::max((max_edge + 255) / 256, (std::max(max_pt, max_kf) + 255) / 256) + 1;
+    h->n_part = std::max((max_edge + 255) / 256, (std::max(8 * max_pt, max_kf) + 255) / 256) + 1;   // 8 = BA_PG lanes per point
     if (bak_ldlt_smem(h->Npad_max) > 160 * 1024 - 2048) {
         delete h;
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_create: max_kf too large for the LDS-resident LDLt panel");

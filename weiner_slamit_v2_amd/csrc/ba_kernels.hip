@@ -95,23 +95,38 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
     atomicMax(p, (unsigned long long)__double_as_longlong(fabs(v)));
 }
 
-// ---- S2: landmark blocks Hll, bl (thread per point, fixed edge order) ---------------------------
+// ---- S2: landmark blocks Hll, bl: BA_PG lanes per point (lane g takes edges g, g + BA_PG, ... of the point's list, then a
+// fixed xor-shuffle tree), so a 50-observation point is 7 serial edges instead of 50 and a wave covers 8 points -------
+#define BA_PG 8
+__device__ __forceinline__ double group_sum(double v) {   // sum over the BA_PG consecutive lanes of a point group
+#pragma unroll
+    for (int d = 1; d < BA_PG; d <<= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_point_reduce(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
     BaState* st = W.st;
     if (st->done || !st->need_linearize) return;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= W.n_pt) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int p = t / BA_PG, g = t % BA_PG;
+    const bool live = p < W.n_pt;
     double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    for (int i = W.pt_ptr[p]; i < W.pt_ptr[p + 1]; ++i) {
-        const int e = W.pt_edges[i];
-        if (!W.e_active[e]) continue;
-        const double* J = W.e_jac + 21 * (size_t)e;
-        const double wO = J[18], r0 = J[19], r1 = J[20];
-        b[0] += J[0] * r0 + J[3] * r1; b[1] += J[1] * r0 + J[4] * r1; b[2] += J[2] * r0 + J[5] * r1;
-        h[0] += (J[0] * J[0] + J[3] * J[3]) * wO; h[1] += (J[0] * J[1] + J[3] * J[4]) * wO; h[2] += (J[0] * J[2] + J[3] * J[5]) * wO;
-        h[3] += (J[1] * J[1] + J[4] * J[4]) * wO; h[4] += (J[1] * J[2] + J[4] * J[5]) * wO; h[5] += (J[2] * J[2] + J[5] * J[5]) * wO;
-    }
+    if (live)
+        for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
+            const int e = W.pt_edges[i];
+            if (!W.e_active[e]) continue;
+            const double* J = W.e_jac + 21 * (size_t)e;
+            const double wO = J[18], r0 = J[19], r1 = J[20];
+            b[0] += J[0] * r0 + J[3] * r1; b[1] += J[1] * r0 + J[4] * r1; b[2] += J[2] * r0 + J[5] * r1;
+            h[0] += (J[0] * J[0] + J[3] * J[3]) * wO; h[1] += (J[0] * J[1] + J[3] * J[4]) * wO; h[2] += (J[0] * J[2] + J[3] * J[5]) * wO;
+            h[3] += (J[1] * J[1] + J[4] * J[4]) * wO; h[4] += (J[1] * J[2] + J[4] * J[5]) * wO; h[5] += (J[2] * J[2] + J[5] * J[5]) * wO;
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = group_sum(h[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b[i] = group_sum(b[i]);
+    if (!live || g != 0) return;
     for (int i = 0; i < 6; ++i) W.Hll[6 * (size_t)p + i] = h[i];
     for (int i = 0; i < 3; ++i) W.bl[3 * (size_t)p + i] = b[i];
     if (st->it == 0) {
@@ -182,27 +197,30 @@ __device__ __forceinline__ void hpl_of(const double* J, double* H /*6x3*/) {
         for (int j = 0; j < 3; ++j) H[3 * i + j] = (J[6 + i] * J[j] + J[12 + i] * J[3 + j]) * wO;
 }
 
-__global__ __launch_bounds__(128) void k_prepare(BaWin* wins) {
+__global__ __launch_bounds__(256) void k_prepare(BaWin* wins) {   // BA_PG lanes per point, like k_point_reduce
     const BaWin& W = wins[blockIdx.y];
     BaState* st = W.st;
     if (st->done) return;
-    const int p = blockIdx.x * 128 + threadIdx.x;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int p = t / BA_PG, g = t % BA_PG;
     if (p >= W.n_pt) return;
     const double lambda = st->lambda;
     const double* h = W.Hll + 6 * (size_t)p;
     const double a = h[0] + lambda, b = h[1], c = h[2], d = h[3] + lambda, e_ = h[4], f = h[5] + lambda;
-    // symmetric 3x3 inverse by cofactors
+    // symmetric 3x3 inverse by cofactors (every lane of the group computes it: cheaper than a broadcast)
     const double c0 = d * f - e_ * e_, c1 = e_ * c - b * f, c2 = b * e_ - d * c;
     const double det = a * c0 + b * c1 + c * c2;
     const double id = 1.0 / det;
     double Di[6];
     Di[0] = c0 * id; Di[1] = c1 * id; Di[2] = c2 * id;
     Di[3] = (a * f - c * c) * id; Di[4] = (b * c - a * e_) * id; Di[5] = (a * d - b * b) * id;
-    for (int i = 0; i < 6; ++i) W.Dinv[6 * (size_t)p + i] = Di[i];
-    const double* bl = W.bl + 3 * (size_t)p;
     const size_t K = (size_t)W.Kpad;
-    for (int j = 0; j < 3; ++j) W.GB[(size_t)W.nS * K + 3 * (size_t)p + j] = bl[j];
-    for (int i = W.pt_ptr[p]; i < W.pt_ptr[p + 1]; ++i) {
+    if (g == 0) {
+        for (int i = 0; i < 6; ++i) W.Dinv[6 * (size_t)p + i] = Di[i];
+        const double* bl = W.bl + 3 * (size_t)p;
+        for (int j = 0; j < 3; ++j) W.GB[(size_t)W.nS * K + 3 * (size_t)p + j] = bl[j];
+    }
+    for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
         const int e = W.pt_edges[i];
         if (!W.e_active[e]) continue;
         const int col = W.pose_col[W.e_kf[e]];
@@ -657,31 +675,38 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
 }
 
 // ---- S9: landmark back-substitution, push(), oplus ------------------------------------------------
-__global__ __launch_bounds__(256) void k_backsub_update(BaWin* wins) {
+__global__ __launch_bounds__(256) void k_backsub_update(BaWin* wins) {   // BA_PG lanes per point; thread t < n_kf also moves pose t
     const BaWin& W = wins[blockIdx.y];
     BaState* st = W.st;
     if (st->done) return;
     __shared__ double sh[4];
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int p = t / BA_PG, g = t % BA_PG;
     const bool ok = st->ok2 != 0;
     const double lambda = st->lambda;
+    const bool live = p < W.n_pt;
+    double cl[3] = {0, 0, 0};
+    if (live && ok) {
+        for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
+            const int e = W.pt_edges[i];
+            if (!W.e_active[e]) continue;
+            const int col = W.pose_col[W.e_kf[e]];
+            if (col < 0) continue;
+            double H[18];
+            hpl_of(W.e_jac + 21 * (size_t)e, H);
+            const double* xp = W.rhs + 6 * col;
+            for (int j = 0; j < 3; ++j)
+                for (int r = 0; r < 6; ++r) cl[j] -= H[3 * r + j] * xp[r];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cl[j] = group_sum(cl[j]);
     double scale = 0;
-    if (p < W.n_pt) {
+    if (live && g == 0) {
         const double* bl = W.bl + 3 * (size_t)p;
-        double cl[3] = {bl[0], bl[1], bl[2]};
         double xl[3] = {0, 0, 0};
         if (ok) {
-            for (int i = W.pt_ptr[p]; i < W.pt_ptr[p + 1]; ++i) {
-                const int e = W.pt_edges[i];
-                if (!W.e_active[e]) continue;
-                const int col = W.pose_col[W.e_kf[e]];
-                if (col < 0) continue;
-                double H[18];
-                hpl_of(W.e_jac + 21 * (size_t)e, H);
-                const double* xp = W.rhs + 6 * col;
-                for (int j = 0; j < 3; ++j)
-                    for (int r = 0; r < 6; ++r) cl[j] -= H[3 * r + j] * xp[r];
-            }
+            for (int j = 0; j < 3; ++j) cl[j] += bl[j];
             const double* Di = W.Dinv + 6 * (size_t)p;
             xl[0] = Di[0] * cl[0] + Di[1] * cl[1] + Di[2] * cl[2];
             xl[1] = Di[1] * cl[0] + Di[3] * cl[1] + Di[4] * cl[2];
@@ -695,13 +720,13 @@ __global__ __launch_bounds__(256) void k_backsub_update(BaWin* wins) {
             W.pt[3 * (size_t)p + j] = v + xl[j];
         }
     }
-    if (p < W.n_kf) {
+    if (t < W.n_kf) {
         double T[7];
-        for (int i = 0; i < 7; ++i) { T[i] = W.pose[7 * (size_t)p + i]; W.pose_bak[7 * (size_t)p + i] = T[i]; }
-        const int col = W.pose_col[p];
+        for (int i = 0; i < 7; ++i) { T[i] = W.pose[7 * (size_t)t + i]; W.pose_bak[7 * (size_t)t + i] = T[i]; }
+        const int col = W.pose_col[t];
         if (col >= 0 && ok) {
             pose_oplus(T, W.rhs + 6 * col);
-            for (int i = 0; i < 7; ++i) W.pose[7 * (size_t)p + i] = T[i];
+            for (int i = 0; i < 7; ++i) W.pose[7 * (size_t)t + i] = T[i];
         }
     }
     const double tot = block_sum_256(scale, sh);
@@ -741,7 +766,7 @@ __global__ __launch_bounds__(256) void k_decide(BaWin* wins) {
     __shared__ double sh[4];
     __shared__ int s_reject;
     const int tid = threadIdx.x;
-    const int ne_blocks = (W.n_edge + 255) / 256, np_blocks = (W.n_pt + 255) / 256;
+    const int ne_blocks = (W.n_edge + 255) / 256, np_blocks = (W.n_pt * BA_PG + 255) / 256;
     double tempChi = sum_parts(W.chi_part, ne_blocks, sh);
     double scale = sum_parts(W.scale_part, np_blocks, sh);
     double ps = 0;
@@ -881,17 +906,17 @@ void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int st
 
 // one LM trial slot for every window of the batch
 void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad) {
-    const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt + 255) / 256, nwin);
+    const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt * BA_PG + 255) / 256, nwin);
     hipLaunchKernelGGL(k_linearize, ge, dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_point_reduce, gp, dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(64), 0, st, wins);
     hipLaunchKernelGGL(k_iter_begin, dim3(1, nwin), dim3(64), 0, st, wins);
-    hipLaunchKernelGGL(k_prepare, dim3((max_pt + 127) / 128, nwin), dim3(128), 0, st, wins);
+    hipLaunchKernelGGL(k_prepare, gp, dim3(256), 0, st, wins);
     const int T = Npad / BA_TILE;
     hipLaunchKernelGGL(k_schur, dim3(T * (T + 1) / 2, BA_SPLITS, nwin), dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_ldlt_solve, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);
-    const int nb = (max_pt > max_kf ? max_pt : max_kf);
+    const int nb = (max_pt * BA_PG > max_kf ? max_pt * BA_PG : max_kf);
     hipLaunchKernelGGL(k_backsub_update, dim3((nb + 255) / 256, nwin), dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_errors, ge, dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_decide, dim3(1, nwin), dim3(256), 0, st, wins);
