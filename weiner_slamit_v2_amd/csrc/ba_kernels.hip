@@ -135,8 +135,23 @@ __global__ __launch_bounds__(256) void k_point_reduce(BaWin* wins) {
     }
 }
 
-// ---- S3: pose blocks Hpp, bp (one wavefront per keyframe, lane-strided + shuffle tree) ----------
-__global__ __launch_bounds__(64) void k_pose_reduce(BaWin* wins) {
+// ---- S3: pose blocks Hpp, bp: one workgroup of 256 threads per keyframe.  Thread-strided edge loop, then every 16-lane row
+// is summed with four DPP exchanges (no LDS round trip) and the 16 row sums of the workgroup are added in a fixed order ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {   // all 16 lanes of a DPP row end up with the row's sum
+    v += dpp_d<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);   // row_half_mirror
+    v += dpp_d<0x140>(v);   // row_mirror
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_pose_reduce(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
     BaState* st = W.st;
     if (st->done || !st->need_linearize) return;
@@ -144,31 +159,42 @@ __global__ __launch_bounds__(64) void k_pose_reduce(BaWin* wins) {
     if (kf >= W.n_kf) return;
     const int col = W.pose_col[kf];
     if (col < 0) return;
-    double h[21], b[6];
-    for (int i = 0; i < 21; ++i) h[i] = 0;
-    for (int i = 0; i < 6; ++i) b[i] = 0;
-    for (int i = W.kf_ptr[kf] + (int)threadIdx.x; i < W.kf_ptr[kf + 1]; i += 64) {
+    __shared__ double s_rows[27][16];
+    const int tid = threadIdx.x;
+    double acc[27];   // b[6] then the 21 upper-triangular entries of H
+    for (int i = 0; i < 27; ++i) acc[i] = 0;
+    for (int i = W.kf_ptr[kf] + tid; i < W.kf_ptr[kf + 1]; i += 256) {
         const int e = W.kf_edges[i];
         if (!W.e_active[e]) continue;
         const double* J = W.e_jac + 21 * (size_t)e;
         const double wO = J[18], r0 = J[19], r1 = J[20];
-        int k = 0;
+        int k = 6;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            b[a] += J[6 + a] * r0 + J[12 + a] * r1;
+            acc[a] += J[6 + a] * r0 + J[12 + a] * r1;
 #pragma unroll
-            for (int c = a; c < 6; ++c) h[k++] += (J[6 + a] * J[6 + c] + J[12 + a] * J[12 + c]) * wO;
+            for (int c = a; c < 6; ++c) acc[k++] += (J[6 + a] * J[6 + c] + J[12 + a] * J[12 + c]) * wO;
         }
     }
-    for (int i = 0; i < 21; ++i) h[i] = wave_sum(h[i]);
-    for (int i = 0; i < 6; ++i) b[i] = wave_sum(b[i]);
-    if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+        const double r = row16_sum(acc[i]);
+        if ((tid & 15) == 0) s_rows[i][tid >> 4] = r;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        double v = 0;
+        for (int j = 0; j < 16; ++j) v += s_rows[tid][j];
+        s_rows[tid][0] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
         double* H = W.Hpp + 36 * (size_t)col;
-        int k = 0;
+        int k = 6;
         double m = 0;
         for (int a = 0; a < 6; ++a)
-            for (int c = a; c < 6; ++c) { H[6 * a + c] = h[k]; H[6 * c + a] = h[k]; if (a == c) m = fmax(m, fabs(h[k])); ++k; }
-        for (int a = 0; a < 6; ++a) W.bp[6 * (size_t)col + a] = b[a];
+            for (int c = a; c < 6; ++c) { const double v = s_rows[k][0]; H[6 * a + c] = v; H[6 * c + a] = v; if (a == c) m = fmax(m, fabs(v)); ++k; }
+        for (int a = 0; a < 6; ++a) W.bp[6 * (size_t)col + a] = s_rows[a][0];
         if (st->it == 0) atomic_max_bits(&st->maxdiag_bits, m);
     }
 }
@@ -909,7 +935,7 @@ void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int
     const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt * BA_PG + 255) / 256, nwin);
     hipLaunchKernelGGL(k_linearize, ge, dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_point_reduce, gp, dim3(256), 0, st, wins);
-    hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(64), 0, st, wins);
+    hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_iter_begin, dim3(1, nwin), dim3(64), 0, st, wins);
     hipLaunchKernelGGL(k_prepare, gp, dim3(256), 0, st, wins);
     const int T = Npad / BA_TILE;
