@@ -588,11 +588,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r = 16 * frt + lk + 4 * g, c = 16 * fct + l15;
-#ifdef LD_X_NOMEM
-                    C[g] = 0.0;
-#else
                     C[g] = (r < rows && c < below && c <= r) ? S[(size_t)(base + r) * N + base + c] : 0.0;
-#endif
                 }
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) B[ks] = Wd[(16 * fct + l15) * LD_P + 4 * ks + lk];
@@ -608,21 +604,12 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
                 if (nct >= min(rt + 1, CT)) { nrt = rt + 1; nct = 0; }
                 if (t + 1 < tend) load_tile(nrt, nct, cn, bn);
                 double4_t acc = cc;
-#ifdef LD_X_NOMFMA
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc[ks & 3] += af[ks] * bc[ks];
-#else
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bc[ks], acc, 0, 0, 0);
-#endif
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r = 16 * rt + lk + 4 * g, c = 16 * ct + l15;
-#ifdef LD_X_NOMEM
-                    if (r == -1) S[c] = acc[g];
-#else
                     if (r < rows && c < below && c <= r) S[(size_t)(base + r) * N + base + c] = acc[g];
-#endif
                 }
                 cc = cn;
 #pragma unroll
