@@ -1,0 +1,39 @@
+"""Randomised BA / pose parity stress: random windows against the CPU oracle (tolerance 1e-5 relative, same iteration counts)."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle import bindings as ob  # noqa: E402
+from weiner_slamit_v2_amd import api, synth  # noqa: E402
+
+t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 120)
+rs = np.random.RandomState(777)
+opt = api.Optimizer(64, 2048, 110000, 1, 0)
+bad, it, worst = [], 0, 0.0
+while time.time() < t_end:
+    it += 1
+    seed = int(rs.randint(0, 1 << 30))
+    nk, npt = int(rs.randint(3, 51)), int(rs.randint(20, 1200))
+    obs = None if rs.rand() < 0.2 else int(rs.randint(2, min(nk, 12) + 1))
+    prob = synth.synth_ba(nk, npt, obs, outlier_frac=float(rs.choice([0.0, 0.03, 0.1])), seed=seed, n_fixed=int(rs.randint(1, min(nk, 4))))
+    g = opt.LocalBundleAdjustment(prob)
+    o = ob.ba_solve(prob)
+    same_its = list(g["stats"]["n_its"]) == list(o["stats"]["n_its"])
+    dp = np.abs(g["kf_pose"] - o["kf_pose"]).max() / max(np.abs(o["kf_pose"]).max(), 1.0)
+    dx = np.abs(g["pt_xyz"] - o["pt_xyz"]).max() / max(np.abs(o["pt_xyz"]).max(), 1.0)
+    worst = max(worst, dp, dx)
+    if not same_its or dp > 1e-5 or dx > 1e-5 or not np.array_equal(g["edge_outlier"], o["edge_outlier"]):
+        bad.append(("ba", seed, nk, npt, obs, same_its, float(dp), float(dx)))
+    pp = synth.synth_pose(int(rs.randint(3, 1500)), float(rs.choice([0.0, 0.15, 0.4])), seed % 100000, float(rs.choice([0.01, 0.05])))
+    gp = api.Optimizer.PoseOptimization([pp])[0]
+    op = ob.pose_solve(pp)
+    dpp = np.abs(gp["pose"] - op["pose"]).max() / max(np.abs(op["pose"]).max(), 1.0)
+    worst = max(worst, dpp)
+    if gp["n_inliers"] != op["n_inliers"] or dpp > 1e-5 or not np.array_equal(gp["outlier"], op["outlier"]):
+        bad.append(("pose", seed, float(dpp), gp["n_inliers"], op["n_inliers"]))
+print("iterations %d, failures %d, worst relative difference %.2e" % (it, len(bad), worst))
+for x in bad[:20]:
+    print(x)
+sys.exit(1 if bad else 0)
