@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent 640x480 streams per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) for real runs; gloo only to rehearse the multi-rank flow with ranks sharing one GPU")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="vga",
                     help="vga = the headline metric's configuration; 720p = BASELINE configs[2] (profiling run)")
     args = ap.parse_args()
@@ -185,11 +187,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":   # rehearsal: every rank on GPU 0, summary tensors on the host
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    cdev = torch.device("cpu") if (world > 1 and args.backend == "gloo") else dev   # where collective tensors live
 
     from weiner_slamit_v2_amd import api, shard, synth
 
@@ -210,7 +218,7 @@ def main():
     d_idx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_best = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_second = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    gather = shard.SummaryGather(B, 2, dev, world)  # per-frame (keypoints, matches) to every rank
+    gather = shard.SummaryGather(B, 2, cdev, world)  # per-frame (keypoints, matches) to every rank
     # ONE non-default stream carries the whole step: extract(k) -> match(k) are ordered by the stream.  (A NULL
     # stream handle would mean "the extractor's own stream" to the C-ABI and un-order the two calls.)
     tstream = torch.cuda.Stream(dev)
@@ -265,7 +273,7 @@ def main():
     torch.cuda.synchronize(dev)
     match_ms = m0.elapsed_time(m1) / 5
 
-    elapsed = shard.max_over_ranks(elapsed, dev, world)
+    elapsed = shard.max_over_ranks(elapsed, cdev, world)
 
     # sanity of the timed work: every frame produced its keypoints and matches
     n_last = d_n[(args.warmup + args.steps - 1) & 1].cpu().numpy()

@@ -1,0 +1,43 @@
+"""bench.py contract checks on the GPU box: the JSON line's schema at N = 1 and the multi-rank flow rehearsed with two
+ranks sharing the GPU (gloo carries the summary; the real run uses nccl = RCCL with one GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def _line(out):
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_schema_single_gpu():
+    out = subprocess.check_output([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-ba"], cwd=ROOT,
+                                  stderr=subprocess.STDOUT, timeout=300)
+    d = _line(out)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "u8" and d["scaling"] == "weak" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["launches"] >= 1
+    assert abs(d["value"] - 64 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 0.01
+
+
+def test_bench_two_rank_rehearsal():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29713", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--no-cpu", "--no-ba"]
+    out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=600, env=env)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["steps"] == 3
+    assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # whole-job aggregate over both ranks
