@@ -110,3 +110,31 @@ def test_full_size_batch_properties():
             assert np.array_equal(ks[j], k1) and np.array_equal(ds[j], d1)
     ks2, ds2 = ext.extract_batch(frames)
     assert all(np.array_equal(a, b) for a, b in zip(ds, ds2))
+
+
+def test_error_codes_of_the_frame_and_search_entry_points():
+    L = api.lib()
+    cam = api.Camera(500, 500, 320, 240, 0.1, 0, 0, 0, 0)
+    xy = np.zeros((4, 2), np.float32)
+    assert L.slamit_undistort_points(0, None, xy.ctypes.data, 4, xy.ctypes.data) == -1
+    assert L.slamit_undistort_points(0, C.byref(cam), None, 4, xy.ctypes.data) == -1
+    assert L.slamit_undistort_points(0, C.byref(cam), None, 0, None) == 0
+    start = np.zeros(64 * 48 + 1, np.int32)
+    assert L.slamit_frame_finish(0, C.byref(cam), None, 0, 0.0, 0.0, 0.1, 0.1, None, start.ctypes.data, None) == 0 and start[-1] == 0
+    assert L.slamit_frame_finish(0, C.byref(cam), None, 5, 0.0, 0.0, 0.1, 0.1, None, start.ctypes.data, None) == -1
+    assert L.slamit_frame_finish_batch_dev(0, C.byref(cam), None, None, 10, 2, 0.0, 0.0, 0.1, 0.1, None, None, None, None) == -1
+    rule = api._search_rule(100, True, 0.8)
+    nm = C.c_int32(7)
+    assert L.slamit_guided_search(0, None, None, C.byref(rule), None, C.byref(nm), None, None, None, None) == -1
+    fv = api.FrameView(0, None, None, None, None, 0, 0, 0.1, 0.1)
+    sq = api.SearchQueries(0, None, None, None, None, None, None)
+    assert L.slamit_guided_search(0, C.byref(fv), C.byref(sq), C.byref(rule), None, C.byref(nm), None, None, None, None) == 0 and nm.value == 0
+    sq.m = 3   # queries announced but no arrays
+    assert L.slamit_guided_search(0, C.byref(fv), C.byref(sq), C.byref(rule), None, C.byref(nm), None, None, None, None) == -1
+    assert L.slamit_guided_search_workspace(-1, 10) == 0 and L.slamit_guided_search_workspace(2, 10) > 2 * 10 * 8 * 128
+    assert L.slamit_guided_search_batch_dev(0, None, C.byref(rule), None, None, None, None, 0, None) == -1
+    # a mismatched array length is caught by the Python binding before it reaches the C-ABI
+    f, q = synth.synth_search(50, 20, 1)
+    q = dict(q, level_min=q["level_min"][:5])
+    with pytest.raises(api.SlamitError):
+        api.ORBmatcher.guided_search(f, q)
