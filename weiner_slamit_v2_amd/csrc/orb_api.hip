@@ -253,7 +253,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         h->levels[l].plane_bytes = h->pyr_frame_total;   // stride between frames of the same level
         h->levels[l].blur_bytes = h->blur_frame_total;
     }
-    if (orbk_octree_smem(h->node_cap) > 160 * 1024 - 1024) {
+    if (orbk_octree_smem(h->node_cap) > 160 * 1024 - 1024 || h->node_cap >= 4096) {   // labels carry the node in 12 bits
         orb_free(h);
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: nfeatures too large for the LDS octree");
     }

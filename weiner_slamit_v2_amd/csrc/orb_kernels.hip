@@ -735,6 +735,7 @@ __device__ __forceinline__ void octree_body(
                 int mx, my;
                 int q = box_quadrant(box[cur][nd], xy & 0xFFFF, xy >> 16, &mx, &my);
                 atomicAdd(&childcnt[nd * 4 + q], 1);
+                ND[k] = (uint16_t)(nd | ((q + 1) << 12));   // the quadrant rides in the label's top bits until the re-label sweep
             }
         }
         __syncthreads();
@@ -844,13 +845,11 @@ __device__ __forceinline__ void octree_body(
         OD_STAMP(3);
         // re-label the keys
         for (int k = tid; k < n_keys; k += NT) {
-            int nd = ND[k];
-            bool split = !careful ? (cnt[cur][nd] > 1) : (rankv[nd] >= 0 && rankv[nd] < kproc);
+            const int lab = ND[k];
+            const int nd = lab & 4095, q = (lab >> 12) - 1;   // q >= 0 exactly for keys of expandable nodes (cnt > 1)
+            bool split = !careful ? (q >= 0) : (rankv[nd] >= 0 && rankv[nd] < kproc);
             int pos;
             if (split) {
-                uint32_t xy = XY[k];
-                int mx, my;
-                int q = box_quadrant(box[cur][nd], xy & 0xFFFF, xy >> 16, &mx, &my);
                 int e = !careful ? ((n - 1 - nd) * 4 + (3 - q)) : ((kproc - 1 - rankv[nd]) * 4 + (3 - q));
                 pos = scanbuf[e];
             } else {
