@@ -118,6 +118,20 @@ def cpu_baseline_ba(prob):
             "sample": "1 window, %.0f ms" % (1e3 * el)}
 
 
+def cpu_baseline_ba_reference(prob):
+    """The reference's own g2o (oracle/_ref/libba_ref.so, built from /root/reference in the authoring container and
+    shipped with the snapshot) on one host core, one window; None when the library is not there."""
+    from oracle import bindings as ob
+
+    if not ob.ba_ref_available():
+        return None
+    t0 = time.perf_counter()
+    r = ob.ba_ref_solve(prob)
+    el = time.perf_counter() - t0
+    return {"value": round(sum(r["stats"]["n_its"]) / el, 1), "unit": "iters/s", "cores": 1, "kind": "reference",
+            "sample": "1 window, %.0f ms (vendored g2o + Eigen of the reference)" % (1e3 * el)}
+
+
 def ba_secondary(device, steps, with_cpu=True):
     """local-BA LM iterations/sec on BASELINE config 4 (50 KF x 2000 points): window-8 visibility
     (16,000 edges) and dense visibility (100,000 edges), single window and a batch of 8 windows,
@@ -155,6 +169,10 @@ def ba_secondary(device, steps, with_cpu=True):
             if with_cpu:
                 entry["cpu_baseline"] = cpu_baseline_ba(prob)
                 entry["speedup_vs_cpu_1core"] = round(entry["value"] / entry["cpu_baseline"]["value"], 1)
+                ref = cpu_baseline_ba_reference(prob)
+                if ref:
+                    entry["cpu_baseline_reference"] = ref
+                    entry["speedup_vs_reference_g2o_1core"] = round(entry["value"] / ref["value"], 1)
             out[name] = entry
             opt.close()
         out["value"] = out["window8"]["value"]
