@@ -30,6 +30,8 @@ def load_ba_golden(path):
                      "lambda": [list(z["ref_lambda"][s][:n[s]]) for s in range(2)],
                      "trials": [[int(v) for v in z["ref_trials"][s][:n[s]]] for s in range(2)],
                      "chi2_init": list(z["ref_chi2_init"])}}
+    if "schedule" in z.files:   # (its_robust, its_final, huber_delta) the reference was run with; absent = local-BA defaults
+        ref["schedule"] = (int(z["schedule"][0]), int(z["schedule"][1]), float(z["schedule"][2]))
     return prob, ref
 
 

@@ -54,7 +54,8 @@ def opt():
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[3:-4] for p in GOLDEN])
 def test_vs_reference_g2o_golden(opt, path):
     prob, ref = load_ba_golden(path)
-    _close(opt.LocalBundleAdjustment(prob), ref, os.path.basename(path))
+    sched = ref.get("schedule", (5, 10, api.HUBER_MONO))   # the global-BA fixtures carry (nIterations, 0, sqrt(5.99))
+    _close(opt.LocalBundleAdjustment(prob, *sched), ref, os.path.basename(path))
 
 
 @pytest.mark.parametrize("k,p,o,seed,nfix", [(6, 80, 3, 31, 1), (20, 400, 6, 32, 2), (33, 700, None, 33, 1)])

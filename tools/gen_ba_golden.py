@@ -24,7 +24,13 @@ CASES = {
     "rejects": (8, 150, 4, 13, 1, 60.0),    # very large initial error: LM iterations with 3-4 rejected trials
     "allout": (8, 150, 4, 11, 1, 200.0),    # hopeless start: every edge fails the gate, stage 2 has nothing to do
     "window8": (50, 2000, 8, 12345, 1, 1.0),  # BASELINE config 4 geometry, 16,000 edges
+    # Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (Optimizer.cc:40-238): ONE optimize(nIterations), Huber delta
+    # sqrt(5.99), keyframe 0 fixed -- the same solve with schedule (nIterations, 0)
+    "global_init": (2, 150, None, 21, 1, 1.0),   # Tracking::CreateInitialMapMonocular: 2 keyframes, GlobalBundleAdjustemnt(mpMap, 20)
+    "global_map": (14, 500, 5, 22, 1, 4.0),      # a small map, 10 iterations
 }
+# name -> (its_robust, its_final, huber_delta); everything else uses the local-BA schedule of Optimizer.cc:507-743
+SCHEDULE = {"global_init": (20, 0, float(np.float32(np.sqrt(5.99)))), "global_map": (10, 0, float(np.float32(np.sqrt(5.99))))}
 
 
 def make(name):
@@ -48,9 +54,10 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     for name in CASES:
         prob = make(name)
-        ref = ob.ba_ref_solve(prob)
+        sched = SCHEDULE.get(name)
+        ref = ob.ba_ref_solve(prob, *sched) if sched else ob.ba_ref_solve(prob)
         st = ref["stats"]
-        pad = lambda rows: np.array([list(r) + [np.nan] * (15 - len(r)) for r in rows], dtype=np.float64)
+        pad = lambda rows: np.array([list(r) + [np.nan] * (32 - len(r)) for r in rows], dtype=np.float64)
         np.savez_compressed(
             os.path.join(out_dir, "ba_%s.npz" % name),
             kf_pose=prob["kf_pose"].astype(np.float32), kf_fixed=prob["kf_fixed"], kf_intr=prob["kf_intr"].astype(np.float32),
@@ -59,7 +66,8 @@ def main():
             ref_kf_pose=ref["kf_pose"], ref_pt_xyz=ref["pt_xyz"], ref_edge_chi2=ref["edge_chi2"],
             ref_edge_outlier=ref["edge_outlier"], ref_edge_stage1_outlier=ref["edge_stage1_outlier"],
             ref_n_its=np.array(st["n_its"]), ref_chi2=pad(st["chi2"]), ref_lambda=pad(st["lambda"]),
-            ref_trials=pad(st["trials"]), ref_chi2_init=np.array(st["chi2_init"]))
+            ref_trials=pad(st["trials"]), ref_chi2_init=np.array(st["chi2_init"]),
+            schedule=np.array(sched if sched else (5, 10, ob.HUBER_MONO), np.float64))
         print(name, "edges", len(prob["edge_kf"]), "its", st["n_its"], "trials", st["trials"],
               "outliers", int(ref["edge_outlier"].sum()))
 

@@ -53,8 +53,23 @@ public:
     template <class FrameT>
     static int PoseOptimization(FrameT* pFrame);
 
+    // Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (Optimizer.cc:40-238; called from
+    // Tracking::CreateInitialMapMonocular and LoopClosing::RunGlobalBundleAdjustment): every keyframe and map point handed
+    // in, keyframe id 0 fixed, ONE optimize(nIterations) with Huber delta sqrt(5.99) (or no kernel) -- the same device solve
+    // with the schedule (nIterations, 0).  Additional members: KeyFrame : mTcwGBA, mnBAGlobalForKF ; MapPoint : mPosGBA,
+    // mnBAGlobalForKF ; Map : GetAllKeyFrames(), GetAllMapPoints().  Mono only.
+    template <class KeyFrameT, class MapPointT>
+    static void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<MapPointT*>& vpMP, int nIterations = 5,
+                                 bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true);
+    template <class MapT>
+    static void GlobalBundleAdjustemnt(MapT* pMap, int nIterations = 5, bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0,
+                                       const bool bRobust = true) {
+        BundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), nIterations, pbStopFlag, nLoopKF, bRobust);
+    }
+
     // POD form: the window already flattened (what the template above produces).
     static int LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, const volatile bool* stop, slamit_ba_result& res);
+    static int SolvePOD(const slamit_ba_problem& prob, const slamit_ba_opts& opts, slamit_ba_result& res);
 
     static int LastStatus() { return lastStatus(); }
     static void SetDevice(int device) { deviceRef() = device; }
@@ -67,7 +82,7 @@ private:
     static std::mutex& solveMutex() { static std::mutex m; return m; }
 };
 
-inline int Optimizer::LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, const volatile bool* stop, slamit_ba_result& res) {
+inline int Optimizer::SolvePOD(const slamit_ba_problem& prob, const slamit_ba_opts& opts, slamit_ba_result& res) {
     std::lock_guard<std::mutex> guard(solveMutex());  // one LocalMapping thread in the reference; be safe anyway
     int* cap = capRef();
     if (!handleRef() || prob.n_kf > cap[0] || prob.n_pt > cap[1] || prob.n_edge > cap[2]) {
@@ -79,13 +94,105 @@ inline int Optimizer::LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, co
         int rc = slamit_ba_create(cap[0], cap[1], cap[2], 1, deviceRef(), &handleRef());
         if (rc != SLAMIT_OK) { handleRef() = 0; cap[0] = cap[1] = cap[2] = 0; return lastStatus() = rc; }
     }
+    return lastStatus() = slamit_ba_solve(handleRef(), &prob, &opts, &res);
+}
+
+inline int Optimizer::LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, const volatile bool* stop, slamit_ba_result& res) {
     slamit_ba_opts o;
     o.its_robust = 5;                              // Optimizer.cc:660
     o.its_final = 10;                              // :707
     o.huber_delta = (double)(float)sqrt(5.991);    // :569 (a float in the reference)
     o.chi2_gate = 5.991;                           // :680,723
     o.stop = reinterpret_cast<const volatile uint8_t*>(stop);
-    return lastStatus() = slamit_ba_solve(handleRef(), &prob, &o, &res);
+    return SolvePOD(prob, o, res);
+}
+
+template <class KeyFrameT, class MapPointT>
+void Optimizer::BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<MapPointT*>& vpMP, int nIterations,
+                                 bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
+    // ---- vertices (Optimizer.cc:69-85, 91-105) and edges (:107-160), flattened ----
+    std::vector<KeyFrameT*> kfs;
+    std::map<KeyFrameT*, int> kfIndex;
+    std::vector<double> pose, intr, pts, uv, invSigma2;
+    std::vector<uint8_t> fixed;
+    std::vector<int32_t> ekf, ept;
+    long unsigned int maxKFid = 0;
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        KeyFrameT* pKF = vpKFs[i];
+        if (pKF->isBad()) continue;
+        kfIndex[pKF] = (int)kfs.size();
+        kfs.push_back(pKF);
+        cv::Mat T = pKF->GetPose();
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) pose.push_back((double)T.template at<float>(r, c));
+        for (int r = 0; r < 3; ++r) pose.push_back((double)T.template at<float>(r, 3));
+        fixed.push_back(pKF->mnId == 0);
+        intr.push_back(pKF->fx); intr.push_back(pKF->fy); intr.push_back(pKF->cx); intr.push_back(pKF->cy);
+        if (pKF->mnId > maxKFid) maxKFid = pKF->mnId;
+    }
+    std::vector<MapPointT*> mps;          // the points that got at least one edge (vbNotIncludedMP == false)
+    bool hasStereo = false;
+    for (size_t i = 0; i < vpMP.size(); i++) {
+        MapPointT* pMP = vpMP[i];
+        if (pMP->isBad()) continue;
+        const std::map<KeyFrameT*, size_t> observations = pMP->GetObservations();
+        int nEdges = 0;
+        const int p = (int)mps.size();
+        for (typename std::map<KeyFrameT*, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) {
+            KeyFrameT* pKF = mit->first;
+            if (pKF->isBad() || pKF->mnId > maxKFid) continue;
+            typename std::map<KeyFrameT*, int>::iterator where = kfIndex.find(pKF);
+            if (where == kfIndex.end()) continue;
+            if (pKF->mvuRight[mit->second] >= 0) { hasStereo = true; continue; }
+            const cv::KeyPoint& kpUn = pKF->mvKeysUn[mit->second];
+            nEdges++;
+            ekf.push_back(where->second); ept.push_back(p);
+            uv.push_back(kpUn.pt.x); uv.push_back(kpUn.pt.y);
+            invSigma2.push_back(pKF->mvInvLevelSigma2[kpUn.octave]);
+        }
+        if (nEdges == 0) continue;        // optimizer.removeVertex(vPoint)
+        cv::Mat X = pMP->GetWorldPos();
+        for (int r = 0; r < 3; ++r) pts.push_back((double)X.template at<float>(r, 0));
+        mps.push_back(pMP);
+    }
+    if (hasStereo) { lastStatus() = SLAMIT_ERR_ARG; return; }
+    if (kfs.empty()) return;
+
+    slamit_ba_problem prob;
+    prob.n_kf = (int32_t)kfs.size(); prob.n_pt = (int32_t)mps.size(); prob.n_edge = (int32_t)ekf.size();
+    prob.kf_pose = pose.data(); prob.kf_fixed = fixed.data(); prob.kf_intr = intr.data(); prob.pt_xyz = pts.data();
+    prob.edge_kf = ekf.data(); prob.edge_pt = ept.data(); prob.edge_uv = uv.data(); prob.edge_inv_sigma2 = invSigma2.data();
+    std::vector<double> outPose(pose.size()), outPts(pts.size() + 3), chi2(ekf.size() + 1);
+    std::vector<uint8_t> outlier(ekf.size() + 1), outlier1(ekf.size() + 1);
+    slamit_ba_result res;
+    res.kf_pose = outPose.data(); res.pt_xyz = outPts.data(); res.edge_chi2 = chi2.data();
+    res.edge_outlier = outlier.data(); res.edge_stage1_outlier = outlier1.data(); res.stats = 0;
+    slamit_ba_opts o;
+    o.its_robust = nIterations;                                        // optimizer.optimize(nIterations), :188
+    o.its_final = 0;
+    o.huber_delta = bRobust ? (double)(float)sqrt(5.99) : HUGE_VAL;    // thHuber2D, :87 ; no kernel = a delta nothing exceeds
+    o.chi2_gate = 5.991;                                               // unused: there is no second stage
+    o.stop = reinterpret_cast<const volatile uint8_t*>(pbStopFlag);
+    if (SolvePOD(prob, o, res) != SLAMIT_OK) return;
+
+    // ---- recover optimized data (:193-237) ----
+    for (size_t k = 0; k < kfs.size(); ++k) {
+        cv::Mat T(4, 4, CV_32F);
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) T.template at<float>(r, c) = (float)outPose[12 * k + 3 * r + c];
+            T.template at<float>(r, 3) = (float)outPose[12 * k + 9 + r];
+            T.template at<float>(3, r) = 0.f;
+        }
+        T.template at<float>(3, 3) = 1.f;
+        if (nLoopKF == 0) kfs[k]->SetPose(T);
+        else { kfs[k]->mTcwGBA = T.clone(); kfs[k]->mnBAGlobalForKF = nLoopKF; }
+    }
+    for (size_t p = 0; p < mps.size(); ++p) {
+        if (mps[p]->isBad()) continue;
+        cv::Mat X(3, 1, CV_32F);
+        for (int r = 0; r < 3; ++r) X.template at<float>(r, 0) = (float)outPts[3 * p + r];
+        if (nLoopKF == 0) { mps[p]->SetWorldPos(X); mps[p]->UpdateNormalAndDepth(); }
+        else { mps[p]->mPosGBA = X.clone(); mps[p]->mnBAGlobalForKF = nLoopKF; }
+    }
 }
 
 template <class FrameT>

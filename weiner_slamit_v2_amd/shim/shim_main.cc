@@ -47,7 +47,9 @@ struct MockMapPoint {
     std::map<MockKeyFrame*, size_t> obs;
     bool bad;
     int normalUpdates;
-    MockMapPoint() : mnId(0), mnBALocalForKF(~0ul), bad(false), normalUpdates(0) {}
+    cv::Mat mPosGBA;
+    long unsigned int mnBAGlobalForKF;
+    MockMapPoint() : mnId(0), mnBALocalForKF(~0ul), bad(false), normalUpdates(0), mnBAGlobalForKF(0) {}
     bool isBad() { return bad; }
     std::map<MockKeyFrame*, size_t> GetObservations() { return obs; }
     cv::Mat GetWorldPos() { return pos.clone(); }
@@ -56,15 +58,15 @@ struct MockMapPoint {
     void EraseObservation(MockKeyFrame* kf) { obs.erase(kf); }
 };
 struct MockKeyFrame {
-    long unsigned int mnId, mnBALocalForKF, mnBAFixedForKF;
-    cv::Mat Tcw;
+    long unsigned int mnId, mnBALocalForKF, mnBAFixedForKF, mnBAGlobalForKF;
+    cv::Mat Tcw, mTcwGBA;
     float fx, fy, cx, cy;
     std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<float> mvuRight, mvInvLevelSigma2;
     std::vector<MockMapPoint*> matches;
     std::vector<MockKeyFrame*> covisible;
     int erased;
-    MockKeyFrame() : mnId(0), mnBALocalForKF(~0ul), mnBAFixedForKF(~0ul), erased(0) {}
+    MockKeyFrame() : mnId(0), mnBALocalForKF(~0ul), mnBAFixedForKF(~0ul), mnBAGlobalForKF(0), erased(0) {}
     bool isBad() { return false; }
     std::vector<MockKeyFrame*> GetVectorCovisibleKeyFrames() { return covisible; }
     std::vector<MockMapPoint*> GetMapPointMatches() { return matches; }
@@ -74,7 +76,13 @@ struct MockKeyFrame {
         for (size_t i = 0; i < matches.size(); ++i) if (matches[i] == mp) { matches[i] = 0; ++erased; }
     }
 };
-struct MockMap { std::mutex mMutexMapUpdate; };
+struct MockMap {
+    std::mutex mMutexMapUpdate;
+    std::vector<MockKeyFrame*> kfs;
+    std::vector<MockMapPoint*> mps;
+    std::vector<MockKeyFrame*> GetAllKeyFrames() { return kfs; }
+    std::vector<MockMapPoint*> GetAllMapPoints() { return mps; }
+};
 
 static int run_orb(int argc, char** argv) {
     if (argc < 6) return 2;
@@ -181,7 +189,20 @@ static int run_ba(int argc, char** argv) {
     for (int k = 0; k < K; ++k) if (k != cur && (!fixed[k] || k == 0)) kfs[cur].covisible.push_back(&kfs[k]);
     MockMap map;
     bool stop = false;
-    Optimizer::LocalBundleAdjustment(&kfs[cur], &stop, &map);
+    // shim_test ba <problem> <out> [global <nIterations> <nLoopKF> <bRobust>]: GlobalBundleAdjustemnt over the same data
+    const bool global = argc >= 8 && std::string(argv[4]) == "global";
+    const unsigned long nLoopKF = global ? (unsigned long)atoi(argv[6]) : 0;
+    if (global) {
+        for (int k = 0; k < K; ++k) map.kfs.push_back(&kfs[k]);
+        for (int q = 0; q < P; ++q) map.mps.push_back(&mps[q]);
+        Optimizer::GlobalBundleAdjustemnt(&map, atoi(argv[5]), &stop, nLoopKF, atoi(argv[7]) != 0);
+        if (nLoopKF) {   // results went to mTcwGBA / mPosGBA: fold them back so that the output format stays the same
+            for (int k = 0; k < K; ++k) if (kfs[k].mnBAGlobalForKF == nLoopKF) kfs[k].Tcw = kfs[k].mTcwGBA.clone();
+            for (int q = 0; q < P; ++q) if (mps[q].mnBAGlobalForKF == nLoopKF) { mps[q].pos = mps[q].mPosGBA.clone(); mps[q].normalUpdates = -1; }
+        }
+    } else {
+        Optimizer::LocalBundleAdjustment(&kfs[cur], &stop, &map);
+    }
     if (Optimizer::LastStatus() != 0) { fprintf(stderr, "BA failed: %s\n", slamit_last_error()); return 1; }
     FILE* f = fopen(argv[3], "wb");
     for (int k = 0; k < K; ++k)
