@@ -23,7 +23,7 @@ def per_kernel(path, counter):
     if not f:
         return {}
     acc = {}
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
         if r.get("Counter_Name") != counter:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -40,7 +40,7 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, tag + "_bench_kernel_stats.csv"))
+        shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
     bench = os.path.join(src, "bench.json")
     if os.path.exists(bench):
         line = [l for l in open(bench).read().splitlines() if l.startswith("{")][-1]
