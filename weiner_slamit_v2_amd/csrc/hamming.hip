@@ -17,7 +17,26 @@
 #include "../../include/slamit.h"
 #include "slamit_internal.h"
 
-#define HM_TILE 256
+#ifndef HM_TILE
+#define HM_TILE 256     // train rows per LDS tile (multiple of 128)
+#endif
+#define HM_PF (HM_TILE / 128)   // uint4 per thread and tile
+#ifndef HM_SLICES
+#define HM_SLICES 8     // lanes per query: each takes every HM_SLICES-th train row of a tile
+#endif
+#define HM_QPB (256 / HM_SLICES)   // queries per workgroup
+
+// popcount(x) + acc in ONE instruction; left to itself the compiler builds a tree of 8 v_bcnt + 3 v_add3 per distance
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc) {
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {   // v_med3_u32 (no builtin for the unsigned form)
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 __global__ __launch_bounds__(256) void hamming_best2_kernel(
     const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed, size_t q_stride,
@@ -28,35 +47,56 @@ __global__ __launch_bounds__(256) void hamming_best2_kernel(
     const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
     const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
     const int tid = threadIdx.x;
-    const int qi = blockIdx.x * 64 + (tid >> 2);
-    const int slice = tid & 3;
-    if (blockIdx.x * 64 >= nq) return;  // uniform
+    const int qi = blockIdx.x * HM_QPB + tid / HM_SLICES;
+    const int slice = tid % HM_SLICES;
+    if (blockIdx.x * HM_QPB >= nq) return;  // uniform
     const uint4* Q = reinterpret_cast<const uint4*>(q + (size_t)pair * q_stride);
     const uint4* T = reinterpret_cast<const uint4*>(t + (size_t)pair * t_stride);
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
     const bool live = qi < nq;
     if (live) { a0 = Q[2 * (size_t)qi]; a1 = Q[2 * (size_t)qi + 1]; }
     // (best, second) are the two smallest keys (distance << 16 | train index): strict '<' with the first index
-    // winning ties is exactly the order of these keys, and a min / max / min triple updates both without a branch
+    // winning ties is exactly the order of these keys, and a median / min pair updates both without a branch
     unsigned kb = 0xFFFFFFFFu, ks = 0xFFFFFFFFu;
+    // the next tile of train descriptors travels HBM -> registers while the current one is being scanned
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    uint4 pf[HM_PF];
+#pragma unroll
+    for (int k = 0; k < HM_PF; ++k) pf[k] = tid + 256 * k < 2 * min(nt, HM_TILE) ? T[tid + 256 * k] : zero;
     for (int base = 0; base < nt; base += HM_TILE) {
         const int rows = min(HM_TILE, nt - base);
         __syncthreads();
-        for (int i = tid; i < rows * 2; i += 256) tile[i] = T[2 * (size_t)base + i];
-        __syncthreads();
-#pragma unroll 4
-        for (int j = slice; j < rows; j += 4) {
-            const uint4 t0 = tile[2 * j], t1 = tile[2 * j + 1];
-            const unsigned d = __popc(a0.x ^ t0.x) + __popc(a0.y ^ t0.y) + __popc(a0.z ^ t0.z) + __popc(a0.w ^ t0.w) +
-                               __popc(a1.x ^ t1.x) + __popc(a1.y ^ t1.y) + __popc(a1.z ^ t1.z) + __popc(a1.w ^ t1.w);
-            const unsigned k = (d << 16) | (unsigned)(base + j);
-            ks = min(ks, max(kb, k));
-            kb = min(kb, k);
-        }
-    }
-    // merge the 4 slices of each query (lanes 4k..4k+3): two smallest of the union
 #pragma unroll
-    for (int m = 1; m <= 2; m <<= 1) {
+        for (int k = 0; k < HM_PF; ++k) tile[tid + 256 * k] = pf[k];
+        __syncthreads();
+        if (base + HM_TILE < nt) {
+            const int nrows2 = 2 * min(HM_TILE, nt - base - HM_TILE);
+            const uint4* Tn = T + 2 * (size_t)(base + HM_TILE);
+#pragma unroll
+            for (int k = 0; k < HM_PF; ++k) pf[k] = tid + 256 * k < nrows2 ? Tn[tid + 256 * k] : zero;
+        }
+#define HM_DIST(T0, T1) bcnt_acc(a1.w ^ T1.w, bcnt_acc(a1.z ^ T1.z, bcnt_acc(a1.y ^ T1.y, bcnt_acc(a1.x ^ T1.x, \
+                        bcnt_acc(a0.w ^ T0.w, bcnt_acc(a0.z ^ T0.z, bcnt_acc(a0.y ^ T0.y, bcnt_acc(a0.x ^ T0.x, 0u))))))))
+#define HM_TAKE(D, J) do { const unsigned k = ((D) << 16) | (unsigned)(base + (J)); \
+            ks = umed3(kb, ks, k);   /* kb <= ks: the median of the three is the new second smallest */ \
+            kb = min(kb, k); } while (0)
+        int j = slice;
+        // four rows per trip, their eight LDS reads issued before the first popcount (unrolled by hand: the asm in umed3
+        // stops the unroller)
+        for (; j + 3 * HM_SLICES < rows; j += 4 * HM_SLICES) {
+            const uint4 t00 = tile[2 * j], t01 = tile[2 * j + 1], t10 = tile[2 * (j + HM_SLICES)], t11 = tile[2 * (j + HM_SLICES) + 1];
+            const uint4 t20 = tile[2 * (j + 2 * HM_SLICES)], t21 = tile[2 * (j + 2 * HM_SLICES) + 1];
+            const uint4 t30 = tile[2 * (j + 3 * HM_SLICES)], t31 = tile[2 * (j + 3 * HM_SLICES) + 1];
+            const unsigned d0 = HM_DIST(t00, t01), d1 = HM_DIST(t10, t11), d2 = HM_DIST(t20, t21), d3 = HM_DIST(t30, t31);
+            HM_TAKE(d0, j); HM_TAKE(d1, j + HM_SLICES); HM_TAKE(d2, j + 2 * HM_SLICES); HM_TAKE(d3, j + 3 * HM_SLICES);
+        }
+        for (; j < rows; j += HM_SLICES) { const uint4 t0 = tile[2 * j], t1 = tile[2 * j + 1]; const unsigned d = HM_DIST(t0, t1); HM_TAKE(d, j); }
+#undef HM_DIST
+#undef HM_TAKE
+    }
+    // merge the slices of each query (adjacent lanes): two smallest of the union
+#pragma unroll
+    for (int m = 1; m < HM_SLICES; m <<= 1) {
         const unsigned ob = (unsigned)__shfl_xor((int)kb, m, 64), os = (unsigned)__shfl_xor((int)ks, m, 64);
         ks = min(min(ks, os), max(kb, ob));
         kb = min(kb, ob);
@@ -175,7 +215,7 @@ int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size
     if (npairs == 0 || max_n == 0) return SLAMIT_OK;
     if (max_n > SLAMIT_HAMMING_MAX_TRAIN) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_hamming_best2_batch_dev: more than SLAMIT_HAMMING_MAX_TRAIN descriptors per set");
     HIP_TRY(hipSetDevice(device));
-    dim3 grid((max_n + 63) / 64, npairs);
+    dim3 grid((max_n + HM_QPB - 1) / HM_QPB, npairs);
     hipLaunchKernelGGL(hamming_best2_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_q, d_nq, 0, q_stride, d_t, d_nt,
                        0, t_stride, d_best_idx, d_best, d_second, out_stride);
     HIP_TRY(hipGetLastError());
@@ -196,7 +236,7 @@ int slamit_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int
     if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess && nt) e = hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + 63) / 64, 1), dim3(256), 0, 0, dq, (const int*)nullptr, nq,
+        hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + HM_QPB - 1) / HM_QPB, 1), dim3(256), 0, 0, dq, (const int*)nullptr, nq,
                            (size_t)0, dt, (const int*)nullptr, nt, (size_t)0, dout, dout + nq, dout + 2 * (size_t)nq, (size_t)0);
         e = hipGetLastError();
     }

@@ -464,6 +464,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     if (cap < h->max_out) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_extract_batch_dev: cap < slamit_orb_max_keypoints()");
     if (stride < (size_t)h->p.width || (nframes > 1 && frame_stride < stride * (size_t)h->p.height))
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: stride smaller than the frame");
+    if (stride >= ((size_t)1 << 24)) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: row pitch of 16 MiB or more");   // kernels address rows with 24-bit multiplies
     int* cand_count = h->d_counts;
     int* kp_count = h->d_counts + (size_t)h->p.max_batch * nl * ORB_CC_PAD;
     HIP_TRY(hipMemsetAsync(cand_count, 0, sizeof(int) * nframes * nl * ORB_CC_PAD, st));

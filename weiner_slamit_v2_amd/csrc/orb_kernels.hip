@@ -65,50 +65,75 @@ __global__ __launch_bounds__(256) void resize_level_kernel(
 
 // --------------------------------------------------------------------------------------------
 // K1 (per level, the path used when planes are 4-byte aligned): one lane = 4 adjacent dst pixels of
-// one dst row, items flattened over (row, group) so every lane of every wave is busy.  All per-column
-// and per-row arithmetic the reference does at run time is in two host-built tables (orbk_resize_tables):
-//   column group (2 x uint4): byte offset of the 12-byte source window | byte shift | offsets of its 2nd and
-//       3rd dword (clamped into the row) ; v_perm selectors of the 4 left taps and the 4 right taps ;
-//       4 x (ialpha0 | ialpha1 << 16)
+// TWO adjacent dst rows, items flattened over (row pair, group) so every lane of every wave is busy.  All
+// per-column and per-row arithmetic the reference does at run time is in two host-built tables
+// (orbk_resize_tables):
+//   column group (3 x uint4): byte offset of the 12-byte source window | byte shift | offsets of its 2nd and
+//       3rd dword (clamped into the row) ; 4 x v_perm selector that lifts (left tap, right tap) of one dst
+//       column out of the 8-byte window as two zero-extended halfwords ; 4 x (ialpha0 | ialpha1 << 16)
 //   row (uint2): sy0 | sy1 << 16 (clamped) ; ibeta0 | ibeta1 << 16
-// A source row costs 3 aligned dword loads, 2 v_alignbyte, 2 v_perm; no LDS, no halo, no barrier.
+// A source row costs 3 aligned dword loads, 2 v_alignbyte, 4 v_perm and 4 v_dot2_u32_u16 (the horizontal pass
+// of one dst pixel is ONE dot product); no LDS, no halo, no barrier.
 // --------------------------------------------------------------------------------------------
+typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rs_dot2(uint32_t taps, uint32_t alpha) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(rs_us2, taps), __builtin_bit_cast(rs_us2, alpha), 0u, false);
+}
+
+template <int RP>   // RP row pairs (2 * RP dst rows) per lane
 __global__ __launch_bounds__(256) void resize_rows4_kernel(
     const uint8_t* __restrict__ src, size_t sstride, size_t sframe,
     uint8_t* __restrict__ dst, size_t dstride, size_t dframe,
-    const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, int ngroups, unsigned inv_groups, int nitems) {
+    const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, int ngroups, unsigned inv_groups, int nitems, int dh) {
     const int item = blockIdx.x * 256 + threadIdx.x;
     if (item >= nitems) return;
-    const int y = (int)__umulhi((unsigned)item, inv_groups);
-    const int g = item - y * ngroups;
+    const int yq = (int)__umulhi((unsigned)item, inv_groups);
+    const int g = item - yq * ngroups;
     // uniform 64-bit bases + 32-bit per-lane offsets (planes are far below 4 GB): global_load saddr + voffset
-    const uint8_t* ct = reinterpret_cast<const uint8_t*>(coltab);
-    const uint4 c0 = *reinterpret_cast<const uint4*>(ct + 32u * (unsigned)g), c1 = *reinterpret_cast<const uint4*>(ct + 32u * (unsigned)g + 16u);
-    const uint2 rt = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(rowtab) + 8u * (unsigned)y);
+    const uint8_t* ct = reinterpret_cast<const uint8_t*>(coltab) + 48u * (unsigned)g;
+    const uint4 c0 = *reinterpret_cast<const uint4*>(ct), c1 = *reinterpret_cast<const uint4*>(ct + 16u);
+    const uint32_t c2x = *reinterpret_cast<const uint32_t*>(ct + 32u);
+    // rows past the bottom are clamped to the last row: they are produced again (same bytes), never skipped, so the
+    // whole lane is straight-line code with every load issued before the first use
+    int yrow[2 * RP];
+    uint2 rt[2 * RP];
+#pragma unroll
+    for (int r = 0; r < 2 * RP; ++r) {
+        yrow[r] = min(2 * RP * yq + r, dh - 1);
+        rt[r] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(rowtab) + 8u * (unsigned)yrow[r]);
+    }
     const unsigned b = c0.x & 0xFFFFu, sh = (c0.x >> 16) & 3u, off1 = (c0.x >> 20) & 15u, off2 = (c0.x >> 24) & 15u;
     const uint8_t* S = src + (size_t)blockIdx.y * sframe;
+    uint8_t* D = dst + (size_t)blockIdx.y * dframe;
     const unsigned ss = (unsigned)sstride;
-    const unsigned o0 = (rt.x & 0xFFFFu) * ss + b, o1 = (rt.x >> 16) * ss + b;
-    const uint32_t p0 = *reinterpret_cast<const uint32_t*>(S + o0), p1 = *reinterpret_cast<const uint32_t*>(S + (o0 + off1)),
-                   p2 = *reinterpret_cast<const uint32_t*>(S + (o0 + off2));
-    const uint32_t q0 = *reinterpret_cast<const uint32_t*>(S + o1), q1 = *reinterpret_cast<const uint32_t*>(S + (o1 + off1)),
-                   q2 = *reinterpret_cast<const uint32_t*>(S + (o1 + off2));
-    const uint32_t plo = __builtin_amdgcn_alignbyte(p1, p0, sh), phi = __builtin_amdgcn_alignbyte(p2, p1, sh);
-    const uint32_t qlo = __builtin_amdgcn_alignbyte(q1, q0, sh), qhi = __builtin_amdgcn_alignbyte(q2, q1, sh);
-    const uint32_t L0 = __builtin_amdgcn_perm(phi, plo, c0.y), R0 = __builtin_amdgcn_perm(phi, plo, c0.z);
-    const uint32_t L1 = __builtin_amdgcn_perm(qhi, qlo, c0.y), R1 = __builtin_amdgcn_perm(qhi, qlo, c0.z);
-    const int b0 = (int)(rt.y & 0xFFFFu), b1 = (int)(rt.y >> 16);
-    const uint32_t al[4] = {c1.x, c1.y, c1.z, c1.w};
-    uint32_t out = 0;
+    const uint32_t sel[4] = {c0.y, c0.z, c0.w, c1.x}, al[4] = {c1.y, c1.z, c1.w, c2x};
+    uint32_t w[4 * RP][3];   // the 12-byte windows of the source rows (two per dst row)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int a0 = (int)(al[j] & 0xFFFFu), a1 = (int)(al[j] >> 16);
-        const int r0 = (int)((L0 >> (8 * j)) & 0xFFu) * a0 + (int)((R0 >> (8 * j)) & 0xFFu) * a1;
-        const int r1 = (int)((L1 >> (8 * j)) & 0xFFu) * a0 + (int)((R1 >> (8 * j)) & 0xFFu) * a1;
-        const int v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
-        out |= (uint32_t)v << (8 * j);
+    for (int r = 0; r < 4 * RP; ++r) {
+        const unsigned srow = (r & 1) ? (rt[r >> 1].x >> 16) : (rt[r >> 1].x & 0xFFFFu);
+        const unsigned ro = __umul24(srow, ss) + b;   // rows < 2^16, pitch < 2^24
+        w[r][0] = *reinterpret_cast<const uint32_t*>(S + ro);
+        w[r][1] = *reinterpret_cast<const uint32_t*>(S + (ro + off1));
+        w[r][2] = *reinterpret_cast<const uint32_t*>(S + (ro + off2));
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.y * dframe + ((unsigned)y * (unsigned)dstride + 4u * (unsigned)g)) = out;
+#pragma unroll
+    for (int k = 0; k < 2 * RP; ++k) {
+        uint32_t h[2][4];   // horizontal pass: h[source row][column] = (left * ialpha0 + right * ialpha1) >> 4
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w[2 * k + r][1], w[2 * k + r][0], sh), hi = __builtin_amdgcn_alignbyte(w[2 * k + r][2], w[2 * k + r][1], sh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[r][j] = rs_dot2(__builtin_amdgcn_perm(hi, lo, sel[j]), al[j]) >> 4;
+        }
+        const unsigned b0 = rt[k].y & 0xFFFFu, b1 = rt[k].y >> 16;
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // (b * (h >> 4)) >> 16 with b <= 2048, h >> 4 <= 32640: 24-bit multiplies
+            const uint32_t v = ((__umul24(b0, h[0][j]) >> 16) + (__umul24(b1, h[1][j]) >> 16) + 2u) >> 2;
+            out |= (v & 0xFFu) << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(D + (__umul24((unsigned)yrow[k], (unsigned)dstride) + 4u * (unsigned)g)) = out;
+    }
 }
 
 // Host: tables of resize_rows4_kernel for one level from the reference-shaped xofs/ialpha/yofs/ibeta tables.
@@ -119,7 +144,7 @@ bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const s
                         const short* ibeta, std::vector<uint32_t>& col, std::vector<uint32_t>& row) {
     const int ng = (dw + 3) / 4, row_end = (sw + 3) & ~3;
     if (sw >= 65536 || sh >= 65536) return false;
-    col.assign((size_t)ng * 8, 0u);
+    col.assign((size_t)ng * 12, 0u);
     for (int g = 0; g < ng; ++g) {
         int L[4], R[4];
         uint32_t a[4];
@@ -132,16 +157,13 @@ bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const s
         }
         const int base = L[0] & ~3, s = L[0] & 3;
         const int off1 = base + 8 <= row_end ? 4 : 0, off2 = base + 12 <= row_end ? 8 : off1;
-        uint32_t selL = 0, selR = 0;
-        for (int j = 0; j < 4; ++j) {   // byte index inside the 8 bytes that start at L[0]
-            if (L[j] < L[0] || R[j] < L[0] || L[j] - L[0] > 7 || R[j] - L[0] > 7 || ialpha[0] < 0) return false;
-            selL |= (uint32_t)(L[j] - L[0]) << (8 * j);
-            selR |= (uint32_t)(R[j] - L[0]) << (8 * j);
-        }
-        uint32_t* c = &col[(size_t)g * 8];
+        uint32_t* c = &col[(size_t)g * 12];
         c[0] = (uint32_t)base | ((uint32_t)s << 16) | ((uint32_t)off1 << 20) | ((uint32_t)off2 << 24);
-        c[1] = selL; c[2] = selR; c[3] = 0;
-        c[4] = a[0]; c[5] = a[1]; c[6] = a[2]; c[7] = a[3];
+        for (int j = 0; j < 4; ++j) {   // byte index inside the 8 bytes that start at L[0]; selector byte 0x0C reads as zero
+            if (L[j] < L[0] || R[j] < L[0] || L[j] - L[0] > 7 || R[j] - L[0] > 7 || ialpha[0] < 0) return false;
+            c[1 + j] = (uint32_t)(L[j] - L[0]) | 0x0C00u | ((uint32_t)(R[j] - L[0]) << 16) | 0x0C000000u;
+            c[5 + j] = a[j];
+        }
     }
     row.assign((size_t)dh * 2, 0u);
     for (int y = 0; y < dh; ++y) {
@@ -156,10 +178,15 @@ bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const s
 
 void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, uint8_t* dst, int dw, int dh,
                        size_t dstride, size_t dframe, const uint32_t* d_col, const uint32_t* d_row, int nframes) {
-    const int ng = (dw + 3) / 4, nitems = ng * dh;
+    static const int rp_env = getenv("SLAMIT_RESIZE_RP") ? atoi(getenv("SLAMIT_RESIZE_RP")) : 0;
+    const int rp = rp_env == 1 || rp_env == 2 || rp_env == 4 ? rp_env : 2;
+    const int ng = (dw + 3) / 4, nitems = ng * ((dh + 2 * rp - 1) / (2 * rp));
     const unsigned inv = (unsigned)((0x100000000ull + (unsigned)ng - 1) / (unsigned)ng);
-    hipLaunchKernelGGL(resize_rows4_kernel, dim3((nitems + 255) / 256, nframes), dim3(256), 0, st, src, sstride, sframe, dst,
-                       dstride, dframe, reinterpret_cast<const uint4*>(d_col), reinterpret_cast<const uint2*>(d_row), ng, inv, nitems);
+    const dim3 grid((nitems + 255) / 256, nframes);
+#define RS_LAUNCH(RP) hipLaunchKernelGGL(resize_rows4_kernel<RP>, grid, dim3(256), 0, st, src, sstride, sframe, dst, dstride, dframe, \
+                                          reinterpret_cast<const uint4*>(d_col), reinterpret_cast<const uint2*>(d_row), ng, inv, nitems, dh)
+    if (rp == 1) RS_LAUNCH(1); else if (rp == 2) RS_LAUNCH(2); else RS_LAUNCH(4);
+#undef RS_LAUNCH
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1047,14 +1074,20 @@ __device__ __forceinline__ uint32_t blur_fetch(const uint8_t* S, unsigned sstrid
 __global__ __launch_bounds__(256) void blur_all_kernel(
     const OrbLevel* __restrict__ levels, const uint4* __restrict__ tiles,
     const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
-    const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+    const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, unsigned ntiles, unsigned inv_tiles, unsigned total) {
     __shared__ __attribute__((aligned(16))) uint8_t in[22][72];
     // row-pass results as VERTICAL PAIRS: rp[p][c] = row 2p | row 2p+1 << 16 (each <= 255 * 257), the operand
     // shape of v_dot2_u32_u16 in the column pass
     __shared__ __attribute__((aligned(16))) uint32_t rp[11][64];
     const int tid = threadIdx.x;
-    const int frame = blockIdx.y;
-    const uint4 tt = tiles[blockIdx.x];   // host-built (orbk_blur_tiles): level, strip origin -- no level search, no division
+    // XCD-aware order: workgroup i runs on XCD i % 8, so XCD k takes the k-th contiguous eighth of the (frame, strip)
+    // list -- strips that share halo columns and rows then share one L2 instead of fetching them into eight
+    const unsigned lin = blockIdx.x, per_xcd = (total + 7u) >> 3;
+    const unsigned logical = (lin & 7u) * per_xcd + (lin >> 3);
+    if (logical >= total) return;
+    int frame = (int)__umulhi(logical, inv_tiles);
+    if ((unsigned)frame * ntiles > logical) --frame;   // the rounded-up reciprocal can overshoot by one on huge grids
+    const uint4 tt = tiles[logical - (unsigned)frame * ntiles];   // host-built (orbk_blur_tiles): level, strip origin -- no level search
     const int level = (int)tt.x, bx = (int)tt.y, by0 = (int)tt.z;
     const OrbLevel& L = levels[level];
     const int w = L.w, h = L.h;
@@ -1415,8 +1448,10 @@ int orbk_blur_tiles(const OrbLevel* host_levels, int nlevels, std::vector<uint32
 
 void orbk_blur(hipStream_t st, const OrbLevel* levels, const uint32_t* d_tiles, int total_tiles, const uint8_t* img0,
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes) {
-    hipLaunchKernelGGL(blur_all_kernel, dim3(total_tiles, nframes), dim3(256), 0, st, levels, reinterpret_cast<const uint4*>(d_tiles), img0,
-                       img0_stride, img0_frame, pyr, blur);
+    const unsigned total = (unsigned)total_tiles * (unsigned)nframes, grid = ((total + 7u) >> 3) << 3;
+    const unsigned inv = (unsigned)((0x100000000ull + (unsigned)total_tiles - 1) / (unsigned)total_tiles);   // exact for logical < 2^32 / tiles
+    hipLaunchKernelGGL(blur_all_kernel, dim3(grid), dim3(256), 0, st, levels, reinterpret_cast<const uint4*>(d_tiles), img0,
+                       img0_stride, img0_frame, pyr, blur, (unsigned)total_tiles, inv, total);
 }
 
 void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,
