@@ -38,7 +38,7 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
 size_t orbk_octree_smem(int node_cap);
 hipError_t orbk_octree_prepare(int node_cap);
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
-                 size_t cand_frame_stride, const int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
+                 size_t cand_frame_stride, int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
                  OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int nframes,
                  int level_override);
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0, size_t img0_stride,
@@ -109,6 +109,7 @@ struct slamit_orb {
     uint32_t* d_cells;   // FAST cell table (orbk_fast_cells), fast_cells entries of 8 words
     int fast_cells;
     int* d_counts;  // cand_count [max_batch][nlevels][ORB_CC_PAD] then kp_count [max_batch][nlevels]
+    bool counters_clean;   // every cand_count is zero (left so by the last call's octree pass)
     OrbLevelKp* d_lkp;
     int* d_tab_i[ORB_MAX_LEVELS][2];      // xofs, yofs per level (level >= 1)
     short* d_tab_s[ORB_MAX_LEVELS][2];    // ialpha, ibeta
@@ -467,7 +468,10 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     if (stride >= ((size_t)1 << 24)) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: row pitch of 16 MiB or more");   // kernels address rows with 24-bit multiplies
     int* cand_count = h->d_counts;
     int* kp_count = h->d_counts + (size_t)h->p.max_batch * nl * ORB_CC_PAD;
-    HIP_TRY(hipMemsetAsync(cand_count, 0, sizeof(int) * nframes * nl * ORB_CC_PAD, st));
+    // the candidate counters are zero between calls: the octree pass consumes and re-zeroes them.  Only a call that
+    // follows a failed one (or the first) clears them itself.
+    if (!h->counters_clean) HIP_TRY(hipMemsetAsync(h->d_counts, 0, sizeof(int) * (size_t)h->p.max_batch * nl * ORB_CC_PAD, st));
+    h->counters_clean = false;
     // K1: pyramid, level l from level l-1
     prof_mark(h, st, ST_RESIZE, true);
     const bool src0_aligned = ((((uintptr_t)d_gray) | stride | frame_stride) & 3) == 0;
@@ -521,6 +525,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     prof_mark(h, st, ST_DESCRIBE, false);
     ++h->prof_call;
     HIP_TRY(hipGetLastError());
+    h->counters_clean = true;
     h->last_img0 = d_gray; h->last_stride = stride; h->last_frame = frame_stride; h->last_nframes = nframes;
     return SLAMIT_OK;
 }
@@ -609,7 +614,7 @@ int slamit_orb_debug_candidates(slamit_orb* h, int frame, int level, int32_t* xy
     HIP_TRY(hipSetDevice(h->device));
     const OrbLevel& L = h->levels[level];
     int n = 0;
-    HIP_TRY(hipMemcpy(&n, h->d_counts + (size_t)(frame * h->nlevels + level) * ORB_CC_PAD, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, h->d_counts + (size_t)(frame * h->nlevels + level) * ORB_CC_PAD + 1, sizeof(int), hipMemcpyDeviceToHost));   // word 1: the count the octree pass consumed
     n = std::min(n, L.cand_cap);
     *n_out = n;
     if (!xys || n == 0) return SLAMIT_OK;

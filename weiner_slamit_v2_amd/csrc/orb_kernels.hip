@@ -928,7 +928,7 @@ __device__ __forceinline__ void octree_body(
 __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
     const OrbLevel* __restrict__ levels, int nlevels,
     const unsigned long long* __restrict__ cand, size_t cand_frame_stride,
-    const int* __restrict__ cand_count,
+    int* __restrict__ cand_count,
     uint32_t* __restrict__ ws_xy, uint16_t* __restrict__ ws_node,
     OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, int* __restrict__ kp_count,
     int node_cap, int key_cap, int level_override /* -1: blockIdx.x */) {
@@ -941,7 +941,12 @@ __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
     const int frame = blockIdx.y;
     const OrbLevel& L = levels[level];
     const int kidx = frame * nlevels + level;
-    const int n_keys = min(cand_count[kidx * ORB_CC_PAD], L.cand_cap);
+    const int n_raw = cand_count[kidx * ORB_CC_PAD];
+    const int n_keys = min(n_raw, L.cand_cap);
+    // this workgroup is the counter's only reader: hand it back zeroed for the next call's FAST pass (no memset launch
+    // per call) and keep the count in the line's second word for slamit_orb_debug_candidates
+    __syncthreads();
+    if (threadIdx.x == 0) { cand_count[kidx * ORB_CC_PAD] = 0; cand_count[kidx * ORB_CC_PAD + 1] = n_raw; }
     const unsigned long long* K = cand + L.cand_off + (size_t)frame * cand_frame_stride;
     OrbLevelKp* OUT = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
     if (n_keys == 0) {
@@ -1421,7 +1426,7 @@ hipError_t orbk_octree_prepare(int node_cap) {
 }
 
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
-                 size_t cand_frame_stride, const int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
+                 size_t cand_frame_stride, int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
                  OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int nframes,
                  int level_override) {
     dim3 grid(level_override >= 0 ? 1 : nlevels, nframes);
