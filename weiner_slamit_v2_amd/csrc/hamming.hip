@@ -17,10 +17,7 @@
 #include "../../include/slamit.h"
 #include "slamit_internal.h"
 
-#ifndef HM_TILE
-#define HM_TILE 256     // train rows per LDS tile (multiple of 128)
-#endif
-#define HM_PF (HM_TILE / 128)   // uint4 per thread and tile
+#define HM_TILE 256      // train rows per LDS tile: two uint4 per thread
 #ifndef HM_SLICES
 #define HM_SLICES 8     // lanes per query: each takes every HM_SLICES-th train row of a tile
 #endif
@@ -60,20 +57,23 @@ __global__ __launch_bounds__(256) void hamming_best2_kernel(
     unsigned kb = 0xFFFFFFFFu, ks = 0xFFFFFFFFu;
     // the next tile of train descriptors travels HBM -> registers while the current one is being scanned
     const uint4 zero = make_uint4(0, 0, 0, 0);
-    uint4 pf[HM_PF];
-#pragma unroll
-    for (int k = 0; k < HM_PF; ++k) pf[k] = tid + 256 * k < 2 * min(nt, HM_TILE) ? T[tid + 256 * k] : zero;
+    // (Two named registers, not an array: the compiler moves a small array to LDS and then waits for the load at once.
+    // Indices are clamped, not predicated: a select between a load and zero turns into a FLAT load, which also counts
+    // in lgkmcnt and would make every LDS wait of the scan wait for the prefetch.  Rows >= nt of a tile are never read.)
+    uint4 p0 = zero, p1 = zero;
+    if (nt > 0) {
+        const int last = 2 * min(nt, HM_TILE) - 1;
+        p0 = T[min(tid, last)]; p1 = T[min(tid + 256, last)];
+    }
     for (int base = 0; base < nt; base += HM_TILE) {
         const int rows = min(HM_TILE, nt - base);
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < HM_PF; ++k) tile[tid + 256 * k] = pf[k];
+        tile[tid] = p0; tile[tid + 256] = p1;
         __syncthreads();
         if (base + HM_TILE < nt) {
-            const int nrows2 = 2 * min(HM_TILE, nt - base - HM_TILE);
+            const int last = 2 * min(HM_TILE, nt - base - HM_TILE) - 1;
             const uint4* Tn = T + 2 * (size_t)(base + HM_TILE);
-#pragma unroll
-            for (int k = 0; k < HM_PF; ++k) pf[k] = tid + 256 * k < nrows2 ? Tn[tid + 256 * k] : zero;
+            p0 = Tn[min(tid, last)]; p1 = Tn[min(tid + 256, last)];
         }
 #define HM_DIST(T0, T1) bcnt_acc(a1.w ^ T1.w, bcnt_acc(a1.z ^ T1.z, bcnt_acc(a1.y ^ T1.y, bcnt_acc(a1.x ^ T1.x, \
                         bcnt_acc(a0.w ^ T0.w, bcnt_acc(a0.z ^ T0.z, bcnt_acc(a0.y ^ T0.y, bcnt_acc(a0.x ^ T0.x, 0u))))))))
