@@ -689,9 +689,12 @@ __device__ __forceinline__ void octree_body(
     const int tid = threadIdx.x;
     // LDS carve (all 8-byte aligned)
     unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);              // cap
-    Box16* box[2] = {reinterpret_cast<Box16*>(best + cap), reinterpret_cast<Box16*>(best + cap) + cap};
-    int* cnt[2] = {reinterpret_cast<int*>(box[1] + cap), reinterpret_cast<int*>(box[1] + cap) + cap};
-    int* childcnt = cnt[1] + cap;        // 4*cap
+    // the two generations of node boxes / populations are addressed as base + generation * cap: an array of two pointers
+    // indexed at run time loses the LDS address space and every access becomes a FLAT load (slower, and it counts in
+    // both wait counters)
+    Box16* const box0 = reinterpret_cast<Box16*>(best + cap);   // 2 * cap
+    int* const cnt0 = reinterpret_cast<int*>(box0 + 2 * cap);    // 2 * cap
+    int* childcnt = cnt0 + 2 * cap;      // 4*cap
     int* scanbuf = childcnt + 4 * cap;   // 5*cap
     int* rankv = scanbuf + 5 * cap;      // cap   (rank of an expandable node in the sorted order)
     int* sorted = rankv + cap;           // cap   (node index at each rank)
@@ -703,8 +706,8 @@ __device__ __forceinline__ void octree_body(
     const int nIni = L.nIni;
     if (tid < nIni) {
         Box16 b; b.x0 = (short)L.rootUL[tid]; b.y0 = 0; b.x1 = (short)L.rootUR[tid]; b.y1 = (short)L.boxH;
-        box[0][tid] = b;
-        cnt[0][tid] = 0;
+        box0[tid] = b;
+        cnt0[tid] = 0;
     }
     __syncthreads();
     {
@@ -724,7 +727,7 @@ __device__ __forceinline__ void octree_body(
             // root (same-address LDS atomics of 64 lanes would serialise)
             for (int q = 0; q < nIni; ++q) {
                 const unsigned long long m = __ballot(r == q);
-                if (m && (tid & 63) == (int)__builtin_ctzll(m)) atomicAdd(&cnt[0][q], (int)__popcll(m));
+                if (m && (tid & 63) == (int)__builtin_ctzll(m)) atomicAdd(&cnt0[q], (int)__popcll(m));
             }
         }
     }
@@ -732,7 +735,7 @@ __device__ __forceinline__ void octree_body(
     if (tid == 0) {  // erase empty roots, keep order (<= 8 roots)
         int m = 0, dropped = 0;
         for (int i = 0; i < nIni; ++i) {
-            if (cnt[0][i] > 0) { scanbuf[i] = m; box[0][m] = box[0][i]; cnt[0][m] = cnt[0][i]; ++m; }
+            if (cnt0[i] > 0) { scanbuf[i] = m; box0[m] = box0[i]; cnt0[m] = cnt0[i]; ++m; }
             else { scanbuf[i] = -1; dropped = 1; }
         }
         s_n = m; s_flag = dropped;
@@ -757,10 +760,10 @@ __device__ __forceinline__ void octree_body(
         __syncthreads();
         for (int k = tid; k < n_keys; k += NT) {
             int nd = ND[k];
-            if (cnt[cur][nd] > 1) {
+            if (cnt0[cur * cap + nd] > 1) {
                 uint32_t xy = XY[k];
                 int mx, my;
-                int q = box_quadrant(box[cur][nd], xy & 0xFFFF, xy >> 16, &mx, &my);
+                int q = box_quadrant(box0[cur * cap + nd], xy & 0xFFFF, xy >> 16, &mx, &my);
                 atomicAdd(&childcnt[nd * 4 + q], 1);
                 ND[k] = (uint16_t)(nd | ((q + 1) << 12));   // the quadrant rides in the label's top bits until the re-label sweep
             }
@@ -776,13 +779,13 @@ __device__ __forceinline__ void octree_body(
             // "largest first": rank expandable nodes by (population desc, list position asc)
             // one wavefront per node i, lanes over j: rank = number of expandable nodes that come before i
             for (int i = tid >> 6; i < n; i += NT / 64) {
-                const int ci_ = cnt[cur][i];
+                const int ci_ = cnt0[cur * cap + i];
                 int r = -1;
                 if (ci_ > 1) {
                     r = 0;
                     for (int j0 = 0; j0 < n; j0 += 64) {
                         const int j = j0 + (tid & 63);
-                        const int cj_ = j < n ? cnt[cur][j] : 0;
+                        const int cj_ = j < n ? cnt0[cur * cap + j] : 0;
                         r += (int)__popcll(__ballot((cj_ > 1) && (cj_ > ci_ || (cj_ == ci_ && j < i))));
                     }
                     if ((tid & 63) == 0) sorted[r] = i;
@@ -793,7 +796,7 @@ __device__ __forceinline__ void octree_body(
             __syncthreads();
             // m = number of expandable nodes
             int local = 0;
-            for (int i = tid; i < n; i += NT) local += cnt[cur][i] > 1;
+            for (int i = tid; i < n; i += NT) local += cnt0[cur * cap + i] > 1;
             if (local) atomicAdd(&s_expand, local);
             __syncthreads();
             const int m = s_expand;
@@ -824,9 +827,9 @@ __device__ __forceinline__ void octree_body(
             nchildslots = 4 * n;
             for (int e = tid; e < 4 * n; e += NT) {
                 int i = n - 1 - (e >> 2), q = 3 - (e & 3);
-                scanbuf[e] = (cnt[cur][i] > 1) && (childcnt[i * 4 + q] > 0);
+                scanbuf[e] = (cnt0[cur * cap + i] > 1) && (childcnt[i * 4 + q] > 0);
             }
-            for (int i = tid; i < n; i += NT) scanbuf[4 * n + i] = cnt[cur][i] <= 1;
+            for (int i = tid; i < n; i += NT) scanbuf[4 * n + i] = cnt0[cur * cap + i] <= 1;
         } else {
             nchildslots = 4 * kproc;
             for (int e = tid; e < nchildslots; e += NT) {
@@ -850,22 +853,22 @@ __device__ __forceinline__ void octree_body(
             int i, q;
             if (!careful) { i = n - 1 - (e >> 2); q = 3 - (e & 3); }
             else { i = sorted[kproc - 1 - (e >> 2)]; q = 3 - (e & 3); }
-            bool split = !careful ? (cnt[cur][i] > 1) : true;
+            bool split = !careful ? (cnt0[cur * cap + i] > 1) : true;
             int cc = childcnt[i * 4 + q];
             if (split && cc > 0) {
                 int pos = scanbuf[e];
                 if (pos < cap) {
-                    box[nxt][pos] = child_box(box[cur][i], q);
-                    cnt[nxt][pos] = cc;
+                    box0[nxt * cap + pos] = child_box(box0[cur * cap + i], q);
+                    cnt0[nxt * cap + pos] = cc;
                 }
                 local_expand += cc > 1;
             }
         }
         for (int i = tid; i < n; i += NT) {
-            bool stays = !careful ? (cnt[cur][i] <= 1) : !(rankv[i] >= 0 && rankv[i] < kproc);
+            bool stays = !careful ? (cnt0[cur * cap + i] <= 1) : !(rankv[i] >= 0 && rankv[i] < kproc);
             if (stays) {
                 int pos = scanbuf[nchildslots + i];
-                if (pos < cap) { box[nxt][pos] = box[cur][i]; cnt[nxt][pos] = cnt[cur][i]; }
+                if (pos < cap) { box0[nxt * cap + pos] = box0[cur * cap + i]; cnt0[nxt * cap + pos] = cnt0[cur * cap + i]; }
             }
         }
         if (local_expand) atomicAdd(&s_expand, local_expand);
