@@ -26,6 +26,10 @@
 #include "ba_types.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+// A pointer read out of BaWin (a struct in HBM) is a GENERIC pointer to the compiler: every access through it is a
+// flat_load / flat_store, which also counts in lgkmcnt -- so each LDS wait of a software pipeline waits for the
+// prefetched HBM data as well.  The hot kernels cast their matrices to the global address space once.
+typedef __attribute__((address_space(1))) double gdouble;
 
 #include "se3_device.h"
 
@@ -287,8 +291,8 @@ __global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
     __shared__ double Bs[BA_TILE * LDS_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t K = (size_t)W.Kpad;
-    const double* A = W.GA + (size_t)(I * BA_TILE) * K;
-    const double* B = W.GB + (size_t)(J * BA_TILE) * K;
+    const gdouble* A = (const gdouble*)W.GA + (size_t)(I * BA_TILE) * K;
+    const gdouble* B = (const gdouble*)W.GB + (size_t)(J * BA_TILE) * K;
     double4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0, 0, 0, 0};
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
         }
     }
     // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
-    double* P = W.part + (size_t)s * W.Npad * W.Npad;
+    gdouble* P = (gdouble*)W.part + (size_t)s * W.Npad * W.Npad;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -468,7 +472,7 @@ __device__ __forceinline__ void ldlt_rows(double* Wd, const double* Dg, int rows
 }
 
 // back-substitution inside one 32-row block: lane k owns x_k, the columns of L11 sit in registers
-__device__ __forceinline__ void ldlt_back_block(const double* S, int N, double* xs, int jb, int nb, int lane) {
+__device__ __forceinline__ void ldlt_back_block(const gdouble* S, int N, double* xs, int jb, int nb, int lane) {
     const int k = lane;
     double v = (k < nb) ? xs[jb + k] : 0.0;
     double col[LD_NB];
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
 #else
 #define STAMP(i)
 #endif
-    double* S = W.S;
+    gdouble* S = (gdouble*)W.S;
     for (int i = tid; i < n; i += LD_THREADS) S[(size_t)n * N + i] = W.rhs[i];  // rhs as row n
     __syncthreads();
     for (int jb = 0; jb < n; jb += LD_NB) {
