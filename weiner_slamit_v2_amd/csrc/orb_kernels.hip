@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
     for (int j = 0; j < 12; ++j) {
         const int idx = lane + 64 * j;
         const int u = c_disc.u[idx], v = c_disc.v[idx];   // padding entries are (0,0): weight zero
-        off[j] = v * stride + u; wu[j] = u; wv[j] = v;
+        off[j] = __mul24(v, stride) + u; wu[j] = u; wv[j] = v;   // |v| <= 15, pitch < 2^23: full-rate 24-bit multiply
     }
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     // all the wave's keypoints at once: their 12 x IC_KP_PER_WAVE byte loads are in flight together, and the
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
 #pragma unroll
     for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
         const int i = min(i0 + k, count - 1);
-        const uint8_t* center = src + ((unsigned)kp0[i].y * (unsigned)stride + (unsigned)kp0[i].x);
+        const uint8_t* center = src + (__umul24((unsigned)kp0[i].y, (unsigned)stride) + (unsigned)kp0[i].x);
 #pragma unroll
         for (int j = 0; j < 12; ++j) val[k][j] = center[off[j]];
     }
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
     for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
         int m10 = 0, m01 = 0;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) { m10 += wu[j] * val[k][j]; m01 += wv[j] * val[k][j]; }
+        for (int j = 0; j < 12; ++j) { m10 += __mul24(wu[j], val[k][j]); m01 += __mul24(wv[j], val[k][j]); }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             m10 += __shfl_xor(m10, d, WAVE);
@@ -1231,23 +1231,29 @@ __global__ __launch_bounds__(256) void describe_kernel(
     for (int it = 0; it < DESC_LOADS; ++it) {
         const int idx = lane + 64 * it;
         lrow[it] = (int)(((unsigned)idx * 5958u) >> 16);   // idx / 11 for idx < 448
-        lcol[it] = idx - lrow[it] * (DESC_PITCH / 4);
+        lcol[it] = idx - __mul24(lrow[it], DESC_PITCH / 4);
+    }
+    // byte offset of each staged dword inside a patch: the same for every keypoint, so it is computed once (24-bit
+    // multiplies are full rate; the v_mul_lo_u32 the compiler would otherwise issue per keypoint and dword is quarter
+    // rate -- the empty asm keeps it from folding these offsets back into (row + y) * pitch)
+    unsigned poff[DESC_LOADS];
+#pragma unroll
+    for (int it = 0; it < DESC_LOADS; ++it) {
+        poff[it] = __umul24((unsigned)min(lrow[it], DESC_ROWS - 1), step) + 4u * (unsigned)lcol[it];
+        asm volatile("" : "+v"(poff[it]));
     }
     uint32_t ld[DESC_KP_PER_WAVE][DESC_LOADS];
 #pragma unroll
     for (int k = 0; k < DESC_KP_PER_WAVE; ++k) {
-        const unsigned base = (unsigned)(kp[k].y - DESC_R) * step + (unsigned)((kp[k].x - DESC_R) & ~3);
+        const unsigned base = __umul24((unsigned)(kp[k].y - DESC_R), step) + (unsigned)((kp[k].x - DESC_R) & ~3);
 #pragma unroll
-        for (int it = 0; it < DESC_LOADS; ++it) {
-            const int row = min(lrow[it], DESC_ROWS - 1);
-            ld[k][it] = *reinterpret_cast<const uint32_t*>(img + (base + (unsigned)row * step + 4u * (unsigned)lcol[it]));
-        }
+        for (int it = 0; it < DESC_LOADS; ++it) ld[k][it] = *reinterpret_cast<const uint32_t*>(img + (base + poff[it]));
     }
 #pragma unroll
     for (int k = 0; k < DESC_KP_PER_WAVE; ++k)
 #pragma unroll
         for (int it = 0; it < DESC_LOADS; ++it)
-            if (lrow[it] < DESC_ROWS) *reinterpret_cast<uint32_t*>(&s_patch[wv][k][lrow[it] * DESC_PITCH + 4 * lcol[it]]) = ld[k][it];
+            if (lrow[it] < DESC_ROWS) *reinterpret_cast<uint32_t*>(&s_patch[wv][k][__mul24(lrow[it], DESC_PITCH) + 4 * lcol[it]]) = ld[k][it];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     int tv0[DESC_KP_PER_WAVE][4], tv1[DESC_KP_PER_WAVE][4];
@@ -1259,7 +1265,7 @@ __global__ __launch_bounds__(256) void describe_kernel(
         for (int t = 0; t < 4; ++t) {
             int r0 = slamit_round_f(px0[t] * b + py0[t] * a), c0 = slamit_round_f(px0[t] * a - py0[t] * b);
             int r1 = slamit_round_f(px1[t] * b + py1[t] * a), c1 = slamit_round_f(px1[t] * a - py1[t] * b);
-            tv0[k][t] = center[r0 * DESC_PITCH + c0]; tv1[k][t] = center[r1 * DESC_PITCH + c1];
+            tv0[k][t] = center[__mul24(r0, DESC_PITCH) + c0]; tv1[k][t] = center[__mul24(r1, DESC_PITCH) + c1];
         }
     }
 #pragma unroll
