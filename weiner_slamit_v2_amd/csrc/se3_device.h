@@ -20,7 +20,19 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
     R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
     R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
-__device__ void R_to_quat(const double* m, double* q) {
+// One case of Eigen's matrix -> quaternion branch for a negative trace, largest diagonal element I.  The indices are
+// compile-time constants: run-time indices into m[] would put the caller's rotation matrix into scratch memory.
+template <int I>
+__device__ __forceinline__ void R_to_quat_case(const double* m, double* q) {
+    constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+    double t = sqrt(m[4 * I] - m[4 * J] - m[4 * K] + 1.0);
+    q[I] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m[3 * K + J] - m[3 * J + K]) * t;
+    q[J] = (m[3 * J + I] + m[3 * I + J]) * t;
+    q[K] = (m[3 * K + I] + m[3 * I + K]) * t;
+}
+__device__ __forceinline__ void R_to_quat(const double* m, double* q) {
     double t = m[0] + m[4] + m[8];
     if (t > 0) {
         t = sqrt(t + 1.0);
@@ -30,16 +42,10 @@ __device__ void R_to_quat(const double* m, double* q) {
     } else {
         int i = 0;
         if (m[4] > m[0]) i = 1;
-        if (m[8] > m[4 * i]) i = 2;
-        int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
-        double qq[4];
-        qq[i] = 0.5 * t;
-        t = 0.5 / t;
-        qq[3] = (m[3 * k + j] - m[3 * j + k]) * t;
-        qq[j] = (m[3 * j + i] + m[3 * i + j]) * t;
-        qq[k] = (m[3 * k + i] + m[3 * i + k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+        if (m[8] > (i ? m[4] : m[0])) i = 2;
+        if (i == 0) R_to_quat_case<0>(m, q);
+        else if (i == 1) R_to_quat_case<1>(m, q);
+        else R_to_quat_case<2>(m, q);
     }
 }
 __device__ __forceinline__ void quat_normalize(double* q) {
