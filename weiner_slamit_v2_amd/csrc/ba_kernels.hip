@@ -23,6 +23,7 @@
 #include <float.h>
 #include <stdint.h>
 
+#define BA_GLOBAL_POINTERS   // BaWin members are global-address-space pointers in this file's device code
 #include "ba_types.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));

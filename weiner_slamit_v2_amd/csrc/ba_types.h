@@ -35,7 +35,15 @@ struct BaState {
     unsigned long long dbg[8];  // diagnostic stamps (s_memtime / s_memrealtime); written only when BA_DIAG_STAMPS is defined
 };
 
-// One window.  All pointers are device addresses inside the handle's slabs.
+// One window.  All pointers are device addresses inside the handle's slabs.  In device code they carry the global
+// address space: a plain pointer read out of a struct in memory is GENERIC to the compiler, and every access through it
+// a flat_load (slower to issue, and it counts in lgkmcnt, so LDS waits also wait for outstanding HBM loads).
+// (Only the kernel translation unit asks for it: host code that fills the struct is also parsed in the device pass.)
+#if defined(BA_GLOBAL_POINTERS) && defined(__HIP_DEVICE_COMPILE__)
+#define BA_G __attribute__((address_space(1)))
+#else
+#define BA_G
+#endif
 struct BaWin {
     int32_t n_kf, n_pt, n_edge, n_free;
     int32_t nS;        // 6 * n_free
@@ -44,37 +52,37 @@ struct BaWin {
     int32_t n_part;    // partial-sum slots of the chi2 reduction
     double huber_delta, chi2_gate;
     // vertices
-    double* pose;      // n_kf x 7: q(x,y,z,w), t
-    double* pose_bak;
-    double* intr;      // n_kf x 4
-    int32_t* pose_col; // n_kf: column block among free poses or -1
-    double* pt;        // n_pt x 3
-    double* pt_bak;
+    BA_G double* pose;      // n_kf x 7: q(x,y,z,w), t
+    BA_G double* pose_bak;
+    BA_G double* intr;      // n_kf x 4
+    BA_G int32_t* pose_col; // n_kf: column block among free poses or -1
+    BA_G double* pt;        // n_pt x 3
+    BA_G double* pt_bak;
     // edges (caller order) + CSR by point and by free pose
-    int32_t* e_kf; int32_t* e_pt;
-    double* e_uv;      // n_edge x 2
-    double* e_w;       // n_edge
-    uint8_t* e_active;
-    uint8_t* e_out1;   // stage-1 outlier flag
-    double* e_chi2;    // chi2 of the last evaluated trial
-    double* e_jac;     // n_edge x 21: A(2x3) B(2x6) wO r0 r1
-    int32_t* pt_ptr; int32_t* pt_edges;     // CSR: edges of each point
-    int32_t* kf_ptr; int32_t* kf_edges;     // CSR: edges of each keyframe
+    BA_G int32_t* e_kf; BA_G int32_t* e_pt;
+    BA_G double* e_uv;      // n_edge x 2
+    BA_G double* e_w;       // n_edge
+    BA_G uint8_t* e_active;
+    BA_G uint8_t* e_out1;   // stage-1 outlier flag
+    BA_G double* e_chi2;    // chi2 of the last evaluated trial
+    BA_G double* e_jac;     // n_edge x 21: A(2x3) B(2x6) wO r0 r1
+    BA_G int32_t* pt_ptr; BA_G int32_t* pt_edges;     // CSR: edges of each point
+    BA_G int32_t* kf_ptr; BA_G int32_t* kf_edges;     // CSR: edges of each keyframe
     // normal equations
-    double* Hll;       // n_pt x 6 (xx xy xz yy yz zz)
-    double* bl;        // n_pt x 3
-    double* Dinv;      // n_pt x 6
-    double* Hpp;       // n_free x 36
-    double* bp;        // n_free x 6
-    double* GA;        // Npad x Kpad : (Hpl * Dinv) scattered, row = pose dof, col = 3*pt + j
-    double* GB;        // Npad x Kpad : Hpl scattered; row nS holds bl
-    double* part;      // BA_SPLITS x Npad x Npad partial products
-    double* S;         // Npad x Npad reduced system (symmetric, full)
-    double* rhs;       // Npad : b_schur in, x_pose out
-    double* x_l;       // n_pt x 3 landmark increments
-    double* chi_part;  // n_part partial robust-cost sums
-    double* scale_part;// n_part partial sums of x(lambda x + b) over landmarks
-    BaState* st;
+    BA_G double* Hll;       // n_pt x 6 (xx xy xz yy yz zz)
+    BA_G double* bl;        // n_pt x 3
+    BA_G double* Dinv;      // n_pt x 6
+    BA_G double* Hpp;       // n_free x 36
+    BA_G double* bp;        // n_free x 6
+    BA_G double* GA;        // Npad x Kpad : (Hpl * Dinv) scattered, row = pose dof, col = 3*pt + j
+    BA_G double* GB;        // Npad x Kpad : Hpl scattered; row nS holds bl
+    BA_G double* part;      // BA_SPLITS x Npad x Npad partial products
+    BA_G double* S;         // Npad x Npad reduced system (symmetric, full)
+    BA_G double* rhs;       // Npad : b_schur in, x_pose out
+    BA_G double* x_l;       // n_pt x 3 landmark increments
+    BA_G double* chi_part;  // n_part partial robust-cost sums
+    BA_G double* scale_part;// n_part partial sums of x(lambda x + b) over landmarks
+    BA_G BaState* st;
 };
 
 #endif

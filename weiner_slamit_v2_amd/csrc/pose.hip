@@ -32,6 +32,28 @@ struct PoseFrame {
     int32_t* n_its;          // 4
     double* chi2_round;      // 4
 };
+// The same record as the kernel sees it: pointers in the global address space.  (Read out of a struct in memory a plain
+// pointer is generic, and every access through it a flat_load; host code that fills PoseFrame is parsed in the device
+// pass too, so the qualified twin is a separate type.)
+#if defined(__HIP_DEVICE_COMPILE__)
+struct PoseFrameG {
+    int32_t n;
+    const __attribute__((address_space(1))) double* pose_in;   // 12
+    const __attribute__((address_space(1))) double* intr;      // 4
+    const __attribute__((address_space(1))) double* xw;        // n x 3
+    const __attribute__((address_space(1))) double* uv;        // n x 2
+    const __attribute__((address_space(1))) double* w;         // n
+    __attribute__((address_space(1))) double* chi2;            // n scratch
+    __attribute__((address_space(1))) uint8_t* outlier;        // n out
+    __attribute__((address_space(1))) double* pose_out;        // 12
+    __attribute__((address_space(1))) int32_t* n_inliers;      // 1
+    __attribute__((address_space(1))) int32_t* n_its;          // 4
+    __attribute__((address_space(1))) double* chi2_round;      // 4
+};
+static_assert(sizeof(PoseFrameG) == sizeof(PoseFrame), "PoseFrameG mirrors PoseFrame");
+#else
+typedef PoseFrame PoseFrameG;   // the host pass only needs the name
+#endif
 
 namespace {
 
@@ -44,7 +66,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {  // 256 thre
 }
 
 // residual + chi2 of every active edge at pose T; returns the robust cost
-__device__ double pose_errors(const PoseFrame& F, const double* T, const uint8_t* active, int robust, double delta, double* sh) {
+__device__ double pose_errors(const PoseFrameG& F, const double* T, const uint8_t* active, int robust, double delta, double* sh) {
     const double dsqr = delta * delta;
     const double fx = F.intr[0], fy = F.intr[1], cx = F.intr[2], cy = F.intr[3];
     double part = 0;
@@ -86,7 +108,7 @@ __device__ bool solve6(const double* H, double lambda, const double* b, double* 
 }  // namespace
 
 __global__ __launch_bounds__(256) void pose_opt_kernel(const PoseFrame* frames) {
-    const PoseFrame F = frames[blockIdx.x];
+    const PoseFrameG F = reinterpret_cast<const PoseFrameG*>(frames)[blockIdx.x];
     const int tid = threadIdx.x, n = F.n;
     __shared__ double sh[4];
     __shared__ double sT0[7], sT[7], sTbak[7], sH[36], sb[6], sx[6];
