@@ -381,6 +381,9 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins) {
 #define LD_NB 32
 #define LD_P (LD_NB + 1)
 #define LD_THREADS 512
+#ifndef LD_CDEPTH
+#define LD_CDEPTH 4         // C tiles of the trailing update in flight per wave
+#endif
 #define LD_PAIRS (LD_NB * (LD_NB - 1) / 2)
 
 // Factor one 32x32 diagonal block in LDS (unit L below, D on the diagonal) with the whole
@@ -586,40 +589,48 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
             double invd8[8];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) invd8[ks] = s_invd[4 * ks + lk];
-            double af[8], bc[8], bn[8];
-            double4_t cc, cn;
+            // LD_CDEPTH C tiles are in flight from L2 per wave; S is addressed in the global address space, so these
+            // loads sit in vmcnt only and the B fragments' LDS waits pass them.  (Measured on the first panel, 20 tiles per
+            // wave: ~2,400 cycles per tile = ~1,000 of MFMA (two waves share a SIMD's matrix unit), ~650 for the C loads
+            // and ~400 for the stores -- one CU moves 64 B/clk and this panel's C traffic alone is 612 KB -- rest LDS.)
+            double af[8], bf[8];
+            double4_t cq[LD_CDEPTH];
             int art = -1;
-            auto load_tile = [&](int frt, int fct, double4_t& C, double* B) {
+            auto load_c = [&](int frt, int fct, double4_t& C) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r = 16 * frt + lk + 4 * g, c = 16 * fct + l15;
                     C[g] = (r < rows && c < below && c <= r) ? S[(size_t)(base + r) * N + base + c] : 0.0;
                 }
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) B[ks] = Wd[(16 * fct + l15) * LD_P + 4 * ks + lk];
             };
-            load_tile(rt, ct, cc, bc);
-            for (; t < tend; ++t) {
-                if (rt != art) {
+            auto advance = [&](int& art_, int& act_) { if (++act_ >= min(art_ + 1, CT)) { ++art_; act_ = 0; } };
+            int lrt = rt, lct = ct;   // tile whose C is fetched next
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) af[ks] = -Wd[(16 * rt + l15) * LD_P + 4 * ks + lk] * invd8[ks];
-                    art = rt;
+            for (int d = 0; d < LD_CDEPTH; ++d)
+                if (t + d < tend) { load_c(lrt, lct, cq[d]); advance(lrt, lct); }
+            for (; t < tend; t += LD_CDEPTH) {
+#pragma unroll
+                for (int d = 0; d < LD_CDEPTH; ++d) {
+                    if (t + d < tend) {
+                        if (rt != art) {
+#pragma unroll
+                            for (int ks = 0; ks < 8; ++ks) af[ks] = -Wd[(16 * rt + l15) * LD_P + 4 * ks + lk] * invd8[ks];
+                            art = rt;
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) bf[ks] = Wd[(16 * ct + l15) * LD_P + 4 * ks + lk];
+                        double4_t acc = cq[d];
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bf[ks], acc, 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int r = 16 * rt + lk + 4 * g, c = 16 * ct + l15;
+                            if (r < rows && c < below && c <= r) S[(size_t)(base + r) * N + base + c] = acc[g];
+                        }
+                        if (t + d + LD_CDEPTH < tend) { load_c(lrt, lct, cq[d]); advance(lrt, lct); }
+                        advance(rt, ct);
+                    }
                 }
-                int nrt = rt, nct = ct + 1;
-                if (nct >= min(rt + 1, CT)) { nrt = rt + 1; nct = 0; }
-                if (t + 1 < tend) load_tile(nrt, nct, cn, bn);
-                double4_t acc = cc;
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bc[ks], acc, 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int r = 16 * rt + lk + 4 * g, c = 16 * ct + l15;
-                    if (r < rows && c < below && c <= r) S[(size_t)(base + r) * N + base + c] = acc[g];
-                }
-                cc = cn;
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) bc[ks] = bn[ks];
-                rt = nrt; ct = nct;
             }
         }
 #endif
