@@ -207,6 +207,54 @@ int slamit_guided_search(int device, const slamit_frame_view* frame, const slami
                          const slamit_search_rule* rule, int32_t* match_kp, int32_t* nmatches, int32_t* best_dist,
                          int32_t* best_level, int32_t* second_dist, int32_t* second_level);
 
+/* ---- Vocabulary-node search (beyond SURVEY.md §8f: the BoW drivers of ORBmatcher) ----------------------
+ * The loop bodies of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:161-290),
+ * ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) (:526-657) and ORBmatcher::SearchForTriangulation (:659-826):
+ * features of the two sides that fall into the same vocabulary node (DBoW2::FeatureVector, built by the reference's
+ * vendored DBoW2 on the host) are compared with DescriptorDistance.  A group = one node present on both sides:
+ * its side-1 feature indices in processing order (queries) and its side-2 feature indices in scan order (candidates).
+ * A feature belongs to one node, so groups are independent (checked: an index may appear once per side); one
+ * wavefront walks a group's queries in order.
+ *
+ * mode 0 (SearchByBoW): per query best / second best with strict '<' over the candidates that are allowed (valid2)
+ *   and not yet matched by an earlier query; accepted iff best <= th (th_inclusive, :243) or best < th (:601) and
+ *   (float)best < nnratio * (float)second (second = 256 without one); an accepted query takes its candidate.
+ * mode 1 (SearchForTriangulation, monocular): per query the candidate of minimum distance among those with
+ *   dist <= th that pass the epipole test (:737-743) and CheckDistEpipolarLine (:135-158), the LAST such candidate on
+ *   ties (:731 'dist > bestDist' lets an equal one replace); candidates are never marked (the reference declares
+ *   vbMatched2 but does not set it).  Float expressions are evaluated as written, without contraction.
+ * The rotation-histogram filter that follows in all three drivers (mbCheckOrientation) is host logic (shim). */
+typedef struct slamit_bow_groups {
+    int32_t n_groups;
+    const int32_t* q_ptr;      /* n_groups + 1: queries of group g are q_idx[q_ptr[g] .. q_ptr[g+1]) */
+    const int32_t* q_idx;      /* side-1 feature indices */
+    const int32_t* c_ptr;      /* n_groups + 1 */
+    const int32_t* c_idx;      /* side-2 feature indices */
+} slamit_bow_groups;
+
+typedef struct slamit_bow_rule {
+    int32_t mode;              /* 0 SearchByBoW, 1 SearchForTriangulation */
+    int32_t th;                /* TH_LOW = 50 */
+    int32_t th_inclusive;      /* mode 0: 1 = best <= th (KeyFrame/Frame), 0 = best < th (KeyFrame/KeyFrame) */
+    float nnratio;             /* mode 0 */
+    /* mode 1 only */
+    float F12[9];              /* fundamental matrix, row-major */
+    float ex, ey;              /* epipole of camera 1 in image 2 */
+    const float* kp1_xy;       /* n1 x 2: mvKeysUn of side 1 */
+    const float* kp2_xy;       /* n2 x 2 */
+    const int32_t* kp2_octave; /* n2 */
+    float scale_factor[16];    /* pKF2->mvScaleFactors */
+    float level_sigma2[16];    /* pKF2->mvLevelSigma2 */
+} slamit_bow_rule;
+
+#define SLAMIT_BOW_MAX_GROUP 2048   /* candidates of one group */
+/* valid1[i] != 0: side-1 feature i is a query (has a good MapPoint / has none yet); valid2[i] != 0: side-2 feature i
+ * may be matched; either may be NULL (= all).  match12[i] = matched side-2 index or -1, dist12[i] (may be NULL) = the
+ * best distance query i saw (256 if none); both have n1 entries.  *nmatches = accepted queries. */
+int slamit_bow_search(int device, const uint8_t* desc1, int32_t n1, const uint8_t* valid1, const uint8_t* desc2, int32_t n2,
+                      const uint8_t* valid2, const slamit_bow_groups* groups, const slamit_bow_rule* rule, int32_t* match12,
+                      int32_t* dist12, int32_t* nmatches);
+
 /* ---- Frame epilogue -------------------------------------------------------
  * What Frame's constructors do right after the extractor: Frame::UndistortKeyPoints (src/Frame.cc:529-559, through
  * cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK)) and Frame::AssignFeaturesToGrid (:336-357, PosInGrid

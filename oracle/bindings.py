@@ -73,6 +73,9 @@ def orb_lib():
         L.orb_oracle_search_init.argtypes = [C.c_int, _i32p, _u8p, _f32p, C.c_int, _f32p, _i32p, _u8p, C.c_float, C.c_float, C.c_float,
                                              C.c_float, C.c_int, C.c_float, C.c_int, _i32p, _i32p]
         L.orb_oracle_undistort.argtypes = [_f32p, _f32p, C.c_int, _f32p]
+        L.orb_oracle_bow_search.argtypes = [C.c_int, _u8p, C.c_int, _u8p, _u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p, _i32p,
+                                            C.c_int, C.c_int, C.c_float, _f32p, C.c_float, C.c_float, _f32p, _f32p, _i32p, _f32p,
+                                            _f32p, _i32p, _i32p]
         L.orb_oracle_frame_finish.argtypes = [_f32p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                               _i32p, _i32p]
         _orb = L
@@ -283,6 +286,36 @@ def search_for_initialization(f1, prev_xy, f2, window=100, nnratio=0.9, th_low=5
                                           float(np.float32(f2["inv_w"])), float(np.float32(f2["inv_h"])), int(window),
                                           float(np.float32(nnratio)), int(th_low), _ptr(m12, _i32p), _ptr(acc, _i32p))
     return m12[:len(o1)], nm, acc[:len(o1)]
+
+
+def bow_search(side1, side2, groups, mode=0, th=50, th_inclusive=True, nnratio=0.6, epi=None):
+    """The BoW drivers' matching loops (orb_oracle_bow_search).  side1 / side2: dicts with desc (n, 32), optional valid
+    (n) and, for mode 1, kp_xy (n, 2) (+ kp_octave on side 2); groups: dict q_ptr, q_idx, c_ptr, c_idx; epi (mode 1):
+    dict F12 (9), ex, ey, scale_factor (16), level_sigma2 (16).  Returns (match12, dist12, nmatches)."""
+    d1 = np.ascontiguousarray(side1["desc"], np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(side2["desc"], np.uint8).reshape(-1, 32)
+    n1, n2 = len(d1), len(d2)
+    v1 = None if side1.get("valid") is None else np.ascontiguousarray(side1["valid"], np.uint8)
+    v2 = None if side2.get("valid") is None else np.ascontiguousarray(side2["valid"], np.uint8)
+    qp, qi, cp, ci = (np.ascontiguousarray(groups[k], np.int32) for k in ("q_ptr", "q_idx", "c_ptr", "c_idx"))
+    m12, dd = np.full(max(n1, 1), -1, np.int32), np.full(max(n1, 1), 256, np.int32)
+    null_f, null_i, null_u = C.cast(None, _f32p), C.cast(None, _i32p), C.cast(None, _u8p)
+    if mode == 1:
+        F = np.ascontiguousarray(epi["F12"], np.float32).reshape(9)
+        k1 = np.ascontiguousarray(side1["kp_xy"], np.float32).reshape(-1, 2)
+        k2 = np.ascontiguousarray(side2["kp_xy"], np.float32).reshape(-1, 2)
+        o2 = np.ascontiguousarray(side2["kp_octave"], np.int32)
+        sf = np.ascontiguousarray(epi["scale_factor"], np.float32)
+        s2 = np.ascontiguousarray(epi["level_sigma2"], np.float32)
+        extra = (_ptr(F, _f32p), float(np.float32(epi["ex"])), float(np.float32(epi["ey"])), _ptr(k1, _f32p), _ptr(k2, _f32p),
+                 _ptr(o2, _i32p), _ptr(sf, _f32p), _ptr(s2, _f32p))
+    else:
+        extra = (null_f, 0.0, 0.0, null_f, null_f, null_i, null_f, null_f)
+    nm = orb_lib().orb_oracle_bow_search(int(mode), _ptr(d1), n1, _ptr(v1) if v1 is not None else null_u, _ptr(d2), n2,
+                                         _ptr(v2) if v2 is not None else null_u, len(qp) - 1, _ptr(qp, _i32p), _ptr(qi, _i32p),
+                                         _ptr(cp, _i32p), _ptr(ci, _i32p), int(th), int(bool(th_inclusive)),
+                                         float(np.float32(nnratio)), *extra, _ptr(m12, _i32p), _ptr(dd, _i32p))
+    return m12[:n1], dd[:n1], nm
 
 
 def undistort(cam9, xy):

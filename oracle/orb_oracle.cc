@@ -1024,3 +1024,76 @@ extern "C" int orb_oracle_search_init(int n1, const int32_t* kp1_octave, const u
     delete g;
     return nmatches;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The BoW drivers' matching loops, over node groups that the caller has already intersected (the while / lower_bound
+// walk over the two DBoW2::FeatureVectors, ORBmatcher.cc:184-278, is host logic in the shim).  Sequential like the
+// reference: groups in order, queries in order, candidates in order.
+//   mode 0: ORBmatcher::SearchByBoW(KeyFrame*, Frame&) :187-262 (th_inclusive = 1, valid2 = NULL) and
+//           ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*) :558-628 (th_inclusive = 0, valid2 = good MapPoint)
+//   mode 1: ORBmatcher::SearchForTriangulation :697-782 (monocular: bStereo1 = bStereo2 = false, bOnlyStereo = false)
+//           with CheckDistEpipolarLine :141-158.  vbMatched2 is declared by the reference and never set: no exclusion.
+// The rotation histogram that follows (:264-287 / :630-654 / :784-808) is host logic in the shim.  PARITY UNPINNED
+// for the float gates of mode 1 (whether the reference's compiler contracts a*b+c is not known; none here).
+extern "C" int orb_oracle_bow_search(int mode, const uint8_t* desc1, int n1, const uint8_t* valid1, const uint8_t* desc2, int n2,
+                                     const uint8_t* valid2, int n_groups, const int32_t* q_ptr, const int32_t* q_idx,
+                                     const int32_t* c_ptr, const int32_t* c_idx, int th, int th_inclusive, float nnratio,
+                                     const float* F12, float ex, float ey, const float* kp1_xy, const float* kp2_xy,
+                                     const int32_t* kp2_octave, const float* scale_factor, const float* level_sigma2,
+                                     int32_t* match12, int32_t* dist12) {
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) { match12[i] = -1; dist12[i] = 256; }
+    std::vector<bool> vbMatched2((size_t)n2, false);
+    for (int g = 0; g < n_groups; g++) {
+        for (int a = q_ptr[g]; a < q_ptr[g + 1]; a++) {
+            const int idx1 = q_idx[a];
+            if (valid1 && !valid1[idx1]) continue;
+            const uint8_t* d1 = desc1 + 32 * (size_t)idx1;
+            if (mode == 0) {
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int b = c_ptr[g]; b < c_ptr[g + 1]; b++) {
+                    const int idx2 = c_idx[b];
+                    if (vbMatched2[idx2] || (valid2 && !valid2[idx2])) continue;
+                    const int dist = descriptor_distance(d1, desc2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestIdx2 >= 0) dist12[idx1] = bestDist1;
+                // (bestIdx2 < 0 can only get here with th >= 256, outside the reference's TH_LOW = 50; the reference would
+                //  index its match vector with -1 there)
+                if (bestIdx2 >= 0 && (th_inclusive ? bestDist1 <= th : bestDist1 < th)) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        match12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        nmatches++;
+                    }
+                }
+            } else {
+                const float x1 = kp1_xy[2 * idx1], y1 = kp1_xy[2 * idx1 + 1];
+                int bestDist = th, bestIdx2 = -1;
+                for (int b = c_ptr[g]; b < c_ptr[g + 1]; b++) {
+                    const int idx2 = c_idx[b];
+                    if (valid2 && !valid2[idx2]) continue;
+                    const int dist = descriptor_distance(d1, desc2 + 32 * (size_t)idx2);
+                    if (dist > th || dist > bestDist) continue;
+                    const float x2 = kp2_xy[2 * idx2], y2 = kp2_xy[2 * idx2 + 1];
+                    const int oct = kp2_octave[idx2];
+                    const float distex = ex - x2;
+                    const float distey = ey - y2;
+                    if (distex * distex + distey * distey < 100 * scale_factor[oct]) continue;
+                    // CheckDistEpipolarLine
+                    const float la = x1 * F12[0] + y1 * F12[3] + F12[6];
+                    const float lb = x1 * F12[1] + y1 * F12[4] + F12[7];
+                    const float lc = x1 * F12[2] + y1 * F12[5] + F12[8];
+                    const float num = la * x2 + lb * y2 + lc;
+                    const float den = la * la + lb * lb;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    if (dsqr < 3.84 * level_sigma2[oct]) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) { match12[idx1] = bestIdx2; dist12[idx1] = bestDist; nmatches++; }
+            }
+        }
+    }
+    return nmatches;
+}

@@ -586,3 +586,64 @@ def test_search_for_initialization_matches_model():
             enm += 1
     assert np.array_equal(m12, e12) and nm == enm and np.array_equal(acc, eacc)
     assert nm > 100 and (acc >= 0).sum() > nm          # some matches were taken over
+
+
+# ---- BoW drivers' loops (orb_oracle_bow_search): definitional checks of the restatement ---------------------------
+def _flip(d, nbits):
+    d = d.copy()
+    for b in range(nbits):
+        d[b >> 3] ^= np.uint8(1 << (b & 7))
+    return d
+
+
+def test_bow_oracle_mode0_order_dependence_and_thresholds():
+    base = np.random.RandomState(1).randint(0, 256, 32).astype(np.uint8)
+    # side 2: candidate 0 at distance 10 from base, candidate 1 at distance 30
+    s2 = dict(desc=np.stack([_flip(base, 10), _flip(base, 30)]), valid=None)
+    # two identical queries in one group: the first takes candidate 0; the second then sees only candidate 1 (30 < 0.6 * 256)
+    s1 = dict(desc=np.stack([base, base]), valid=None)
+    g = dict(q_ptr=[0, 2], q_idx=[0, 1], c_ptr=[0, 2], c_idx=[0, 1])
+    m, d, nm = ob.bow_search(s1, s2, g, mode=0, th=50, th_inclusive=True, nnratio=0.6)
+    assert list(m) == [0, 1] and list(d) == [10, 30] and nm == 2
+    # ratio test: 10 < 0.3 * 30 fails -> the first query takes nothing, the second is in the same situation
+    m, d, nm = ob.bow_search(s1, s2, g, mode=0, th=50, th_inclusive=True, nnratio=0.3)
+    assert list(m) == [-1, -1] and list(d) == [10, 10] and nm == 0
+    # threshold: th = 10 inclusive accepts, exclusive rejects (ORBmatcher.cc:243 '<=' vs :601 '<')
+    s2one = dict(desc=s2["desc"][:1], valid=None)
+    g1 = dict(q_ptr=[0, 1], q_idx=[0], c_ptr=[0, 1], c_idx=[0])
+    assert ob.bow_search(s1, s2one, g1, mode=0, th=10, th_inclusive=True, nnratio=0.6)[2] == 1
+    assert ob.bow_search(s1, s2one, g1, mode=0, th=10, th_inclusive=False, nnratio=0.6)[2] == 0
+    # masks: an invalid query is skipped, an invalid candidate is invisible
+    assert ob.bow_search(dict(s1, valid=[0, 1]), s2, g, mode=0, th=50, nnratio=0.6)[0].tolist() == [-1, 0]
+    assert ob.bow_search(s1, dict(s2, valid=[0, 1]), g, mode=0, th=50, nnratio=0.6)[0].tolist() == [1, -1]
+    # groups do not see each other's candidates
+    g2 = dict(q_ptr=[0, 1, 2], q_idx=[0, 1], c_ptr=[0, 1, 2], c_idx=[1, 0])
+    assert ob.bow_search(s1, s2, g2, mode=0, th=50, nnratio=0.6)[0].tolist() == [1, 0]
+
+
+def test_bow_oracle_mode1_gates_and_last_wins():
+    base = np.random.RandomState(2).randint(0, 256, 32).astype(np.uint8)
+    # F12 of a sideways translation between identical cameras: the epipolar line of (x1, y1) is the row y = y1
+    F = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)
+    scale = (np.float32(1.2) ** np.arange(16, dtype=np.float32)).tolist()
+    epi = dict(F12=F, ex=-1e6, ey=-1e6, scale_factor=scale, level_sigma2=[s * s for s in scale])
+    s1 = dict(desc=base[None], valid=None, kp_xy=[[100.0, 50.0]])
+    # three candidates at distance 20, all on the line; two at the same distance: the LAST one wins (ORBmatcher.cc:731)
+    s2 = dict(desc=np.stack([_flip(base, 20)] * 3), valid=None, kp_xy=[[80.0, 50.0], [70.0, 50.5], [60.0, 49.5]], kp_octave=[0, 0, 0])
+    g = dict(q_ptr=[0, 1], q_idx=[0], c_ptr=[0, 3], c_idx=[0, 1, 2])
+    m, d, nm = ob.bow_search(s1, s2, g, mode=1, th=50, epi=epi)
+    assert list(m) == [2] and list(d) == [20] and nm == 1
+    # 2 px off the line at octave 0: dsqr = 4 > 3.84 -> rejected; at octave 2 (sigma2 = 2.07) 4 < 7.96 -> accepted
+    s2b = dict(s2, kp_xy=[[80.0, 50.0], [70.0, 50.5], [60.0, 52.0]])
+    assert ob.bow_search(s1, s2b, g, mode=1, th=50, epi=epi)[0].tolist() == [1]
+    assert ob.bow_search(s1, dict(s2b, kp_octave=[0, 0, 2]), g, mode=1, th=50, epi=epi)[0].tolist() == [2]
+    # epipole test: a candidate closer than sqrt(100 * scaleFactor) to the epipole is skipped
+    epi_near = dict(epi, ex=60.0, ey=49.5)
+    assert ob.bow_search(s1, s2, g, mode=1, th=50, epi=epi_near)[0].tolist() == [1]
+    # distance gate: nothing above th
+    assert ob.bow_search(s1, s2, g, mode=1, th=19, epi=epi)[2] == 0
+    # a closer candidate beats a later equal one
+    s2c = dict(s2, desc=np.stack([_flip(base, 20), _flip(base, 5), _flip(base, 20)]))
+    assert ob.bow_search(s1, s2c, g, mode=1, th=50, epi=epi)[0].tolist() == [1]
+    # degenerate line (F = 0): den == 0 -> no match
+    assert ob.bow_search(s1, s2, g, mode=1, th=50, epi=dict(epi, F12=np.zeros(9, np.float32)))[2] == 0

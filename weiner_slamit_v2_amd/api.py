@@ -79,6 +79,16 @@ def _search_rule(th_dist, use_ratio, nnratio, chi2_gate=0.0, inv_level_sigma2=No
     return SearchRule(int(th_dist), int(bool(use_ratio)), float(nnratio), float(chi2_gate), (C.c_float * 16)(*sig), int(mode))
 
 
+class BowGroups(C.Structure):
+    _fields_ = [("n_groups", C.c_int32), ("q_ptr", C.c_void_p), ("q_idx", C.c_void_p), ("c_ptr", C.c_void_p), ("c_idx", C.c_void_p)]
+
+
+class BowRule(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("th", C.c_int32), ("th_inclusive", C.c_int32), ("nnratio", C.c_float),
+                ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float), ("kp1_xy", C.c_void_p), ("kp2_xy", C.c_void_p),
+                ("kp2_octave", C.c_void_p), ("scale_factor", C.c_float * 16), ("level_sigma2", C.c_float * 16)]
+
+
 class SearchBatch(C.Structure):
     _fields_ = [("nframes", C.c_int32), ("kp_cap", C.c_int32), ("q_cap", C.c_int32), ("d_n", C.c_void_p),
                 ("d_kps_un", C.c_void_p), ("d_desc", C.c_void_p), ("d_kp_taken", C.c_void_p), ("min_x", C.c_float),
@@ -108,7 +118,7 @@ EXPORTS = [
     "slamit_orb_create", "slamit_orb_destroy", "slamit_orb_tables", "slamit_orb_max_keypoints",
     "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
     "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
-    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_guided_search_workspace", "slamit_guided_search_batch_dev", "slamit_undistort_points", "slamit_frame_finish",
+    "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_guided_search_workspace", "slamit_guided_search_batch_dev", "slamit_bow_search", "slamit_undistort_points", "slamit_frame_finish",
     "slamit_frame_finish_batch_dev", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
     "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
 ]
@@ -153,6 +163,7 @@ def lib():
         L.slamit_guided_search_workspace.restype = sz
         L.slamit_guided_search_batch_dev.argtypes = [i32, C.POINTER(SearchBatch), C.POINTER(SearchRule), vp, vp, vp, vp, sz, vp]
         f32 = C.c_float
+        L.slamit_bow_search.argtypes = [i32, vp, i32, vp, vp, i32, vp, C.POINTER(BowGroups), C.POINTER(BowRule), vp, vp, vp]
         L.slamit_undistort_points.argtypes = [i32, C.POINTER(Camera), vp, i32, vp]
         L.slamit_frame_finish.argtypes = [i32, C.POINTER(Camera), vp, i32, f32, f32, f32, f32, vp, vp, vp]
         L.slamit_frame_finish_batch_dev.argtypes = [i32, C.POINTER(Camera), vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp]
@@ -476,6 +487,41 @@ class ORBmatcher:
         frame = dict(f2, kp_taken=np.zeros(len(np.asarray(f2["kp_octave"])), np.uint8))
         m12, nm, out4 = ORBmatcher.guided_search(frame, q, th_low, False, nnratio, device=device, mode=1)
         return m12, nm, out4[:, 1].copy()   # the level slot carries the keypoint accepted at the query's own turn
+
+    @staticmethod
+    def bow_search(side1, side2, groups, mode=0, th=50, th_inclusive=True, nnratio=0.6, epi=None, device=0):
+        """The matching loops of SearchByBoW (mode 0; ORBmatcher.cc:161-290, 526-657) and SearchForTriangulation (mode 1;
+        :659-826) over vocabulary-node groups.  side1 / side2: dicts with desc (n, 32), optional valid (n) and, for mode 1,
+        kp_xy (n, 2) (+ kp_octave on side 2); groups: dict q_ptr, q_idx, c_ptr, c_idx (CSR per common node); epi (mode 1):
+        dict F12 (9, row-major), ex, ey, scale_factor (16), level_sigma2 (16).  Returns (match12, dist12, nmatches)
+        before the rotation-histogram filter."""
+        d1 = np.ascontiguousarray(side1["desc"], np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(side2["desc"], np.uint8).reshape(-1, 32)
+        n1, n2 = len(d1), len(d2)
+        v1 = None if side1.get("valid") is None else np.ascontiguousarray(side1["valid"], np.uint8)
+        v2 = None if side2.get("valid") is None else np.ascontiguousarray(side2["valid"], np.uint8)
+        qp, qi, cp, ci = (np.ascontiguousarray(groups[k], np.int32) for k in ("q_ptr", "q_idx", "c_ptr", "c_idx"))
+        g = BowGroups(len(qp) - 1, qp.ctypes.data, qi.ctypes.data, cp.ctypes.data, ci.ctypes.data)
+        rule = BowRule()
+        rule.mode, rule.th, rule.th_inclusive, rule.nnratio = int(mode), int(th), int(bool(th_inclusive)), float(nnratio)
+        keep = []
+        if mode == 1:
+            k1 = np.ascontiguousarray(side1["kp_xy"], np.float32).reshape(-1, 2)
+            k2 = np.ascontiguousarray(side2["kp_xy"], np.float32).reshape(-1, 2)
+            o2 = np.ascontiguousarray(side2["kp_octave"], np.int32)
+            keep = [k1, k2, o2]
+            rule.F12 = (C.c_float * 9)(*[float(v) for v in np.asarray(epi["F12"], np.float32).reshape(9)])
+            rule.ex, rule.ey = float(np.float32(epi["ex"])), float(np.float32(epi["ey"]))
+            rule.kp1_xy, rule.kp2_xy, rule.kp2_octave = k1.ctypes.data, k2.ctypes.data, o2.ctypes.data
+            rule.scale_factor = (C.c_float * 16)(*[float(v) for v in list(epi["scale_factor"])[:16] + [1.0] * (16 - len(epi["scale_factor"]))])
+            rule.level_sigma2 = (C.c_float * 16)(*[float(v) for v in list(epi["level_sigma2"])[:16] + [1.0] * (16 - len(epi["level_sigma2"]))])
+        m12, dd = np.full(max(n1, 1), -1, np.int32), np.full(max(n1, 1), 256, np.int32)
+        nm = C.c_int32(0)
+        _check(lib().slamit_bow_search(device, _np_ptr(d1), n1, _np_ptr(v1) if v1 is not None else None, _np_ptr(d2), n2,
+                                       _np_ptr(v2) if v2 is not None else None, C.byref(g), C.byref(rule), _np_ptr(m12),
+                                       _np_ptr(dd), C.byref(nm)), "slamit_bow_search")
+        del keep
+        return m12[:n1], dd[:n1], nm.value
 
     def match(self, q, t, th=None):
         """All-pairs match with the reference's acceptance rule: best <= th and best < nnratio*second

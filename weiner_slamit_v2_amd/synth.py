@@ -294,3 +294,59 @@ def synth_init_pair(n=1500, seed=0):
     f1 = dict(kp_octave=o1, desc=d1, angle=rs.uniform(0, 360, n1).astype(np.float32))
     f2["angle"] = rs.uniform(0, 360, n).astype(np.float32)
     return f1, prev, f2
+
+
+def synth_bow(n1=1000, n2=1000, n_nodes=100, seed=0, mode=0, big_group=0):
+    """Two keyframes as the BoW drivers see them: descriptors, per-feature vocabulary node (DBoW2::FeatureVector at
+    levelsup 4 puts ~10 features of a 1000-feature frame into each of ~100 nodes), validity masks, and the node groups
+    common to both sides in ascending node order (what the reference's while / lower_bound walk visits).  Side 2 holds
+    noisy copies of side-1 descriptors (several per source now and then, so queries compete for candidates) that mostly
+    share the source's node.  mode 1 adds the SearchForTriangulation geometry: a pure sideways translation between two
+    identical pinhole cameras (epipolar lines are image rows), matching features on the same row up to a pixel or two.
+    big_group > 0 forces that many candidates into one node (more than one wavefront of them).
+    Returns (side1, side2, groups, epi)."""
+    rs = np.random.RandomState(5000 + seed)
+    d1 = rs.randint(0, 256, (n1, 32)).astype(np.uint8)
+    node1 = rs.randint(0, max(n_nodes, 1), n1)
+    src = rs.randint(0, max(n1, 1), n2) if n1 else np.zeros(n2, np.int64)
+    d2 = d1[src].copy() if n1 else rs.randint(0, 256, (n2, 32)).astype(np.uint8)
+    for i in range(n2):
+        for b in rs.randint(0, 256, rs.randint(0, 90)):          # up to ~90 flipped bits
+            d2[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    node2 = np.where(rs.rand(n2) < 0.85, node1[src] if n1 else 0, rs.randint(0, max(n_nodes, 1), n2))
+    if big_group and n2:
+        node2[:min(big_group, n2)] = node1[0] if n1 else 0
+    if n2 > 10:                                                   # exact duplicates: ties in distance
+        d2[1] = d2[0]; node2[1] = node2[0]
+    side1 = dict(desc=d1, valid=(rs.rand(n1) < 0.8).astype(np.uint8))
+    side2 = dict(desc=d2, valid=None if mode == 0 and seed % 2 == 0 else (rs.rand(n2) < 0.85).astype(np.uint8))
+    qp, qi, cp, ci = [0], [], [0], []
+    for node in sorted(set(node1.tolist()) & set(node2.tolist())):
+        a, b = np.nonzero(node1 == node)[0], np.nonzero(node2 == node)[0]
+        qi += a.tolist(); ci += b.tolist()
+        qp.append(len(qi)); cp.append(len(ci))
+    groups = dict(q_ptr=np.array(qp, np.int32), q_idx=np.array(qi, np.int32), c_ptr=np.array(cp, np.int32), c_idx=np.array(ci, np.int32))
+    epi = None
+    if mode == 1:
+        fx, fy, cx, cy = np.float32(517.3), np.float32(516.5), np.float32(318.6), np.float32(255.3)
+        xy1 = np.stack([rs.uniform(20, 620, n1), rs.uniform(20, 460, n1)], 1).astype(np.float32)
+        # camera 2 = camera 1 shifted along x: x2 = x1 - disparity, y2 = y1 (+ noise; some far off the line)
+        disp = rs.uniform(2, 60, n2).astype(np.float32)
+        noise = np.where(rs.rand(n2) < 0.75, rs.normal(0, 0.8, n2), rs.normal(0, 12.0, n2)).astype(np.float32)
+        xy2 = np.stack([xy1[src, 0] - disp, xy1[src, 1] + noise], 1).astype(np.float32) if n1 else np.zeros((n2, 2), np.float32)
+        oct2 = rs.randint(0, 8, n2).astype(np.int32)
+        # F12 with x1^T F12 x2 = 0 for t = (b, 0, 0), R = I:  F = K^-T [t]x K^-1  (any scale)
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+        tx = np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])
+        Ki = np.linalg.inv(K)
+        F = (Ki.T @ tx @ Ki).astype(np.float32)
+        if seed % 3 == 0:
+            F[:, :] = 0                                           # degenerate: den == 0 for every query
+        scale = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+        # the epipole of a sideways translation is at infinity; put a finite one inside the image to exercise :737-743
+        epi = dict(F12=F.reshape(9), ex=float(xy2[0, 0]) if n2 else 0.0, ey=float(xy2[0, 1]) if n2 else 0.0,
+                   scale_factor=scale.tolist(), level_sigma2=(scale * scale).tolist())
+        side1["kp_xy"] = xy1
+        side2["kp_xy"] = xy2
+        side2["kp_octave"] = oct2
+    return side1, side2, groups, epi
