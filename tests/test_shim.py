@@ -597,3 +597,121 @@ def test_shim_global_bundle_adjustment(tmp_path, name, its, loopkf):
     assert np.abs(pts - ref["pt_xyz"]).max() < tol * np.abs(ref["pt_xyz"]).max()
     assert erased == 0                                  # a global BA never erases observations
     assert updates == (P if loopkf == 0 else -P)        # UpdateNormalAndDepth only on the direct write-back path
+
+
+def _three_maxima(sizes):
+    """ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1605-1646): indices of the kept bins."""
+    max1 = max2 = max3 = 0
+    i1 = i2 = i3 = -1
+    for i, s in enumerate(sizes):
+        if s > max1:
+            max3, max2, max1 = max2, max1, s
+            i3, i2, i1 = i2, i1, i
+        elif s > max2:
+            max3, max2 = max2, s
+            i3, i2 = i2, i
+        elif s > max3:
+            max3, i3 = s, i
+    if max2 < 0.1 * float(max1):
+        i2 = i3 = -1
+    elif max3 < 0.1 * float(max1):
+        i3 = -1
+    return {i1, i2, i3}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_shim_bow_drivers(tmp_path, variant):
+    """SearchByBoW(KeyFrame*, Frame&), SearchByBoW(KeyFrame*, KeyFrame*) and SearchForTriangulation through the templates:
+    feature-vector walk and rotation histogram on the host, the node loops in one slamit_bow_search call.  Expected =
+    the oracle's sequential loops + the same histogram in numpy."""
+    from oracle import bindings as ob
+    from weiner_slamit_v2_amd import synth
+
+    _build()
+    f32 = np.float32
+    n1, n2, nodes, nnratio = 1100, 1000, 90, 0.75
+    s1, s2, g, epi = synth.synth_bow(n1, n2, nodes, 21 + variant, mode=1)
+    rs = np.random.RandomState(17 + variant)
+    # map-point state per feature: 0 none, 1 good, 2 bad
+    pr = [0.8, 0.15, 0.05] if variant == 2 else [0.3, 0.6, 0.1]   # triangulation matches the features WITHOUT a map point
+    mp1 = rs.choice([0, 1, 2], n1, p=pr).astype(np.int32)
+    mp2 = rs.choice([0, 1, 2], n2, p=pr).astype(np.int32)
+    # the node of every feature, recovered from the groups (features outside common nodes get private node ids)
+    node1, node2 = np.full(n1, -1, np.int32), np.full(n2, -1, np.int32)
+    for k in range(len(g["q_ptr"]) - 1):
+        node1[g["q_idx"][g["q_ptr"][k]:g["q_ptr"][k + 1]]] = 2 * k
+        node2[g["c_idx"][g["c_ptr"][k]:g["c_ptr"][k + 1]]] = 2 * k
+    node1[node1 < 0] = 2 * np.arange((node1 < 0).sum()) + 1 + 2 * len(g["q_ptr"])
+    node2[node2 < 0] = 2 * np.arange((node2 < 0).sum()) + 100001
+    # the reference's validity rules per driver
+    if variant == 0:
+        v1, v2, kw = (mp1 == 1), None, dict(mode=0, th=50, th_inclusive=True, nnratio=nnratio)
+    elif variant == 1:
+        v1, v2, kw = (mp1 == 1), (mp2 == 1), dict(mode=0, th=50, th_inclusive=False, nnratio=nnratio)
+    else:
+        v1, v2, kw = (mp1 == 0), (mp2 == 0), dict(mode=1, th=50, epi=epi)
+    o1 = dict(s1, valid=v1.astype(np.uint8))
+    o2 = dict(s2, valid=None if v2 is None else v2.astype(np.uint8))
+    m12, d12, nm = ob.bow_search(o1, o2, g, **kw)
+    hit = np.nonzero(m12 >= 0)[0]
+    assert len(hit) > 100, "test premise: enough matches for a histogram"
+    # angles: one dominant rotation for ~80 % of the matches
+    a2 = rs.uniform(0, 360, n2).astype(f32)
+    a1 = rs.uniform(0, 360, n1).astype(f32)
+    a1[hit] = ((a2[m12[hit]] + np.where(rs.rand(len(hit)) < 0.8, 25.0, rs.uniform(0, 360, len(hit)))) % 360.0).astype(f32)
+    # camera geometry that reproduces epi["ex"], epi["ey"]: K2 = (fx, fy, cx, cy), R2w = I, t2w = 0, Cw chosen accordingly
+    fx, fy, cx, cy = f32(517.3), f32(516.5), f32(318.6), f32(255.3)
+    Cz = f32(2.0)
+    Cw = np.array([(f32(epi["ex"]) - cx) / fx * Cz, (f32(epi["ey"]) - cy) / fy * Cz, Cz], f32)
+    ex = f32(f32(fx * Cw[0]) * f32(f32(1.0) / Cw[2])) + cx
+    ey = f32(f32(fy * Cw[1]) * f32(f32(1.0) / Cw[2])) + cy
+    if variant == 2:   # the epipole the shim will compute may differ from the requested one in the last bit: use ITS value
+        m12, d12, nm = ob.bow_search(o1, o2, g, **dict(kw, epi=dict(epi, ex=float(ex), ey=float(ey))))
+        hit = np.nonzero(m12 >= 0)[0]
+        a1[hit] = ((a2[m12[hit]] + np.where(rs.rand(len(hit)) < 0.8, 25.0, rs.uniform(0, 360, len(hit)))) % 360.0).astype(f32)
+
+    def side(s, ang, node, mp, n):
+        xy = np.asarray(s["kp_xy"], f32).reshape(n, 2)
+        octv = np.asarray(s.get("kp_octave", np.zeros(n)), np.int32)
+        return np.asarray(s["desc"], np.uint8).tobytes() + ang.tobytes() + node.astype(np.int32).tobytes() + mp.tobytes() + xy.tobytes() + octv.tobytes()
+
+    blob = struct.pack("<iiif", variant, n1, n2, nnratio) + side(s1, a1, node1, mp1, n1) + side(s2, a2, node2, mp2, n2)
+    blob += np.asarray(epi["F12"], f32).tobytes() + Cw.tobytes() + np.eye(3, dtype=f32).tobytes() + np.zeros(3, f32).tobytes()
+    blob += np.array([fx, fy, cx, cy], f32).tobytes() + np.asarray(epi["scale_factor"][:8], f32).tobytes() + np.asarray(epi["level_sigma2"][:8], f32).tobytes()
+    pin, pout = tmp_path / "b.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "bow", str(pin), str(pout)])
+    raw = open(pout, "rb").read()
+    status, got_nm = struct.unpack_from("<ii", raw, 0)
+    assert status == 0
+    # expected: rotation histogram over the matches, keep the three maxima
+    hist = [[] for _ in range(30)]
+    factor = f32(1.0) / f32(30)
+    for i1 in hit:
+        rot = f32(a1[i1] - a2[m12[i1]])
+        if rot < 0:
+            rot = f32(rot + f32(360))
+        b = int(np.floor(f32(rot * factor) + f32(0.5)))
+        hist[0 if b == 30 else b].append(i1)
+    keep = _three_maxima([len(h) for h in hist])
+    e12 = m12.copy()
+    for i in range(30):
+        if i not in keep:
+            e12[hist[i]] = -1
+    enm = int((e12 >= 0).sum())
+    assert enm < len(hit), "test premise: the histogram removes something"
+    assert got_nm == enm
+    if variant == 0:
+        got = np.frombuffer(raw, np.int32, n2, 8)
+        exp = np.full(n2, -1, np.int32)
+        ok = np.nonzero(e12 >= 0)[0]
+        exp[e12[ok]] = ok
+        assert np.array_equal(got, exp)
+    elif variant == 1:
+        assert np.array_equal(np.frombuffer(raw, np.int32, n1, 8), e12)
+    else:
+        npairs = struct.unpack_from("<i", raw, 8)[0]
+        pairs = np.frombuffer(raw, np.int32, 2 * npairs, 12).reshape(npairs, 2)
+        ok = np.nonzero(e12 >= 0)[0]
+        assert npairs == enm and np.array_equal(pairs[:, 0], ok) and np.array_equal(pairs[:, 1], e12[ok])

@@ -16,6 +16,17 @@ ext = {}
 while time.time() < t_end:
     it += 1
     seed = int(rs.randint(0, 1 << 30))
+    # 0. vocabulary-node search (SearchByBoW / SearchForTriangulation loops)
+    bmode = int(rs.randint(0, 2))
+    b1, b2, bg, bepi = synth.synth_bow(int(rs.randint(0, 2500)), int(rs.randint(0, 2500)), int(rs.randint(1, 300)), seed % 100000, mode=bmode,
+                                       big_group=int(rs.choice([0, 0, 0, 300])))
+    bkw = dict(mode=bmode, th=int(rs.choice([50, 100])), th_inclusive=bool(rs.rand() < 0.5), nnratio=float(rs.choice([0.6, 0.75, 0.9])), epi=bepi)
+    try:
+        ga, go = api.ORBmatcher.bow_search(b1, b2, bg, **bkw), ob.bow_search(b1, b2, bg, **bkw)
+        if not (np.array_equal(ga[0], go[0]) and np.array_equal(ga[1], go[1]) and ga[2] == go[2]):
+            bad.append(("bow", seed, bmode))
+    except Exception as e:  # noqa: BLE001
+        bad.append(("bow exception", seed, str(e)[:80]))
     # 1. guided search, modes 0 (with / without ratio, gate) and 1
     n, m = int(rs.randint(0, 3000)), int(rs.randint(0, 1500))
     crowd = rs.rand() < 0.2

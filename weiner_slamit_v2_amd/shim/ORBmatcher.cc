@@ -79,6 +79,37 @@ bool ORBmatcher::GuidedSearch(const std::vector<cv::KeyPoint>& keysUn, const cv:
     return g_status == SLAMIT_OK;
 }
 
+bool ORBmatcher::BowSearch(const cv::Mat& desc1, const std::vector<uint8_t>& valid1, const cv::Mat& desc2, const std::vector<uint8_t>* valid2,
+                           const BowGroups& g, int th, bool thInclusive, float nnratio, const EpipolarGate* gate, std::vector<int>& match12) {
+    const int n1 = desc1.rows, n2 = desc2.rows;
+    match12.assign(n1, -1);
+    g_status = SLAMIT_OK;
+    if (n1 == 0 || n2 == 0 || g.size() == 0) return true;
+    std::vector<uint8_t> t1, t2;
+    slamit_bow_groups gg;
+    gg.n_groups = g.size(); gg.q_ptr = g.q_ptr.data(); gg.q_idx = g.q_idx.data(); gg.c_ptr = g.c_ptr.data(); gg.c_idx = g.c_idx.data();
+    slamit_bow_rule rule;
+    memset(&rule, 0, sizeof(rule));
+    rule.mode = gate ? 1 : 0; rule.th = th; rule.th_inclusive = thInclusive ? 1 : 0; rule.nnratio = nnratio;
+    std::vector<float> xy1, xy2;
+    std::vector<int32_t> oct2;
+    if (gate) {
+        memcpy(rule.F12, gate->F12, sizeof(rule.F12)); rule.ex = gate->ex; rule.ey = gate->ey;
+        xy1.resize(2 * (size_t)n1); xy2.resize(2 * (size_t)n2); oct2.resize(n2);
+        for (int i = 0; i < n1; ++i) { xy1[2 * i] = (*gate->keys1)[i].pt.x; xy1[2 * i + 1] = (*gate->keys1)[i].pt.y; }
+        for (int i = 0; i < n2; ++i) { xy2[2 * i] = (*gate->keys2)[i].pt.x; xy2[2 * i + 1] = (*gate->keys2)[i].pt.y; oct2[i] = (*gate->keys2)[i].octave; }
+        rule.kp1_xy = xy1.data(); rule.kp2_xy = xy2.data(); rule.kp2_octave = oct2.data();
+        for (int i = 0; i < 16; ++i) {
+            rule.scale_factor[i] = i < (int)gate->scaleFactors->size() ? (*gate->scaleFactors)[i] : 1.f;
+            rule.level_sigma2[i] = i < (int)gate->levelSigma2->size() ? (*gate->levelSigma2)[i] : 1.f;
+        }
+    }
+    int nm = 0;
+    g_status = slamit_bow_search(0, packed_rows(desc1, t1), n1, valid1.empty() ? nullptr : valid1.data(), packed_rows(desc2, t2), n2,
+                                 valid2 ? valid2->data() : nullptr, &gg, &rule, match12.data(), nullptr, &nm);
+    return g_status == SLAMIT_OK;
+}
+
 int ORBmatcher::SearchBruteForce(const std::vector<cv::KeyPoint>& keys1, const cv::Mat& desc1,
                                  const std::vector<cv::KeyPoint>& keys2, const cv::Mat& desc2,
                                  std::vector<int>& vnMatches12, int th) {

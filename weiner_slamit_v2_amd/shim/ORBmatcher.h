@@ -8,7 +8,9 @@
 // SearchByProjection(CurrentFrame, LastFrame, th, bMono): projection and window sizing are host code
 // over the caller's Frame / MapPoint types (templates, like Optimizer.h), the grid window query +
 // Hamming best/second + greedy assignment of every map point is ONE slamit_guided_search call.
-// The remaining BoW / Sim3 / fuse / triangulation drivers stay with the caller.
+// Beyond §8f: the vocabulary-node drivers SearchByBoW (KeyFrame/Frame and KeyFrame/KeyFrame) and
+// SearchForTriangulation -- the walk over the two DBoW2::FeatureVectors and the rotation histogram are host code,
+// the matching loops of every common node are ONE slamit_bow_search call.  The Sim3 drivers stay with the caller.
 #ifndef SLAMIT_SHIM_ORBMATCHER_H
 #define SLAMIT_SHIM_ORBMATCHER_H
 
@@ -16,6 +18,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #ifdef SLAMIT_USE_OPENCV
@@ -92,6 +95,43 @@ public:
     template <class FrameT>
     int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
                                 int windowSize = 10);
+
+    // Relocalization / loop-detection matcher (ORBmatcher.cc:161-290): map points of a keyframe against the features of a
+    // frame that fall into the same vocabulary node.  Members used: KeyFrame : GetMapPointMatches(), mFeatVec
+    // (node id -> feature indices, ascending node id: DBoW2::FeatureVector or any std::map-like), mDescriptors, mvKeysUn ;
+    // Frame : N, mFeatVec, mDescriptors, mvKeys ; MapPoint : isBad().
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches);
+
+    // Loop closing's keyframe-to-keyframe matcher (ORBmatcher.cc:526-657).
+    template <class KeyFrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12);
+
+    // LocalMapping::CreateNewMapPoints' matcher (ORBmatcher.cc:659-826), monocular: features without a map point, same
+    // vocabulary node, epipolar constraint.  Additional KeyFrame members: N, GetMapPoint(i), GetCameraCenter(),
+    // GetRotation(), GetTranslation(), fx, fy, cx, cy, mvScaleFactors, mvLevelSigma2, mvuRight.  A keyframe with a stereo
+    // keypoint (mvuRight >= 0) or bOnlyStereo is refused (returns 0, LastStatus() != 0).
+    template <class KeyFrameT>
+    int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                               const bool bOnlyStereo);
+
+    // Node groups common to two feature vectors, and the device call the three templates above make.
+    struct BowGroups {
+        std::vector<int32_t> q_ptr, q_idx, c_ptr, c_idx;
+        BowGroups() : q_ptr(1, 0), c_ptr(1, 0) {}
+        int size() const { return (int)q_ptr.size() - 1; }
+    };
+    template <class FeatVecT>
+    static void CommonNodes(const FeatVecT& fv1, const FeatVecT& fv2, BowGroups& g);
+    struct EpipolarGate {          // SearchForTriangulation's per-candidate tests
+        float F12[9], ex, ey;
+        const std::vector<cv::KeyPoint>* keys1;
+        const std::vector<cv::KeyPoint>* keys2;
+        const std::vector<float>* scaleFactors;
+        const std::vector<float>* levelSigma2;
+    };
+    static bool BowSearch(const cv::Mat& desc1, const std::vector<uint8_t>& valid1, const cv::Mat& desc2, const std::vector<uint8_t>* valid2,
+                          const BowGroups& g, int th, bool thInclusive, float nnratio, const EpipolarGate* gate, std::vector<int>& match12);
 
     // The device call the templates make.  kp_taken / queries are in the order the reference visits them.
     struct GuidedQueries {
@@ -304,6 +344,169 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const S
                     CurrentFrame.mvpMapPoints[rotHist[i][j]] = nullptr;
                     nmatches--;
                 }
+    }
+    return nmatches;
+}
+
+template <class FeatVecT>
+void ORBmatcher::CommonNodes(const FeatVecT& fv1, const FeatVecT& fv2, BowGroups& g) {
+    // both are ordered by node id: the reference's lower_bound walk (ORBmatcher.cc:184-278) visits exactly the common ids
+    typename FeatVecT::const_iterator a = fv1.begin(), b = fv2.begin();
+    while (a != fv1.end() && b != fv2.end()) {
+        if (a->first == b->first) {
+            for (size_t i = 0; i < a->second.size(); ++i) g.q_idx.push_back((int32_t)a->second[i]);
+            for (size_t i = 0; i < b->second.size(); ++i) g.c_idx.push_back((int32_t)b->second[i]);
+            g.q_ptr.push_back((int32_t)g.q_idx.size());
+            g.c_ptr.push_back((int32_t)g.c_idx.size());
+            ++a; ++b;
+        } else if (a->first < b->first) ++a;
+        else ++b;
+    }
+}
+
+template <class KeyFrameT, class FrameT, class MapPointT>
+int ORBmatcher::SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches) {
+    const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPointT*>(F.N, static_cast<MapPointT*>(NULL));
+    const int n1 = (int)vpMapPointsKF.size();
+    std::vector<uint8_t> valid1(n1, 0);
+    for (int i = 0; i < n1; ++i) valid1[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();   // :201-206
+    BowGroups g;
+    CommonNodes(pKF->mFeatVec, F.mFeatVec, g);
+    std::vector<int> match12;
+    if (!BowSearch(pKF->mDescriptors, valid1, F.mDescriptors, NULL, g, TH_LOW, true, mfNNratio, NULL, match12)) return 0;
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < n1; ++i) {
+        const int bestIdxF = match12[i];
+        if (bestIdxF < 0) continue;
+        vpMapPointMatches[bestIdxF] = vpMapPointsKF[i];
+        if (mbCheckOrientation) {
+            float rot = pKF->mvKeysUn[i].angle - F.mvKeys[bestIdxF].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdxF);
+        }
+        nmatches++;
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                vpMapPointMatches[rotHist[i][j]] = static_cast<MapPointT*>(NULL);
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+template <class KeyFrameT, class MapPointT>
+int ORBmatcher::SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12) {
+    const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+    vpMatches12 = std::vector<MapPointT*>(n1, static_cast<MapPointT*>(NULL));
+    std::vector<uint8_t> valid1(n1, 0), valid2(n2, 0);
+    for (int i = 0; i < n1; ++i) valid1[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();   // :563-567
+    for (int i = 0; i < n2; ++i) valid2[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();   // :581-587
+    BowGroups g;
+    CommonNodes(pKF1->mFeatVec, pKF2->mFeatVec, g);
+    std::vector<int> match12;
+    if (!BowSearch(pKF1->mDescriptors, valid1, pKF2->mDescriptors, &valid2, g, TH_LOW, false, mfNNratio, NULL, match12)) return 0;
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int idx1 = 0; idx1 < n1; ++idx1) {
+        const int bestIdx2 = match12[idx1];
+        if (bestIdx2 < 0) continue;
+        vpMatches12[idx1] = vpMapPoints2[bestIdx2];
+        if (mbCheckOrientation) {
+            float rot = pKF1->mvKeysUn[idx1].angle - pKF2->mvKeysUn[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(idx1);
+        }
+        nmatches++;
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                vpMatches12[rotHist[i][j]] = static_cast<MapPointT*>(NULL);
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+template <class KeyFrameT>
+int ORBmatcher::SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                                       const bool bOnlyStereo) {
+    vMatchedPairs.clear();
+    const int n1 = pKF1->N, n2 = pKF2->N;
+    bool stereo = bOnlyStereo;
+    for (int i = 0; i < n1 && !stereo; ++i) stereo = pKF1->mvuRight[i] >= 0;
+    for (int i = 0; i < n2 && !stereo; ++i) stereo = pKF2->mvuRight[i] >= 0;
+    if (stereo) { setStatus(-1); return 0; }   // monocular path only (the reference application is MONOCULAR)
+    // epipole of camera 1 in image 2 (:665-673)
+    const cv::Mat Cw = pKF1->GetCameraCenter(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+    float C2[3];
+    for (int r = 0; r < 3; ++r)
+        C2[r] = R2w.template at<float>(r, 0) * Cw.template at<float>(0, 0) + R2w.template at<float>(r, 1) * Cw.template at<float>(1, 0) +
+                R2w.template at<float>(r, 2) * Cw.template at<float>(2, 0) + t2w.template at<float>(r, 0);
+    const float invz = 1.0f / C2[2];
+    EpipolarGate gate;
+    gate.ex = pKF2->fx * C2[0] * invz + pKF2->cx;
+    gate.ey = pKF2->fy * C2[1] * invz + pKF2->cy;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) gate.F12[3 * r + c] = F12.template at<float>(r, c);
+    gate.keys1 = &pKF1->mvKeysUn; gate.keys2 = &pKF2->mvKeysUn;
+    gate.scaleFactors = &pKF2->mvScaleFactors; gate.levelSigma2 = &pKF2->mvLevelSigma2;
+    std::vector<uint8_t> valid1(n1, 0), valid2(n2, 0);
+    for (int i = 0; i < n1; ++i) valid1[i] = pKF1->GetMapPoint(i) ? 0 : 1;   // :700-704: skip features that have a MapPoint
+    for (int i = 0; i < n2; ++i) valid2[i] = pKF2->GetMapPoint(i) ? 0 : 1;   // :724-728
+    BowGroups g;
+    CommonNodes(pKF1->mFeatVec, pKF2->mFeatVec, g);
+    std::vector<int> vMatches12;
+    if (!BowSearch(pKF1->mDescriptors, valid1, pKF2->mDescriptors, &valid2, g, TH_LOW, true, 0.f, &gate, vMatches12)) return 0;
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int idx1 = 0; idx1 < n1; ++idx1) {
+        const int bestIdx2 = vMatches12[idx1];
+        if (bestIdx2 < 0) continue;
+        nmatches++;
+        if (mbCheckOrientation) {
+            float rot = pKF1->mvKeysUn[idx1].angle - pKF2->mvKeysUn[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(idx1);
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                vMatches12[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    vMatchedPairs.reserve(nmatches);
+    for (size_t i = 0, iend = vMatches12.size(); i < iend; i++) {
+        if (vMatches12[i] < 0) continue;
+        vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
     }
     return nmatches;
 }

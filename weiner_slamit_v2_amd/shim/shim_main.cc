@@ -9,6 +9,7 @@
 //     shim_test frame <problem.bin> <out.bin>
 //     shim_test fuse <problem.bin> <out.bin>
 //     shim_test init <problem.bin> <out.bin>
+//     shim_test bow <problem.bin> <out.bin>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -609,6 +610,91 @@ static int run_init(int argc, char** argv) {
     return 0;
 }
 
+// ---- SearchByBoW / SearchForTriangulation through the templates ----------------------------------------------------
+struct MockBowPoint {
+    int id; bool bad;
+    bool isBad() const { return bad; }
+};
+struct MockBowKF {   // doubles as the Frame of SearchByBoW(KeyFrame*, Frame&)
+    int N;
+    std::map<unsigned, std::vector<unsigned> > mFeatVec;   // the shape of DBoW2::FeatureVector
+    cv::Mat mDescriptors, Ow, Rcw, tcw;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    std::vector<MockBowPoint*> matches;
+    std::vector<float> mvuRight, mvScaleFactors, mvLevelSigma2;
+    float fx, fy, cx, cy;
+    std::vector<MockBowPoint*> GetMapPointMatches() { return matches; }
+    MockBowPoint* GetMapPoint(size_t i) { return matches[i]; }
+    cv::Mat GetCameraCenter() { return Ow; }
+    cv::Mat GetRotation() { return Rcw; }
+    cv::Mat GetTranslation() { return tcw; }
+};
+// problem.bin: int32 variant (0 KeyFrame/Frame, 1 KeyFrame/KeyFrame, 2 triangulation) n1 n2 ; float nnratio ;
+//   per side: u8 desc[32 n], float angle[n], int32 node[n], int32 mp[n] (0 none, 1 good, 2 bad), float xy[2 n], int32 octave[n] ;
+//   float F12[9] Cw[3] R2w[9] t2w[3] intr[4] scale[8] sigma2[8]
+// out.bin: int32 status nmatches ; variant 0: int32[n2] (side-1 index of the map point given to frame feature i, or -1),
+//   variant 1: int32[n1] (side-2 index whose map point was matched, or -1), variant 2: int32 npairs, then int32 pairs[2 npairs]
+static void fill_side(Reader& R, int n, MockBowKF& K, std::vector<MockBowPoint>& pts) {
+    const unsigned char* d = R.arr<unsigned char>(32 * (size_t)n);
+    const float* ang = R.arr<float>(n); const int* node = R.arr<int>(n); const int* mp = R.arr<int>(n);
+    const float* xy = R.arr<float>(2 * (size_t)n); const int* oct = R.arr<int>(n);
+    K.N = n; K.mDescriptors = cv::Mat(n, 32, CV_8U); K.mvKeysUn.resize(n); K.matches.assign(n, (MockBowPoint*)0); K.mvuRight.assign(n, -1.f);
+    pts.resize(n);
+    for (int i = 0; i < n; ++i) {
+        memcpy(K.mDescriptors.ptr(i), d + 32 * (size_t)i, 32);
+        K.mvKeysUn[i] = cv::KeyPoint(xy[2 * i], xy[2 * i + 1], 31.f, ang[i], 0, oct[i]);
+        K.mFeatVec[(unsigned)node[i]].push_back((unsigned)i);
+        pts[i].id = i; pts[i].bad = mp[i] == 2;
+        if (mp[i]) K.matches[i] = &pts[i];
+    }
+    K.mvKeys = K.mvKeysUn;
+}
+static int run_bow(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<unsigned char> raw = slurp(argv[2]);
+    Reader R{raw.data()};
+    const int variant = R.get<int>(), n1 = R.get<int>(), n2 = R.get<int>();
+    const float nnratio = R.get<float>();
+    MockBowKF K1, K2;
+    std::vector<MockBowPoint> p1, p2;
+    fill_side(R, n1, K1, p1);
+    fill_side(R, n2, K2, p2);
+    const float* F = R.arr<float>(9); const float* Cw = R.arr<float>(3); const float* R2 = R.arr<float>(9); const float* t2 = R.arr<float>(3);
+    const float* intr = R.arr<float>(4); const float* scale = R.arr<float>(8); const float* sig = R.arr<float>(8);
+    K1.Ow = mat_from(Cw, 3);
+    K2.Rcw = cv::Mat(3, 3, CV_32F); K2.tcw = mat_from(t2, 3);
+    cv::Mat F12(3, 3, CV_32F);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { K2.Rcw.at<float>(r, c) = R2[3 * r + c]; F12.at<float>(r, c) = F[3 * r + c]; }
+    K2.fx = intr[0]; K2.fy = intr[1]; K2.cx = intr[2]; K2.cy = intr[3];
+    K2.mvScaleFactors.assign(scale, scale + 8); K2.mvLevelSigma2.assign(sig, sig + 8);
+    ORBmatcher matcher(nnratio, true);
+    int nm = 0;
+    std::vector<int> out;
+    if (variant == 0) {
+        std::vector<MockBowPoint*> got;
+        nm = matcher.SearchByBoW(&K1, K2, got);
+        out.assign(n2, -1);
+        for (int i = 0; i < n2 && i < (int)got.size(); ++i) if (got[i]) out[i] = got[i]->id;
+    } else if (variant == 1) {
+        std::vector<MockBowPoint*> got;
+        nm = matcher.SearchByBoW(&K1, &K2, got);
+        out.assign(n1, -1);
+        for (int i = 0; i < n1 && i < (int)got.size(); ++i) if (got[i]) out[i] = got[i]->id;
+    } else {
+        std::vector<std::pair<size_t, size_t> > pairs;
+        nm = matcher.SearchForTriangulation(&K1, &K2, F12, pairs, false);
+        out.push_back((int)pairs.size());
+        for (size_t k = 0; k < pairs.size(); ++k) { out.push_back((int)pairs[k].first); out.push_back((int)pairs[k].second); }
+    }
+    const int status = ORBmatcher::LastStatus();
+    if (status != 0) fprintf(stderr, "bow failed: %s\n", slamit_last_error());
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(&status, 4, 1, f); fwrite(&nm, 4, 1, f);
+    fwrite(out.data(), 4, out.size(), f);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
@@ -620,5 +706,6 @@ int main(int argc, char** argv) {
     if (mode == "frame") return run_frame(argc, argv);
     if (mode == "fuse") return run_fuse(argc, argv);
     if (mode == "init") return run_init(argc, argv);
+    if (mode == "bow") return run_bow(argc, argv);
     return 2;
 }
