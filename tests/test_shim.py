@@ -715,3 +715,250 @@ def test_shim_bow_drivers(tmp_path, variant):
         pairs = np.frombuffer(raw, np.int32, 2 * npairs, 12).reshape(npairs, 2)
         ok = np.nonzero(e12 >= 0)[0]
         assert npairs == enm and np.array_equal(pairs[:, 0], ok) and np.array_equal(pairs[:, 1], e12[ok])
+
+
+# ---- the Sim3 drivers (loop closing) through the templates -----------------------------------------------------------
+def _f32_apply(R, t, P):
+    """R * p + t the way the shim writes it (float, left to right)."""
+    return np.stack([((R[r, 0] * P[:, 0] + R[r, 1] * P[:, 1]) + R[r, 2] * P[:, 2]) + t[r] for r in range(3)], 1).astype(np.float32)
+
+
+def _norm3(V):
+    return np.sqrt((V.astype(np.float64) ** 2).sum(1)).astype(np.float32)   # cv::norm: double accumulation
+
+
+def _decompose_scw(S):
+    f32 = np.float32
+    scw = f32(np.sqrt((S[0, :3].astype(np.float64) ** 2).sum()))
+    R = (S[:3, :3] / scw).astype(f32)
+    t = (S[:3, 3] / scw).astype(f32)
+    O = np.array([-(R[:, r].astype(np.float64) * t.astype(np.float64)).sum() for r in range(3)]).astype(f32)
+    return R, t, O
+
+
+def _sim3_scene(seed, n=1300, m=800):
+    """A keyframe (synth_search keypoints + grid) and m map points that project near some of its keypoints under (Rc, tc)."""
+    from weiner_slamit_v2_amd import synth
+    f32 = np.float32
+    rs = np.random.RandomState(seed)
+    frame, _ = synth.synth_search(n, 4, seed)
+    fx, fy, cx, cy = f32(526.69), f32(540.36), f32(313.07), f32(238.39)
+    Rc, tc = synth.se3_exp(np.array([0.02, -0.015, 0.03, 0.1, -0.05, 0.02]) * (1 + seed % 3))
+    src = rs.randint(0, n, m)
+    depth = rs.uniform(2, 8, m)
+    px = frame["kp_xy"][src].astype(np.float64) + rs.normal(0, 1.0, (m, 2))
+    pc = np.stack([(px[:, 0] - cx) / fx * depth, (px[:, 1] - cy) / fy * depth, depth], 1)
+    pc[::41] *= -1                                   # behind the camera
+    pos = ((pc - tc) @ Rc).astype(f32)               # world position: Rc^T (pc - tc)
+    Ow = -(Rc.T @ tc)
+    PO = pos.astype(np.float64) - Ow
+    d3 = np.sqrt((PO ** 2).sum(1))
+    normal = (PO / np.maximum(d3[:, None], 1e-6)).astype(f32)
+    normal[::17] *= -1                               # viewing angle check fails
+    maxd, mind = (d3 * 1.5).astype(f32), (d3 * 0.6).astype(f32)
+    mind[::23] = (d3[::23] * 1.2).astype(f32)        # outside the scale-invariance range
+    level = np.clip(frame["kp_octave"][src] + rs.randint(0, 2, m), 0, 7).astype(np.int32)
+    bad = (rs.rand(m) < 0.05).astype(np.int32)
+    qdesc = frame["desc"][src].copy()
+    for j in range(m):
+        for b in rs.randint(0, 256, rs.randint(0, 30)):
+            qdesc[j, b >> 3] ^= np.uint8(1 << (b & 7))
+    pts = dict(pos=pos, normal=normal, maxd=maxd, mind=mind, level=level, bad=bad, desc=qdesc, src=src)
+    cam = dict(R=Rc.astype(f32), t=tc.astype(f32), intr=np.array([fx, fy, cx, cy], f32),
+               bounds=np.array([frame["min_x"], 645.1, frame["min_y"], 483.9, frame["inv_w"], frame["inv_h"]], f32),
+               scale=(f32(1.2) ** np.arange(8, dtype=f32)).astype(f32))
+    return frame, cam, pts
+
+
+def _points_blob(pts, idx2=None):
+    m = len(pts["level"])
+    idx2 = np.full(m, -1, np.int32) if idx2 is None else idx2.astype(np.int32)
+    return (struct.pack("<i", m) + pts["pos"].tobytes() + pts["normal"].tobytes() + pts["maxd"].tobytes() + pts["mind"].tobytes() +
+            pts["level"].tobytes() + pts["bad"].astype(np.int32).tobytes() + idx2.tobytes() + pts["desc"].tobytes())
+
+
+def _kf_blob(frame, cam, mp):
+    n = len(frame["kp_octave"])
+    return (cam["R"].tobytes() + cam["t"].tobytes() + cam["intr"].tobytes() + cam["bounds"].tobytes() + cam["scale"].tobytes() + struct.pack("<i", n) +
+            frame["kp_xy"].astype(np.float32).tobytes() + frame["kp_octave"].astype(np.int32).tobytes() + mp.astype(np.int32).tobytes() + frame["desc"].tobytes())
+
+
+def _project_checks(cam, pc, P, O, pts, th, viewing=True, pc_for_dist=None, inv_double=False):
+    """u, v, radius and the keep-mask of the reference's per-point tests (depth, image, distance range, viewing angle)."""
+    f32 = np.float32
+    fx, fy, cx, cy = cam["intr"]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        invz = (1.0 / pc[:, 2].astype(np.float64)).astype(f32) if inv_double else (f32(1) / pc[:, 2]).astype(f32)
+    u, v = fx * (pc[:, 0] * invz) + cx, fy * (pc[:, 1] * invz) + cy
+    b = cam["bounds"]
+    ok = ~(pc[:, 2] < 0) & (u >= b[0]) & (u < b[1]) & (v >= b[2]) & (v < b[3])
+    if pc_for_dist is None:
+        PO = np.stack([P[:, 0] - O[0], P[:, 1] - O[1], P[:, 2] - O[2]], 1).astype(f32)
+        dist = _norm3(PO)
+    else:
+        dist = _norm3(pc_for_dist)
+    ok &= ~((dist < pts["mind"]) | (dist > pts["maxd"]))
+    if viewing:
+        dot = (PO.astype(np.float64) * pts["normal"].astype(np.float64)).sum(1)
+        ok &= ~(dot < 0.5 * dist.astype(np.float64))
+    radius = (f32(th) * cam["scale"][pts["level"]]).astype(f32)
+    return u.astype(f32), v.astype(f32), radius, ok
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1])
+def test_shim_sim3_projection_and_fuse(tmp_path, variant):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) and ORBmatcher::Fuse(pKF, Scw, vpPoints, th,
+    vpReplacePoint) through the templates: Scw decomposition, projection and tests on the host, one guided search on the
+    device, the reference's bookkeeping in order."""
+    from oracle import bindings as ob
+
+    _build()
+    f32 = np.float32
+    rs = np.random.RandomState(40 + variant)
+    frame, cam, pts = _sim3_scene(60 + variant)
+    n, m = len(frame["kp_octave"]), len(pts["level"])
+    th = 10 if variant == 0 else 4.0
+    s = f32(1.7)
+    S = np.zeros((3, 4), f32)
+    S[:, :3] = s * cam["R"]
+    S[:, 3] = s * cam["t"]
+    # which map point already sits at a keypoint
+    mp = np.where(rs.rand(n) < 0.3, rs.randint(0, m, n), -1).astype(np.int32)
+    init = np.where(rs.rand(n) < 0.25, rs.randint(0, m, n), -1).astype(np.int32)       # variant 0: vpMatched on entry
+    blob = struct.pack("<iif", variant, 1, float(th)) + _points_blob(pts) + _kf_blob(frame, cam, mp) + S.tobytes()
+    if variant == 0:
+        blob += init.tobytes()
+    pin, pout = tmp_path / "s.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "sim3", str(pin), str(pout)])
+    r = np.fromfile(pout, np.int32)
+    assert r[0] == 0
+    # expected
+    R, t, O = _decompose_scw(np.vstack([S, [0, 0, 0, 1]]).astype(f32))
+    pc = _f32_apply(R, t, pts["pos"])
+    u, v, radius, ok = _project_checks(cam, pc, pts["pos"], O, pts, th, inv_double=(variant == 1))
+    ok &= pts["bad"] == 0
+    already = set(init[init >= 0].tolist()) if variant == 0 else set(mp[mp >= 0].tolist())
+    ok &= ~np.isin(np.arange(m), list(already))
+    keep = np.nonzero(ok)[0]
+    assert 150 < len(keep) < m
+    q = dict(uvr=np.stack([u, v, radius], 1)[keep], level_min=pts["level"][keep] - 1, level_max=pts["level"][keep], desc=pts["desc"][keep],
+             takes=np.full(len(keep), 1 if variant == 0 else 0, np.uint8))
+    taken = (init >= 0).astype(np.uint8) if variant == 0 else np.zeros(n, np.uint8)
+    match, nm, _ = ob.guided_search(dict(frame, kp_taken=taken), q, 50, False, 0.75)
+    if variant == 0:
+        exp = init.copy()
+        hit = match >= 0
+        exp[match[hit]] = keep[hit]
+        assert r[1] == int(hit.sum()) and r[1] > 50
+        assert np.array_equal(r[2:2 + n], exp)
+    else:
+        owner = mp.copy()
+        replace, added = np.full(m, -1, np.int32), np.full(m, -1, np.int32)
+        nf = 0
+        for k, j in enumerate(keep):
+            bi = match[k]
+            if bi < 0:
+                continue
+            if owner[bi] >= 0:
+                if not pts["bad"][owner[bi]]:
+                    replace[j] = owner[bi]
+            else:
+                added[j], owner[bi] = bi, j
+            nf += 1
+        assert r[1] == nf and nf > 50 and (replace >= 0).sum() > 5 and (added >= 0).sum() > 5
+        assert np.array_equal(r[2:2 + m], replace) and np.array_equal(r[2 + m:2 + 2 * m], added) and np.array_equal(r[2 + 2 * m:2 + 2 * m + n], owner)
+
+
+@pytest.mark.gpu
+def test_shim_search_by_sim3(tmp_path):
+    """ORBmatcher::SearchBySim3 through the template: both directions are one guided search each, then the agreement test."""
+    from oracle import bindings as ob
+    from weiner_slamit_v2_amd import synth
+
+    _build()
+    f32 = np.float32
+    rs = np.random.RandomState(77)
+    frame1, cam1, pts = _sim3_scene(71)
+    n1, m = len(frame1["kp_octave"]), len(pts["level"])
+    th = 7.5
+    # camera 2: a second pose; its keypoints are the projections of the map points (+ noise) and some random ones
+    R2, t2 = synth.se3_exp(np.array([-0.03, 0.02, 0.01, -0.2, 0.05, 0.1]))
+    cam2 = dict(cam1, R=R2.astype(f32), t=t2.astype(f32))
+    pc2 = (pts["pos"].astype(np.float64) @ R2.T) + t2
+    fx, fy, cx, cy = [float(x) for x in cam1["intr"]]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        uv2 = np.stack([fx * pc2[:, 0] / pc2[:, 2] + cx, fy * pc2[:, 1] / pc2[:, 2] + cy], 1)
+    vis = (pc2[:, 2] > 0.5) & (uv2[:, 0] > 5) & (uv2[:, 0] < 635) & (uv2[:, 1] > 5) & (uv2[:, 1] < 475)
+    vidx = np.nonzero(vis)[0]
+    extra = 400
+    xy2 = np.concatenate([uv2[vidx] + rs.normal(0, 0.8, (len(vidx), 2)), np.stack([rs.uniform(0, 640, extra), rs.uniform(0, 480, extra)], 1)]).astype(f32)
+    oct2 = np.concatenate([np.clip(pts["level"][vidx] - rs.randint(0, 2, len(vidx)), 0, 7), rs.randint(0, 8, extra)]).astype(np.int32)
+    d2 = np.concatenate([pts["desc"][vidx], rs.randint(0, 256, (extra, 32)).astype(np.uint8)])
+    for i in range(len(vidx)):
+        for b in rs.randint(0, 256, rs.randint(0, 40)):
+            d2[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    n2 = len(xy2)
+    frame2 = dict(frame1, kp_xy=xy2, kp_octave=oct2, desc=d2)
+    # map points at keypoints: KF1 keypoint src[j] holds point j (last writer wins), KF2 keypoint i holds point vidx[i]
+    mp1 = np.full(n1, -1, np.int32)
+    mp1[pts["src"]] = np.arange(m)
+    mp2 = np.full(n2, -1, np.int32)
+    mp2[:len(vidx)] = vidx
+    mp2[rs.rand(n2) < 0.1] = -1
+    idx_in_kf2 = np.full(m, -1, np.int32)
+    have = np.nonzero(mp2 >= 0)[0]
+    idx_in_kf2[mp2[have]] = have
+    init = np.where((rs.rand(n1) < 0.1) & (mp1 >= 0), mp1, -1).astype(np.int32)      # matches known on entry
+    # similarity between the cameras: p_c1 = s12 R12 p_c2 + t12 (s12 slightly off 1: projections move a little)
+    s12 = f32(1.01)
+    R12 = (cam1["R"].astype(np.float64) @ R2.T).astype(f32)
+    t12 = (cam1["t"].astype(np.float64) - R12.astype(np.float64) @ t2).astype(f32)
+    blob = struct.pack("<iif", 2, 2, th) + _points_blob(pts, idx_in_kf2) + _kf_blob(frame1, cam1, mp1) + _kf_blob(frame2, cam2, mp2)
+    blob += struct.pack("<f", float(s12)) + R12.tobytes() + t12.tobytes() + init.tobytes()
+    pin, pout = tmp_path / "s.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "sim3", str(pin), str(pout)])
+    r = np.fromfile(pout, np.int32)
+    assert r[0] == 0
+    # expected (ORBmatcher.cc:1119-1121, 1146-1323)
+    sR12 = (s12 * R12).astype(f32)
+    sR21 = ((1.0 / float(s12)) * R12.T.astype(np.float64)).astype(f32)
+    t21 = np.array([-(sR21[r_].astype(np.float64) * t12.astype(np.float64)).sum() for r_ in range(3)]).astype(f32)
+    done1 = init >= 0
+    done2 = np.zeros(n2, bool)
+    for i in np.nonzero(done1)[0]:
+        k = idx_in_kf2[init[i]]
+        if 0 <= k < n2:
+            done2[k] = True
+
+    def direction(mp_from, done, cam_from, sR, ts, frame_to, cam_to):
+        ids = np.nonzero((mp_from >= 0) & ~done)[0]
+        pid = mp_from[ids]
+        sub = {k: pts[k][pid] for k in ("pos", "normal", "maxd", "mind", "level", "bad", "desc")}
+        pa = _f32_apply(cam_from["R"], cam_from["t"], sub["pos"])
+        pb = _f32_apply(sR, ts, pa)
+        camx = dict(cam_to, intr=cam1["intr"])                      # both directions use camera 1's intrinsics
+        u, v, radius, ok = _project_checks(camx, pb, None, None, sub, th, viewing=False, pc_for_dist=pb, inv_double=True)
+        ok &= sub["bad"] == 0
+        keep = np.nonzero(ok)[0]
+        q = dict(uvr=np.stack([u, v, radius], 1)[keep], level_min=sub["level"][keep] - 1, level_max=sub["level"][keep], desc=sub["desc"][keep],
+                 takes=np.zeros(len(keep), np.uint8))
+        match, _, _ = ob.guided_search(dict(frame_to, kp_taken=np.zeros(len(frame_to["kp_octave"]), np.uint8)), q, 100, False, 0.75)
+        out = np.full(len(mp_from), -1, np.int32)
+        out[ids[keep]] = match
+        return out
+
+    vn1 = direction(mp1, done1, cam1, sR21, t21, frame2, cam2)
+    vn2 = direction(mp2, done2, cam2, sR12, t12, frame1, cam1)
+    exp = init.copy()
+    nfound = 0
+    for i1 in range(n1):
+        k = vn1[i1]
+        if k >= 0 and vn2[k] == i1:
+            exp[i1] = mp2[k]
+            nfound += 1
+    assert nfound > 100 and (vn1 >= 0).sum() > nfound, "test premise: matches, and some that fail the agreement test"
+    assert r[1] == nfound
+    assert np.array_equal(r[2:2 + n1], exp)

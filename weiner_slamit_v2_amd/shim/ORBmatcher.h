@@ -10,7 +10,8 @@
 // Hamming best/second + greedy assignment of every map point is ONE slamit_guided_search call.
 // Beyond §8f: the vocabulary-node drivers SearchByBoW (KeyFrame/Frame and KeyFrame/KeyFrame) and
 // SearchForTriangulation -- the walk over the two DBoW2::FeatureVectors and the rotation histogram are host code,
-// the matching loops of every common node are ONE slamit_bow_search call.  The Sim3 drivers stay with the caller.
+// the matching loops of every common node are ONE slamit_bow_search call; and the loop-closing Sim3 drivers
+// SearchByProjection(pKF, Scw, ...), Fuse(pKF, Scw, ...) and SearchBySim3 over the guided search.
 #ifndef SLAMIT_SHIM_ORBMATCHER_H
 #define SLAMIT_SHIM_ORBMATCHER_H
 
@@ -114,6 +115,18 @@ public:
     template <class KeyFrameT>
     int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
                                const bool bOnlyStereo);
+
+    // Loop closing's Sim3 drivers (ORBmatcher.cc:293-407, 981-1100, 1102-1330): projection with the similarity transform and
+    // every geometric test are host code, the window query + Hamming selection of all map points is one guided-search call
+    // per direction.  Additional members: KeyFrame : GetMapPoints() (anything with count(MapPoint*)), IsInImage(u, v) ;
+    // MapPoint : GetIndexInKeyFrame(pKF).  cv::Mat products follow cv::gemm for CV_32F (products summed in double).
+    template <class KeyFrameT, class MapPointT>
+    int SearchByProjection(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints, std::vector<MapPointT*>& vpMatched, int th);
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints, float th, std::vector<MapPointT*>& vpReplacePoint);
+    template <class KeyFrameT, class MapPointT>
+    int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                     const cv::Mat& t12, const float th);
 
     // Node groups common to two feature vectors, and the device call the three templates above make.
     struct BowGroups {
@@ -509,6 +522,216 @@ int ORBmatcher::SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, cv::Mat
         vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
     }
     return nmatches;
+}
+
+// ---- Sim3 drivers ------------------------------------------------------------------------------------------------
+namespace sim3detail {
+// Scw -> Rcw, tcw, Ow exactly as ORBmatcher.cc:301-306 computes them (cv::Mat::dot and cv::gemm sum in double)
+inline void decompose(const cv::Mat& Scw, float R[3][3], float t[3], float O[3]) {
+    double d = 0;
+    for (int c = 0; c < 3; ++c) d += (double)Scw.at<float>(0, c) * (double)Scw.at<float>(0, c);
+    const float scw = (float)sqrt(d);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) R[r][c] = Scw.at<float>(r, c) / scw;
+        t[r] = Scw.at<float>(r, 3) / scw;
+    }
+    for (int r = 0; r < 3; ++r) {
+        double a = 0;
+        for (int c = 0; c < 3; ++c) a += (double)R[c][r] * (double)t[c];
+        O[r] = (float)(-a);
+    }
+}
+inline void apply(const float R[3][3], const float t[3], const float p[3], float out[3]) {   // R * p + t
+    for (int r = 0; r < 3; ++r) out[r] = R[r][0] * p[0] + R[r][1] * p[1] + R[r][2] * p[2] + t[r];
+}
+inline float norm3(const float v[3]) { return (float)sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); }   // cv::norm
+}  // namespace sim3detail
+
+template <class KeyFrameT, class MapPointT>
+int ORBmatcher::SearchByProjection(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints, std::vector<MapPointT*>& vpMatched, int th) {
+    const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy;
+    float R[3][3], t[3], O[3];
+    sim3detail::decompose(Scw, R, t, O);
+    const int n = (int)pKF->mvKeysUn.size();
+    std::vector<MapPointT*> found(vpMatched.begin(), vpMatched.end());   // spAlreadyFound (:309-310)
+    GuidedQueries q;
+    std::vector<MapPointT*> who;
+    for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
+        MapPointT* pMP = vpPoints[iMP];
+        bool seen = false;
+        for (size_t k = 0; k < found.size() && !seen; ++k) seen = found[k] == pMP;
+        if (pMP->isBad() || seen) continue;
+        const cv::Mat p3Dw = pMP->GetWorldPos();
+        const float P[3] = {p3Dw.template at<float>(0, 0), p3Dw.template at<float>(1, 0), p3Dw.template at<float>(2, 0)};
+        float pc[3];
+        sim3detail::apply(R, t, P, pc);
+        if (pc[2] < 0.0) continue;
+        const float invz = 1 / pc[2];
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+        const float PO[3] = {P[0] - O[0], P[1] - O[1], P[2] - O[2]};
+        const float dist = sim3detail::norm3(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const cv::Mat Pn = pMP->GetNormal();
+        const double dot = (double)PO[0] * Pn.template at<float>(0, 0) + (double)PO[1] * Pn.template at<float>(1, 0) + (double)PO[2] * Pn.template at<float>(2, 0);
+        if (dot < 0.5 * dist) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist, pKF->mfLogScaleFactor);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        q.add(u, v, radius, nPredictedLevel - 1, nPredictedLevel, pMP->GetDescriptor(), true);   // :378 'if(vpMatched[idx]) continue'
+        who.push_back(pMP);
+    }
+    std::vector<uint8_t> taken((size_t)n, 0);
+    for (int i = 0; i < n && i < (int)vpMatched.size(); ++i) taken[i] = vpMatched[i] ? 1 : 0;
+    std::vector<int> matchKp;
+    if (!GuidedSearch(pKF->mvKeysUn, pKF->mDescriptors, taken, pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv,
+                      pKF->mfGridElementHeightInv, q, TH_LOW, false, mfNNratio, matchKp))
+        return 0;
+    int nmatches = 0;
+    for (size_t k = 0; k < who.size(); ++k)
+        if (matchKp[k] >= 0) { vpMatched[matchKp[k]] = who[k]; nmatches++; }
+    return nmatches;
+}
+
+template <class KeyFrameT, class MapPointT>
+int ORBmatcher::Fuse(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints, float th, std::vector<MapPointT*>& vpReplacePoint) {
+    const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy;
+    float R[3][3], t[3], O[3];
+    sim3detail::decompose(Scw, R, t, O);
+    const int n = (int)pKF->mvKeysUn.size();
+    const auto spAlreadyFound = pKF->GetMapPoints();
+    GuidedQueries q;
+    std::vector<int> who;
+    const int nPoints = (int)vpPoints.size();
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+        MapPointT* pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        const cv::Mat p3Dw = pMP->GetWorldPos();
+        const float P[3] = {p3Dw.template at<float>(0, 0), p3Dw.template at<float>(1, 0), p3Dw.template at<float>(2, 0)};
+        float pc[3];
+        sim3detail::apply(R, t, P, pc);
+        if (pc[2] < 0.0f) continue;
+        const float invz = (float)(1.0 / pc[2]);   // :1013 'const float invz = 1.0/...' : a double division
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+        const float PO[3] = {P[0] - O[0], P[1] - O[1], P[2] - O[2]};
+        const float dist3D = sim3detail::norm3(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const cv::Mat Pn = pMP->GetNormal();
+        const double dot = (double)PO[0] * Pn.template at<float>(0, 0) + (double)PO[1] * Pn.template at<float>(1, 0) + (double)PO[2] * Pn.template at<float>(2, 0);
+        if (dot < 0.5 * dist3D) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF->mfLogScaleFactor);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        q.add(u, v, radius, nPredictedLevel - 1, nPredictedLevel, pMP->GetDescriptor(), false);
+        who.push_back(iMP);
+    }
+    std::vector<int> matchKp;
+    const std::vector<uint8_t> none((size_t)n, 0);
+    if (!GuidedSearch(pKF->mvKeysUn, pKF->mDescriptors, none, pKF->mnMinX, pKF->mnMinY, pKF->mfGridElementWidthInv,
+                      pKF->mfGridElementHeightInv, q, TH_LOW, false, mfNNratio, matchKp))
+        return 0;
+    int nFused = 0;
+    for (size_t k = 0; k < who.size(); ++k) {   // the bookkeeping of :1074-1091, in map-point order
+        const int bestIdx = matchKp[k];
+        if (bestIdx < 0) continue;
+        MapPointT* pMP = vpPoints[who[k]];
+        MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) vpReplacePoint[who[k]] = pMPinKF;
+        } else {
+            pMP->AddObservation(pKF, bestIdx);
+            pKF->AddMapPoint(pMP, bestIdx);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
+template <class KeyFrameT, class MapPointT>
+int ORBmatcher::SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                             const cv::Mat& t12, const float th) {
+    const float fx = pKF1->fx, fy = pKF1->fy, cx = pKF1->cx, cy = pKF1->cy;   // both directions use camera 1's intrinsics (:1105-1108)
+    const cv::Mat R1w = pKF1->GetRotation(), t1w = pKF1->GetTranslation(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+    float Ra[3][3], ta[3], Rb[3][3], tb[3], sR12[3][3], sR21[3][3], t12v[3], t21[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+            Ra[r][c] = R1w.template at<float>(r, c); Rb[r][c] = R2w.template at<float>(r, c);
+            sR12[r][c] = s12 * R12.template at<float>(r, c);                                   // :1119
+            sR21[r][c] = (float)((1.0 / s12) * (double)R12.template at<float>(c, r));          // :1120 (double scale factor)
+        }
+        ta[r] = t1w.template at<float>(r, 0); tb[r] = t2w.template at<float>(r, 0); t12v[r] = t12.template at<float>(r, 0);
+    }
+    for (int r = 0; r < 3; ++r) {                                                              // :1121 t21 = -sR21 * t12
+        double a = 0;
+        for (int c = 0; c < 3; ++c) a += (double)sR21[r][c] * (double)t12v[c];
+        t21[r] = (float)(-a);
+    }
+    const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {
+        MapPointT* pMP = vpMatches12[i];
+        if (pMP) {
+            vbAlreadyMatched1[i] = true;
+            const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+        }
+    }
+    // one direction: map points of `from` (camera pose Rf, tf), moved into the other camera by (sR, ts), searched in `to`
+    struct Dir {
+        static bool run(ORBmatcher* self, KeyFrameT* to, const std::vector<MapPointT*>& pts, const std::vector<bool>& done, const float Rf[3][3],
+                        const float tf[3], const float sR[3][3], const float ts[3], float fx, float fy, float cx, float cy, float th,
+                        std::vector<int>& vnMatch) {
+            const int N = (int)pts.size();
+            vnMatch.assign(N, -1);
+            GuidedQueries q;
+            std::vector<int> who;
+            for (int i = 0; i < N; i++) {
+                MapPointT* pMP = pts[i];
+                if (!pMP || done[i]) continue;
+                if (pMP->isBad()) continue;
+                const cv::Mat p3Dw = pMP->GetWorldPos();
+                const float P[3] = {p3Dw.template at<float>(0, 0), p3Dw.template at<float>(1, 0), p3Dw.template at<float>(2, 0)};
+                float pa[3], pb[3];
+                sim3detail::apply(Rf, tf, P, pa);
+                sim3detail::apply(sR, ts, pa, pb);
+                if (pb[2] < 0.0) continue;
+                const float invz = (float)(1.0 / pb[2]);
+                const float x = pb[0] * invz, y = pb[1] * invz;
+                const float u = fx * x + cx, v = fy * y + cy;
+                if (!to->IsInImage(u, v)) continue;
+                const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+                const float dist3D = sim3detail::norm3(pb);
+                if (dist3D < minDistance || dist3D > maxDistance) continue;
+                const int nPredictedLevel = pMP->PredictScale(dist3D, to->mfLogScaleFactor);
+                const float radius = th * to->mvScaleFactors[nPredictedLevel];
+                q.add(u, v, radius, nPredictedLevel - 1, nPredictedLevel, pMP->GetDescriptor(), false);
+                who.push_back(i);
+            }
+            std::vector<int> matchKp;
+            const std::vector<uint8_t> none(to->mvKeysUn.size(), 0);
+            if (!GuidedSearch(to->mvKeysUn, to->mDescriptors, none, to->mnMinX, to->mnMinY, to->mfGridElementWidthInv, to->mfGridElementHeightInv, q,
+                              TH_HIGH, false, self->mfNNratio, matchKp))
+                return false;
+            for (size_t k = 0; k < who.size(); ++k) vnMatch[who[k]] = matchKp[k];
+            return true;
+        }
+    };
+    std::vector<int> vnMatch1, vnMatch2;
+    if (!Dir::run(this, pKF2, vpMapPoints1, vbAlreadyMatched1, Ra, ta, sR21, t21, fx, fy, cx, cy, th, vnMatch1)) return 0;   // :1146-1223
+    if (!Dir::run(this, pKF1, vpMapPoints2, vbAlreadyMatched2, Rb, tb, sR12, t12v, fx, fy, cx, cy, th, vnMatch2)) return 0;  // :1225-1304
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {   // check agreement (:1306-1323)
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; nFound++; }
+        }
+    }
+    return nFound;
 }
 
 template <class FrameT>

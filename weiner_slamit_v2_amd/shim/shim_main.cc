@@ -10,6 +10,7 @@
 //     shim_test fuse <problem.bin> <out.bin>
 //     shim_test init <problem.bin> <out.bin>
 //     shim_test bow <problem.bin> <out.bin>
+//     shim_test sim3 <problem.bin> <out.bin>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -484,8 +485,9 @@ struct MockFusePoint {
     float maxd, mind;
     cv::Mat pos, normal, desc;
     MockFusePoint* replacedBy;
-    int addedAt;
-    MockFusePoint() : id(-1), nobs(0), level(0), bad(false), inKF(false), maxd(0), mind(0), replacedBy(0), addedAt(-1) {}
+    int addedAt, idxInKF2;
+    MockFusePoint() : id(-1), nobs(0), level(0), bad(false), inKF(false), maxd(0), mind(0), replacedBy(0), addedAt(-1), idxInKF2(-1) {}
+    int GetIndexInKeyFrame(MockFuseKF*) { return idxInKF2; }
     bool isBad() { return bad; }
     bool IsInKeyFrame(MockFuseKF*) { return inKF; }
     cv::Mat GetWorldPos() { return pos.clone(); }
@@ -511,6 +513,8 @@ struct MockFuseKF {
     bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
     MockFusePoint* GetMapPoint(size_t idx) { return mps[idx]; }
     void AddMapPoint(MockFusePoint* p, size_t idx) { mps[idx] = p; }
+    std::vector<MockFusePoint*> GetMapPointMatches() { return mps; }
+    std::set<MockFusePoint*> GetMapPoints() { std::set<MockFusePoint*> r; for (size_t i = 0; i < mps.size(); ++i) if (mps[i]) r.insert(mps[i]); return r; }
 };
 
 // problem.bin: int32 n m ; float th ; float R[9] t[3] O[3] ; float intr[4] ; float bounds[6] (minx maxx miny maxy invw invh) ;
@@ -695,6 +699,97 @@ static int run_bow(int argc, char** argv) {
     return 0;
 }
 
+// ---- the Sim3 drivers through the templates -----------------------------------------------------------------------
+// problem.bin: int32 variant (0 SearchByProjection(pKF, Scw, ...), 1 Fuse(pKF, Scw, ...), 2 SearchBySim3) nkf ; float th ;
+//   map points: int32 m ; float pos[3m] normal[3m] maxd[m] mind[m] ; int32 level[m] bad[m] idx_in_kf2[m] ; u8 desc[32m]
+//   per keyframe (nkf of them): float R[9] t[3] intr[4] bounds[6] scale[8] ; int32 n ; float xy[2n] ; int32 octave[n] mp[n] (map point
+//     id sitting at the keypoint or -1) ; u8 desc[32n]
+//   variant 0/1: float Scw[12] (rows 0..2 of the 4x4) ; variant 0: int32 matched[n] ; variant 2: float s12 R12[9] t12[3] ; int32 matches12[n1]
+// out.bin: int32 status count ; variant 0: int32 matched[n] ; variant 1: int32 replace[m] addedAt[m] owner[n] ; variant 2: int32 matches12[n1]
+static void read_kf(Reader& Rd, MockFuseKF& KF, std::vector<MockFusePoint>& pts) {
+    const float* Rv = Rd.arr<float>(9); const float* tv = Rd.arr<float>(3); const float* intr = Rd.arr<float>(4);
+    const float* b = Rd.arr<float>(6); const float* scale = Rd.arr<float>(8);
+    const int n = Rd.get<int>();
+    const float* xy = Rd.arr<float>(2 * (size_t)n); const int* oct = Rd.arr<int>(n); const int* mp = Rd.arr<int>(n);
+    const unsigned char* kd = Rd.arr<unsigned char>(32 * (size_t)n);
+    KF.R = cv::Mat(3, 3, CV_32F); KF.t = cv::Mat(3, 1, CV_32F);
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) KF.R.at<float>(r, c) = Rv[3 * r + c]; KF.t.at<float>(r, 0) = tv[r]; }
+    KF.fx = intr[0]; KF.fy = intr[1]; KF.cx = intr[2]; KF.cy = intr[3]; KF.mfLogScaleFactor = 0.18232f;
+    KF.mnMinX = b[0]; KF.mnMaxX = b[1]; KF.mnMinY = b[2]; KF.mnMaxY = b[3]; KF.mfGridElementWidthInv = b[4]; KF.mfGridElementHeightInv = b[5];
+    KF.mvScaleFactors.assign(scale, scale + 8);
+    KF.mvuRight.assign(n, -1.f); KF.mvKeysUn.resize(n); KF.mps.assign(n, (MockFusePoint*)0);
+    KF.mDescriptors = cv::Mat(n, 32, CV_8U);
+    for (int i = 0; i < n; ++i) {
+        KF.mvKeysUn[i] = cv::KeyPoint(xy[2 * i], xy[2 * i + 1], 31.f, -1.f, 0, oct[i]);
+        memcpy(KF.mDescriptors.ptr(i), kd + 32 * (size_t)i, 32);
+        if (mp[i] >= 0) KF.mps[i] = &pts[mp[i]];
+    }
+}
+static int run_sim3(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<unsigned char> raw = slurp(argv[2]);
+    Reader Rd{raw.data()};
+    const int variant = Rd.get<int>(), nkf = Rd.get<int>();
+    const float th = Rd.get<float>();
+    const int m = Rd.get<int>();
+    const float* pos = Rd.arr<float>(3 * (size_t)m); const float* nrm = Rd.arr<float>(3 * (size_t)m);
+    const float* maxd = Rd.arr<float>(m); const float* mind = Rd.arr<float>(m);
+    const int* level = Rd.arr<int>(m); const int* bad = Rd.arr<int>(m); const int* idx2 = Rd.arr<int>(m);
+    const unsigned char* md = Rd.arr<unsigned char>(32 * (size_t)m);
+    std::vector<MockFusePoint> pts(m);
+    for (int j = 0; j < m; ++j) {
+        MockFusePoint& p = pts[j];
+        p.id = j; p.level = level[j]; p.bad = bad[j] != 0; p.maxd = maxd[j]; p.mind = mind[j]; p.idxInKF2 = idx2[j];
+        p.pos = mat_from(pos + 3 * (size_t)j, 3); p.normal = mat_from(nrm + 3 * (size_t)j, 3);
+        p.desc = cv::Mat(1, 32, CV_8U); memcpy(p.desc.ptr(0), md + 32 * (size_t)j, 32);
+    }
+    MockFuseKF KF[2];
+    for (int k = 0; k < nkf && k < 2; ++k) read_kf(Rd, KF[k], pts);
+    ORBmatcher matcher(0.75f, true);
+    std::vector<int> out;
+    int count = 0;
+    if (variant == 0 || variant == 1) {
+        const float* S = Rd.arr<float>(12);
+        cv::Mat Scw = cv::Mat::zeros(4, 4, CV_32F);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) Scw.at<float>(r, c) = S[4 * r + c];
+        Scw.at<float>(3, 3) = 1.f;
+        std::vector<MockFusePoint*> vp(m);
+        for (int j = 0; j < m; ++j) vp[j] = &pts[j];
+        const int n = (int)KF[0].mvKeysUn.size();
+        if (variant == 0) {
+            const int* init = Rd.arr<int>(n);
+            std::vector<MockFusePoint*> vpMatched(n, (MockFusePoint*)0);
+            for (int i = 0; i < n; ++i) if (init[i] >= 0) vpMatched[i] = &pts[init[i]];
+            count = matcher.SearchByProjection(&KF[0], Scw, vp, vpMatched, (int)th);
+            for (int i = 0; i < n; ++i) out.push_back(vpMatched[i] ? vpMatched[i]->id : -1);
+        } else {
+            std::vector<MockFusePoint*> vpReplace(m, (MockFusePoint*)0);
+            count = matcher.Fuse(&KF[0], Scw, vp, th, vpReplace);
+            for (int j = 0; j < m; ++j) out.push_back(vpReplace[j] ? vpReplace[j]->id : -1);
+            for (int j = 0; j < m; ++j) out.push_back(pts[j].addedAt);
+            for (int i = 0; i < n; ++i) out.push_back(KF[0].mps[i] ? KF[0].mps[i]->id : -1);
+        }
+    } else {
+        const float s12 = Rd.get<float>();
+        const float* Rv = Rd.arr<float>(9); const float* tv = Rd.arr<float>(3);
+        cv::Mat R12(3, 3, CV_32F), t12 = mat_from(tv, 3);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R12.at<float>(r, c) = Rv[3 * r + c];
+        const int n1 = (int)KF[0].mvKeysUn.size();
+        const int* init = Rd.arr<int>(n1);
+        std::vector<MockFusePoint*> vpMatches12(n1, (MockFusePoint*)0);
+        for (int i = 0; i < n1; ++i) if (init[i] >= 0) vpMatches12[i] = &pts[init[i]];
+        count = matcher.SearchBySim3(&KF[0], &KF[1], vpMatches12, s12, R12, t12, th);
+        for (int i = 0; i < n1; ++i) out.push_back(vpMatches12[i] ? vpMatches12[i]->id : -1);
+    }
+    const int status = ORBmatcher::LastStatus();
+    if (status != 0) fprintf(stderr, "sim3 failed: %s\n", slamit_last_error());
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(&status, 4, 1, f); fwrite(&count, 4, 1, f);
+    fwrite(out.data(), 4, out.size(), f);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
@@ -707,5 +802,6 @@ int main(int argc, char** argv) {
     if (mode == "fuse") return run_fuse(argc, argv);
     if (mode == "init") return run_init(argc, argv);
     if (mode == "bow") return run_bow(argc, argv);
+    if (mode == "sim3") return run_sim3(argc, argv);
     return 2;
 }
