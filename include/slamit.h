@@ -407,6 +407,39 @@ typedef struct slamit_pose_result {
 int slamit_pose_optimize_batch(int device, int nframes, const slamit_pose_problem* probs, slamit_pose_result* results);
 int slamit_pose_optimize(int device, const slamit_pose_problem* prob, slamit_pose_result* res);
 
+/* ---- Sim3 between two keyframes (beyond SURVEY.md §8f: loop closing) ---------------------------------
+ * Optimizer::OptimizeSim3 (src/Optimizer.cc:1046-1247) with the g2o it instantiates: one VertexSim3Expmap
+ * (Thirdparty/g2o/g2o/types/types_seven_dof_expmap.h, sim3.h), per correspondence a fixed point in each camera frame and
+ * the pair EdgeSim3ProjectXYZ (x1 = K1 proj(S12 X2)) / EdgeInverseSim3ProjectXYZ (x2 = K2 proj(S12^-1 X1)), Huber kernels
+ * of width (float)sqrt(th2), NUMERIC Jacobians (g2o's central differences, delta 1e-9, core/base_binary_edge.hpp:131-200:
+ * the analytic ones are commented out in the reference), Levenberg-Marquardt on the dense 7 x 7 system.  Schedule:
+ * 5 iterations, drop every pair with chi2 > th2 on either edge, return 0 if fewer than 10 pairs are left, 10 more
+ * iterations (5 if nothing was dropped), count the pairs with both chi2 <= th2.  One workgroup per problem. */
+typedef struct slamit_sim3_problem {
+    int32_t n;                   /* correspondences that pass the reference's validity tests (:1112-1136) */
+    const double* p1;            /* n x 3: P3D1c = R1w P1 + t1w (float values widened) */
+    const double* p2;            /* n x 3: P3D2c */
+    const double* obs1;          /* n x 2: kpUn1.pt */
+    const double* obs2;          /* n x 2: kpUn2.pt */
+    const double* inv_sigma2_1;  /* n: pKF1->mvInvLevelSigma2[kpUn1.octave] */
+    const double* inv_sigma2_2;  /* n */
+    double intr1[4], intr2[4];   /* fx fy cx cy of K1, K2 */
+    double r12[9], t12[3], s12;  /* g2oS12 on entry: rotation (row-major), translation, scale */
+    double th2;                  /* chi2 threshold (10 in LoopClosing::ComputeSim3) */
+    int32_t fix_scale;           /* bFixScale */
+} slamit_sim3_problem;
+
+typedef struct slamit_sim3_result {
+    double r12[9], t12[3], s12;  /* optimised g2oS12 (the input when the function returns 0 at the 10-pair test) */
+    uint8_t* inlier;             /* n out: 0 = the reference sets vpMatches1[idx] to NULL */
+    int32_t n_inliers;           /* the reference's return value */
+    int32_t n_its[2];            /* LM iterations run in each stage */
+    double chi2[2];              /* robust cost of the last evaluated trial of each stage */
+} slamit_sim3_result;
+
+int slamit_sim3_optimize_batch(int device, int nproblems, const slamit_sim3_problem* probs, slamit_sim3_result* results);
+int slamit_sim3_optimize(int device, const slamit_sim3_problem* prob, slamit_sim3_result* res);
+
 /* ---- misc -------------------------------------------------------------------------------- */
 
 const char* slamit_last_error(void);

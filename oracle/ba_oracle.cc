@@ -617,3 +617,247 @@ extern "C" int pose_oracle_solve(const slamit_pose_problem* pb, slamit_pose_resu
     res->n_inliers = n - nBad;
     return 0;
 }
+
+
+// =================================================================================================
+// Optimizer::OptimizeSim3 (S/Optimizer.cc:1046-1247): one VertexSim3Expmap, per correspondence a fixed point in each
+// camera frame and the pair EdgeSim3ProjectXYZ / EdgeInverseSim3ProjectXYZ (G/types/types_seven_dof_expmap.h:118-152)
+// with Huber kernels of width (float)sqrt(th2), BlockSolverX + LinearSolverDense + Levenberg.  The reference's analytic
+// Jacobians are commented out, so g2o differentiates numerically (G/core/base_binary_edge.hpp:131-200: central
+// differences, delta 1e-9, through the vertex's oplus = Sim3(update) * estimate, G/types/sim3.h:69-146).  Schedule:
+// optimize(5), drop the pairs with chi2 > th2 on either edge, return 0 below 10 pairs, optimize(10 or 5), count.
+// Pinned to the reference's g2o (oracle/ba_ref_harness.cc:sim3_ref_solve, tests/golden/sim3_*.npz).
+// =================================================================================================
+namespace {
+
+struct Sim3 { double q[4], t[3], s; };   // q = (x, y, z, w)
+
+// Sim3(const Vector7d& update): [omega, upsilon, sigma] (sim3.h:69-146)
+Sim3 sim3_exp(const double u[7]) {
+    const double omega[3] = {u[0], u[1], u[2]}, ups[3] = {u[3], u[4], u[5]}, sigma = u[6];
+    const double theta = sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
+    const double O[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+    Sim3 S;
+    S.s = exp(sigma);
+    const double eps = 0.00001;
+    double A, B, C, R[9];
+    double ca = 1.0, cb = 1.0;   // R = I + ca * Omega + cb * Omega2
+    if (fabs(sigma) < eps) {
+        C = 1;
+        if (theta < eps) { A = 1. / 2.; B = 1. / 6.; }
+        else {
+            const double theta2 = theta * theta;
+            A = (1 - cos(theta)) / (theta2);
+            B = (theta - sin(theta)) / (theta2 * theta);
+            ca = sin(theta) / theta; cb = (1 - cos(theta)) / (theta * theta);
+        }
+    } else {
+        C = (S.s - 1) / sigma;
+        if (theta < eps) {
+            const double sigma2 = sigma * sigma;
+            A = ((sigma - 1) * S.s + 1) / sigma2;
+            B = ((0.5 * sigma2 - sigma + 1) * S.s) / (sigma2 * sigma);
+        } else {
+            ca = sin(theta) / theta; cb = (1 - cos(theta)) / (theta * theta);
+            const double a = S.s * sin(theta), b = S.s * cos(theta), theta2 = theta * theta, sigma2 = sigma * sigma;
+            const double c = theta2 + sigma2;
+            A = (a * sigma + (1 - b) * theta) / (theta * c);
+            B = (C - ((b - 1) * sigma + a * theta) / (c)) * 1. / (theta2);
+        }
+    }
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0 ? 1.0 : 0.0) + ca * O[i] + cb * O2[i];
+    R_to_quat(R, S.q);   // Quaterniond(R): not normalised
+    for (int i = 0; i < 3; ++i) {
+        double acc = 0;
+        for (int j = 0; j < 3; ++j) acc += (A * O[3 * i + j] + B * O2[3 * i + j] + (i == j ? C : 0.0)) * ups[j];
+        S.t[i] = acc;
+    }
+    return S;
+}
+Sim3 sim3_mul(const Sim3& a, const Sim3& b) {   // sim3.h:258-264
+    Sim3 r;
+    quat_mul(a.q, b.q, r.q);
+    double rt[3];
+    quat_rot(a.q, b.t, rt);
+    for (int i = 0; i < 3; ++i) r.t[i] = a.s * rt[i] + a.t[i];
+    r.s = a.s * b.s;
+    return r;
+}
+void sim3_map(const Sim3& S, const double x[3], double out[3]) {   // s * (r * xyz) + t
+    double rx[3];
+    quat_rot(S.q, x, rx);
+    for (int i = 0; i < 3; ++i) out[i] = S.s * rx[i] + S.t[i];
+}
+Sim3 sim3_inverse(const Sim3& S) {   // Sim3(r.conjugate(), r.conjugate() * ((-1. / s) * t), 1. / s)
+    Sim3 r;
+    r.q[0] = -S.q[0]; r.q[1] = -S.q[1]; r.q[2] = -S.q[2]; r.q[3] = S.q[3];
+    const double k = -1. / S.s;
+    const double kt[3] = {k * S.t[0], k * S.t[1], k * S.t[2]};
+    quat_rot(r.q, kt, r.t);
+    r.s = 1. / S.s;
+    return r;
+}
+
+struct SPair { double p1[3], p2[3], o1[2], o2[2], w1, w2; bool active; double e12[2], e21[2], chi12, chi21; };
+
+// the two edge errors of one pair at S (types_seven_dof_expmap.h:128-133, 146-151)
+void sim3_pair_error(const Sim3& S, const Sim3& Sinv, const double* in1, const double* in2, const SPair& P, double e12[2], double e21[2]) {
+    double v[3];
+    sim3_map(S, P.p2, v);
+    e12[0] = P.o1[0] - (v[0] / v[2] * in1[0] + in1[2]);
+    e12[1] = P.o1[1] - (v[1] / v[2] * in1[1] + in1[3]);
+    sim3_map(Sinv, P.p1, v);
+    e21[0] = P.o2[0] - (v[0] / v[2] * in2[0] + in2[2]);
+    e21[1] = P.o2[1] - (v[1] / v[2] * in2[1] + in2[3]);
+}
+inline double huber_rho(double chi2, double delta, double dsqr) { return chi2 > dsqr ? 2 * sqrt(chi2) * delta - dsqr : chi2; }
+
+double sim3_errors(const Sim3& S, const double* in1, const double* in2, std::vector<SPair>& E, double delta) {
+    const Sim3 Sinv = sim3_inverse(S);
+    const double dsqr = delta * delta;
+    double total = 0;
+    for (size_t k = 0; k < E.size(); ++k) {
+        SPair& P = E[k];
+        if (!P.active) continue;
+        sim3_pair_error(S, Sinv, in1, in2, P, P.e12, P.e21);
+        P.chi12 = P.e12[0] * P.w1 * P.e12[0] + P.e12[1] * P.w1 * P.e12[1];
+        P.chi21 = P.e21[0] * P.w2 * P.e21[0] + P.e21[1] * P.w2 * P.e21[1];
+        total += huber_rho(P.chi12, delta, dsqr) + huber_rho(P.chi21, delta, dsqr);
+    }
+    return total;
+}
+
+void sim3_oplus(Sim3& S, const double* x, bool fix_scale) {   // VertexSim3Expmap::oplusImpl
+    double u[7];
+    for (int i = 0; i < 7; ++i) u[i] = x[i];
+    if (fix_scale) u[6] = 0;
+    S = sim3_mul(sim3_exp(u), S);
+}
+
+int sim3_optimize_stage(Sim3& S, const double* in1, const double* in2, std::vector<SPair>& E, double delta, bool fix_scale, int iterations,
+                        double* lastChi) {
+    bool any = false;
+    for (size_t k = 0; k < E.size(); ++k) any |= E[k].active;
+    if (!any) return 0;
+    const double dsqr = delta * delta;
+    double lambda = -1, ni = 2;
+    int nBad = 0, done = 0;
+    bool ok = true;
+    for (int it = 0; it < iterations && ok; ++it) {
+        double currentChi = sim3_errors(S, in1, in2, E, delta), tempChi = currentChi;
+        const double iniChi = currentChi;
+        double H[49], b[7];
+        for (int i = 0; i < 49; ++i) H[i] = 0;
+        for (int i = 0; i < 7; ++i) b[i] = 0;
+        // numeric Jacobians of every active edge wrt the 7 increments (base_binary_edge.hpp:176-198)
+        const double dl = 1e-9, scalar = 1.0 / (2 * dl);
+        Sim3 Sp[7], Sm[7], Spi[7], Smi[7];
+        for (int d = 0; d < 7; ++d) {
+            double add[7] = {0, 0, 0, 0, 0, 0, 0};
+            add[d] = dl;
+            Sp[d] = S; sim3_oplus(Sp[d], add, fix_scale); Spi[d] = sim3_inverse(Sp[d]);
+            add[d] = -dl;
+            Sm[d] = S; sim3_oplus(Sm[d], add, fix_scale); Smi[d] = sim3_inverse(Sm[d]);
+        }
+        for (size_t k = 0; k < E.size(); ++k) {
+            const SPair& P = E[k];
+            if (!P.active) continue;
+            double J12[14], J21[14];   // 2 x 7 each, row-major
+            for (int d = 0; d < 7; ++d) {
+                double a12[2], a21[2], c12[2], c21[2];
+                sim3_pair_error(Sp[d], Spi[d], in1, in2, P, a12, a21);
+                sim3_pair_error(Sm[d], Smi[d], in1, in2, P, c12, c21);
+                J12[d] = scalar * (a12[0] - c12[0]); J12[7 + d] = scalar * (a12[1] - c12[1]);
+                J21[d] = scalar * (a21[0] - c21[0]); J21[7 + d] = scalar * (a21[1] - c21[1]);
+            }
+            const double r12 = P.chi12 > dsqr ? delta / sqrt(P.chi12) : 1.0, r21 = P.chi21 > dsqr ? delta / sqrt(P.chi21) : 1.0;
+            const double w12 = r12 * P.w1, w21 = r21 * P.w2;
+            for (int i = 0; i < 7; ++i) {
+                b[i] -= r12 * (J12[i] * P.w1 * P.e12[0] + J12[7 + i] * P.w1 * P.e12[1]);
+                b[i] -= r21 * (J21[i] * P.w2 * P.e21[0] + J21[7 + i] * P.w2 * P.e21[1]);
+                for (int j = 0; j < 7; ++j)
+                    H[7 * i + j] += (J12[i] * J12[j] + J12[7 + i] * J12[7 + j]) * w12 + (J21[i] * J21[j] + J21[7 + i] * J21[7 + j]) * w21;
+            }
+        }
+        if (it == 0) {
+            double maxDiag = 0;
+            for (int j = 0; j < 7; ++j) maxDiag = std::max(fabs(H[8 * j]), maxDiag);
+            lambda = 1e-5 * maxDiag; ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            const Sim3 backup = S;
+            std::vector<double> A(49), x(b, b + 7);
+            for (int i = 0; i < 49; ++i) A[i] = H[i] + (i % 8 == 0 ? lambda : 0.0);
+            const bool ok2 = ldlt_solve(A, 7, x);
+            if (ok2) sim3_oplus(S, x.data(), fix_scale); else x.assign(7, 0.0);
+            tempChi = sim3_errors(S, in1, in2, E, delta);
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            double scale = 0;
+            for (int k = 0; k < 7; ++k) scale += x[k] * (lambda * x[k] + b[k]);
+            rho /= scale + 1e-3;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                const double alpha = std::min(1. - pow((2 * rho - 1), 3), 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2; S = backup;
+            }
+            ++qmax;
+        } while (rho < 0 && qmax < 10);
+        ++done;
+        *lastChi = tempChi;
+        if (qmax == 10 || rho == 0) { ok = false; continue; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
+        if (nBad >= 3) ok = false;
+    }
+    return done;
+}
+
+}  // namespace
+
+extern "C" int sim3_oracle_solve(const slamit_sim3_problem* pb, slamit_sim3_result* res) {
+    const int n = pb->n;
+    Sim3 S;
+    R_to_quat(pb->r12, S.q);   // Sim3(R, t, s): Quaterniond(R), not normalised
+    for (int i = 0; i < 3; ++i) S.t[i] = pb->t12[i];
+    S.s = pb->s12;
+    const float th2 = (float)pb->th2;
+    const double delta = (double)(float)sqrt(th2);   // const float deltaHuber = sqrt(th2)
+    std::vector<SPair> E(n);
+    for (int k = 0; k < n; ++k) {
+        SPair& P = E[k];
+        for (int i = 0; i < 3; ++i) { P.p1[i] = pb->p1[3 * k + i]; P.p2[i] = pb->p2[3 * k + i]; }
+        for (int i = 0; i < 2; ++i) { P.o1[i] = pb->obs1[2 * k + i]; P.o2[i] = pb->obs2[2 * k + i]; }
+        P.w1 = pb->inv_sigma2_1[k]; P.w2 = pb->inv_sigma2_2[k];
+        P.active = true; P.e12[0] = P.e12[1] = P.e21[0] = P.e21[1] = 0; P.chi12 = P.chi21 = 0;
+        res->inlier[k] = 1;
+    }
+    for (int k = 0; k < 2; ++k) { res->n_its[k] = 0; res->chi2[k] = 0; }
+    memcpy(res->r12, pb->r12, sizeof(res->r12)); memcpy(res->t12, pb->t12, sizeof(res->t12)); res->s12 = pb->s12;
+    res->n_its[0] = sim3_optimize_stage(S, pb->intr1, pb->intr2, E, delta, pb->fix_scale != 0, 5, &res->chi2[0]);
+    int nBad = 0;
+    for (int k = 0; k < n; ++k)
+        if (E[k].chi12 > th2 || E[k].chi21 > th2) { res->inlier[k] = 0; E[k].active = false; ++nBad; }
+    const int more = nBad > 0 ? 10 : 5;
+    if (n - nBad < 10) { res->n_inliers = 0; return 0; }
+    res->n_its[1] = sim3_optimize_stage(S, pb->intr1, pb->intr2, E, delta, pb->fix_scale != 0, more, &res->chi2[1]);
+    int nIn = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!E[k].active) continue;
+        if (E[k].chi12 > th2 || E[k].chi21 > th2) res->inlier[k] = 0;
+        else ++nIn;
+    }
+    double R[9];
+    quat_to_R(S.q, R);   // rotation().toRotationMatrix()
+    memcpy(res->r12, R, sizeof(R));
+    for (int i = 0; i < 3; ++i) res->t12[i] = S.t[i];
+    res->s12 = S.s;
+    res->n_inliers = nIn;
+    return 0;
+}

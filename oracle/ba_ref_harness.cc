@@ -21,6 +21,7 @@
 #include "Thirdparty/g2o/g2o/solvers/linear_solver_dense.h"
 #include "Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h"
 #include "Thirdparty/g2o/g2o/types/types_six_dof_expmap.h"
+#include "Thirdparty/g2o/g2o/types/types_seven_dof_expmap.h"
 
 #include "../include/slamit.h"
 
@@ -220,5 +221,112 @@ extern "C" int pose_ref_solve(const slamit_pose_problem* pb, slamit_pose_result*
     Eigen::Matrix<double, 4, 4> T = static_cast<g2o::VertexSE3Expmap*>(optimizer.vertex(0))->estimate().to_homogeneous_matrix();
     for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) res->pose[3 * r + c] = T(r, c); res->pose[9 + r] = T(r, 3); }
     res->n_inliers = nInitialCorrespondences - nBad;
+    return 0;
+}
+
+
+// Optimizer::OptimizeSim3 (S/Optimizer.cc:1046-1247) driven from POD inputs with the reference's g2o: the graph the
+// reference builds after its validity tests (:1099-1178), the two-stage schedule and the inlier tests (:1180-1247).
+extern "C" int sim3_ref_solve(const slamit_sim3_problem* pb, slamit_sim3_result* res) {
+    g2o::SparseOptimizer optimizer;
+    g2o::BlockSolverX::LinearSolverType* linearSolver = new g2o::LinearSolverDense<g2o::BlockSolverX::PoseMatrixType>();
+    g2o::BlockSolverX* solver_ptr = new g2o::BlockSolverX(linearSolver);
+    g2o::OptimizationAlgorithmLevenberg* solver = new g2o::OptimizationAlgorithmLevenberg(solver_ptr);
+    optimizer.setAlgorithm(solver);
+    Eigen::Matrix3d R;
+    R << pb->r12[0], pb->r12[1], pb->r12[2], pb->r12[3], pb->r12[4], pb->r12[5], pb->r12[6], pb->r12[7], pb->r12[8];
+    const g2o::Sim3 g2oS12(R, Eigen::Vector3d(pb->t12[0], pb->t12[1], pb->t12[2]), pb->s12);
+    g2o::VertexSim3Expmap* vSim3 = new g2o::VertexSim3Expmap();
+    vSim3->_fix_scale = pb->fix_scale != 0;
+    vSim3->setEstimate(g2oS12);
+    vSim3->setId(0);
+    vSim3->setFixed(false);
+    vSim3->_principle_point1[0] = pb->intr1[2]; vSim3->_principle_point1[1] = pb->intr1[3];
+    vSim3->_focal_length1[0] = pb->intr1[0]; vSim3->_focal_length1[1] = pb->intr1[1];
+    vSim3->_principle_point2[0] = pb->intr2[2]; vSim3->_principle_point2[1] = pb->intr2[3];
+    vSim3->_focal_length2[0] = pb->intr2[0]; vSim3->_focal_length2[1] = pb->intr2[1];
+    optimizer.addVertex(vSim3);
+    const int N = pb->n;
+    std::vector<g2o::EdgeSim3ProjectXYZ*> vpEdges12;
+    std::vector<g2o::EdgeInverseSim3ProjectXYZ*> vpEdges21;
+    const float th2 = (float)pb->th2;
+    const float deltaHuber = sqrt(th2);
+    int nCorrespondences = 0;
+    for (int i = 0; i < N; i++) {
+        res->inlier[i] = 1;
+        const int id1 = 2 * i + 1, id2 = 2 * (i + 1);
+        g2o::VertexSBAPointXYZ* vPoint1 = new g2o::VertexSBAPointXYZ();
+        vPoint1->setEstimate(Eigen::Vector3d(pb->p1[3 * i], pb->p1[3 * i + 1], pb->p1[3 * i + 2]));
+        vPoint1->setId(id1); vPoint1->setFixed(true);
+        optimizer.addVertex(vPoint1);
+        g2o::VertexSBAPointXYZ* vPoint2 = new g2o::VertexSBAPointXYZ();
+        vPoint2->setEstimate(Eigen::Vector3d(pb->p2[3 * i], pb->p2[3 * i + 1], pb->p2[3 * i + 2]));
+        vPoint2->setId(id2); vPoint2->setFixed(true);
+        optimizer.addVertex(vPoint2);
+        nCorrespondences++;
+        Eigen::Matrix<double, 2, 1> obs1;
+        obs1 << pb->obs1[2 * i], pb->obs1[2 * i + 1];
+        g2o::EdgeSim3ProjectXYZ* e12 = new g2o::EdgeSim3ProjectXYZ();
+        e12->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(id2)));
+        e12->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(0)));
+        e12->setMeasurement(obs1);
+        e12->setInformation(Eigen::Matrix2d::Identity() * pb->inv_sigma2_1[i]);
+        g2o::RobustKernelHuber* rk1 = new g2o::RobustKernelHuber;
+        e12->setRobustKernel(rk1);
+        rk1->setDelta(deltaHuber);
+        optimizer.addEdge(e12);
+        Eigen::Matrix<double, 2, 1> obs2;
+        obs2 << pb->obs2[2 * i], pb->obs2[2 * i + 1];
+        g2o::EdgeInverseSim3ProjectXYZ* e21 = new g2o::EdgeInverseSim3ProjectXYZ();
+        e21->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(id1)));
+        e21->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(0)));
+        e21->setMeasurement(obs2);
+        e21->setInformation(Eigen::Matrix2d::Identity() * pb->inv_sigma2_2[i]);
+        g2o::RobustKernelHuber* rk2 = new g2o::RobustKernelHuber;
+        e21->setRobustKernel(rk2);
+        rk2->setDelta(deltaHuber);
+        optimizer.addEdge(e21);
+        vpEdges12.push_back(e12);
+        vpEdges21.push_back(e21);
+    }
+    for (int k = 0; k < 2; ++k) { res->n_its[k] = 0; res->chi2[k] = 0; }
+    memcpy(res->r12, pb->r12, sizeof(res->r12)); memcpy(res->t12, pb->t12, sizeof(res->t12)); res->s12 = pb->s12;
+    optimizer.initializeOptimization();
+    int it = optimizer.optimize(5);
+    res->n_its[0] = it < 0 ? 0 : it;
+    res->chi2[0] = it > 0 ? optimizer.activeRobustChi2() : 0.0;
+    int nBad = 0;
+    for (size_t i = 0; i < vpEdges12.size(); i++) {
+        g2o::EdgeSim3ProjectXYZ* e12 = vpEdges12[i];
+        g2o::EdgeInverseSim3ProjectXYZ* e21 = vpEdges21[i];
+        if (!e12 || !e21) continue;
+        if (e12->chi2() > th2 || e21->chi2() > th2) {
+            res->inlier[i] = 0;
+            optimizer.removeEdge(e12);
+            optimizer.removeEdge(e21);
+            vpEdges12[i] = static_cast<g2o::EdgeSim3ProjectXYZ*>(NULL);
+            vpEdges21[i] = static_cast<g2o::EdgeInverseSim3ProjectXYZ*>(NULL);
+            nBad++;
+        }
+    }
+    const int nMoreIterations = nBad > 0 ? 10 : 5;
+    if (nCorrespondences - nBad < 10) { res->n_inliers = 0; return 0; }
+    optimizer.initializeOptimization();
+    it = optimizer.optimize(nMoreIterations);
+    res->n_its[1] = it < 0 ? 0 : it;
+    res->chi2[1] = it > 0 ? optimizer.activeRobustChi2() : 0.0;
+    int nIn = 0;
+    for (size_t i = 0; i < vpEdges12.size(); i++) {
+        g2o::EdgeSim3ProjectXYZ* e12 = vpEdges12[i];
+        g2o::EdgeInverseSim3ProjectXYZ* e21 = vpEdges21[i];
+        if (!e12 || !e21) continue;
+        if (e12->chi2() > th2 || e21->chi2() > th2) res->inlier[i] = 0;
+        else nIn++;
+    }
+    const g2o::Sim3 out = static_cast<g2o::VertexSim3Expmap*>(optimizer.vertex(0))->estimate();
+    const Eigen::Matrix3d Ro = out.rotation().toRotationMatrix();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) res->r12[3 * r + c] = Ro(r, c); res->t12[r] = out.translation()[r]; }
+    res->s12 = out.scale();
+    res->n_inliers = nIn;
     return 0;
 }

@@ -467,6 +467,61 @@ def _pose_call(which, prob):
     return {"pose": pose, "outlier": outl[:n].copy(), "n_inliers": r.n_inliers, "n_its": list(r.n_its), "chi2": list(r.chi2)}
 
 
+class _Sim3Problem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("p1", C.c_void_p), ("p2", C.c_void_p), ("obs1", C.c_void_p), ("obs2", C.c_void_p),
+                ("inv_sigma2_1", C.c_void_p), ("inv_sigma2_2", C.c_void_p), ("intr1", C.c_double * 4), ("intr2", C.c_double * 4),
+                ("r12", C.c_double * 9), ("t12", C.c_double * 3), ("s12", C.c_double), ("th2", C.c_double), ("fix_scale", C.c_int32)]
+
+
+class _Sim3Result(C.Structure):
+    _fields_ = [("r12", C.c_double * 9), ("t12", C.c_double * 3), ("s12", C.c_double), ("inlier", C.c_void_p), ("n_inliers", C.c_int32),
+                ("n_its", C.c_int32 * 2), ("chi2", C.c_double * 2)]
+
+
+def sim3_problem_struct(prob, cls=_Sim3Problem):
+    """ctypes view of a synth.synth_sim3-style dict (shared with api.py through the same field layout)."""
+    keep = {k: np.ascontiguousarray(prob[k], np.float64) for k in ("p1", "p2", "obs1", "obs2", "inv_sigma2_1", "inv_sigma2_2")}
+    p = cls()
+    p.n = len(keep["inv_sigma2_1"])
+    for k, a in keep.items():
+        setattr(p, k, a.ctypes.data)
+    p.intr1 = (C.c_double * 4)(*[float(v) for v in prob["intr1"]])
+    p.intr2 = (C.c_double * 4)(*[float(v) for v in prob["intr2"]])
+    p.r12 = (C.c_double * 9)(*[float(v) for v in np.asarray(prob["r12"]).reshape(9)])
+    p.t12 = (C.c_double * 3)(*[float(v) for v in prob["t12"]])
+    p.s12, p.th2, p.fix_scale = float(prob["s12"]), float(prob["th2"]), int(prob["fix_scale"])
+    return p, keep
+
+
+def _sim3_call(which, prob):
+    if ("sim3", which) not in _ba:
+        build()
+        if which == "oracle":
+            fn = C.CDLL(os.path.join(HERE, "libba_oracle.so")).sim3_oracle_solve
+        else:
+            fn = C.CDLL(os.path.join(HERE, "_ref", "libba_ref.so")).sim3_ref_solve
+        fn.argtypes = [C.POINTER(_Sim3Problem), C.POINTER(_Sim3Result)]
+        _ba[("sim3", which)] = fn
+    p, keep = sim3_problem_struct(prob)
+    inl = np.zeros(max(p.n, 1), np.uint8)
+    r = _Sim3Result()
+    r.inlier = inl.ctypes.data
+    assert _ba[("sim3", which)](C.byref(p), C.byref(r)) == 0
+    del keep
+    return {"r12": np.array(r.r12[:]).reshape(3, 3), "t12": np.array(r.t12[:]), "s12": r.s12, "inlier": inl[:p.n].copy(),
+            "n_inliers": r.n_inliers, "n_its": list(r.n_its), "chi2": list(r.chi2)}
+
+
+def sim3_solve(prob):
+    """CPU oracle restatement of Optimizer::OptimizeSim3 (oracle/ba_oracle.cc)."""
+    return _sim3_call("oracle", prob)
+
+
+def sim3_ref_solve(prob):
+    """The reference's own g2o (oracle/_ref/libba_ref.so).  Authoring container only."""
+    return _sim3_call("ref", prob)
+
+
 def pose_solve(prob):
     """CPU restatement of PoseOptimization (oracle/ba_oracle.cc)."""
     return _pose_call("oracle", prob)

@@ -41,3 +41,23 @@ def load_pose_golden(path):
     ref = {"pose": z["ref_pose"], "outlier": z["ref_outlier"], "n_inliers": int(z["ref_n_inliers"]),
            "n_its": [int(v) for v in z["ref_n_its"]], "chi2": [float(v) for v in z["ref_chi2"]]}
     return prob, ref
+
+
+def load_sim3_golden(path):
+    z = np.load(path)
+    prob = {k: z[k].astype(np.float64) for k in ("p1", "p2", "obs1", "obs2", "inv_sigma2_1", "inv_sigma2_2", "intr1", "intr2", "r12", "t12")}
+    prob.update(s12=float(z["s12"]), th2=float(z["th2"]), fix_scale=int(z["fix_scale"]), n=len(z["inv_sigma2_1"]))
+    ref = {"r12": z["ref_r12"], "t12": z["ref_t12"], "s12": float(z["ref_s12"]), "inlier": z["ref_inlier"], "n_inliers": int(z["ref_n_inliers"]),
+           "n_its": [int(v) for v in z["ref_n_its"]], "chi2": [float(v) for v in z["ref_chi2"]]}
+    return prob, ref
+
+
+def sim3_close(got, ref, tol=1e-5):
+    """OptimizeSim3 results agree: identical inlier set / counts / iteration counts, S12 within tol (relative)."""
+    assert got["n_inliers"] == ref["n_inliers"] and list(got["n_its"]) == list(ref["n_its"])
+    assert np.array_equal(np.asarray(got["inlier"]), np.asarray(ref["inlier"]))
+    assert np.abs(np.asarray(got["r12"]).reshape(3, 3) - np.asarray(ref["r12"]).reshape(3, 3)).max() <= tol
+    assert np.abs(np.asarray(got["t12"]) - np.asarray(ref["t12"])).max() <= tol * max(1.0, np.abs(ref["t12"]).max())
+    assert abs(got["s12"] - ref["s12"]) <= tol * abs(ref["s12"])
+    for a, b in zip(got["chi2"], ref["chi2"]):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b))

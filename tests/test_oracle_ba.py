@@ -84,3 +84,36 @@ def test_cost_decreases():
     # inliers end near the noise floor (1 px, 2 dof per edge)
     inl = r["edge_outlier"] == 0
     assert r["edge_chi2"][inl].mean() < 2.5
+
+
+# ---- Optimizer::OptimizeSim3: the oracle against golden vectors from the reference's own g2o ----------------------
+SIM3_GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "sim3_*.npz")))
+
+
+@pytest.mark.parametrize("path", SIM3_GOLDEN, ids=[os.path.basename(p)[5:-4] for p in SIM3_GOLDEN])
+def test_sim3_oracle_matches_reference_g2o_golden(path):
+    from tests.helpers import load_sim3_golden, sim3_close
+
+    prob, ref = load_sim3_golden(path)
+    sim3_close(ob.sim3_solve(prob), ref, tol=1e-6)
+
+
+def test_sim3_golden_set_covers_the_branches():
+    from tests.helpers import load_sim3_golden
+
+    assert {os.path.basename(p)[5:-4] for p in SIM3_GOLDEN} >= {"typical", "many_outliers", "fixed_scale", "twelve", "under10", "rough"}
+    _, ref = load_sim3_golden(os.path.join(ROOT, "tests", "golden", "sim3_under10.npz"))
+    prob, _ = load_sim3_golden(os.path.join(ROOT, "tests", "golden", "sim3_under10.npz"))
+    assert ref["n_inliers"] == 0 and ref["n_its"][1] == 0                  # fewer than 10 pairs left: returns 0 ...
+    assert np.array_equal(ref["r12"].reshape(9), prob["r12"].reshape(9)) and ref["s12"] == prob["s12"]   # ... and g2oS12 untouched
+    _, ref = load_sim3_golden(os.path.join(ROOT, "tests", "golden", "sim3_fixed_scale.npz"))
+    assert ref["s12"] == 1.0                                                   # bFixScale: the scale never moves
+
+
+@pytest.mark.skipif(not ob.ba_ref_available(), reason="reference g2o build (oracle/_ref) only exists in the authoring container")
+def test_sim3_oracle_matches_live_reference_g2o():
+    from tests.helpers import sim3_close
+
+    for seed in range(20, 26):
+        pr = synth.synth_sim3(int(40 + 70 * (seed % 5)), 0.1 * (seed % 4), seed, 0.02 + 0.02 * (seed % 3), fix_scale=(seed % 5 == 0))
+        sim3_close(ob.sim3_solve(pr), ob.sim3_ref_solve(pr), tol=1e-6)

@@ -350,3 +350,34 @@ def synth_bow(n1=1000, n2=1000, n_nodes=100, seed=0, mode=0, big_group=0):
         side2["kp_xy"] = xy2
         side2["kp_octave"] = oct2
     return side1, side2, groups, epi
+
+
+def synth_sim3(n=200, outlier_frac=0.15, seed=0, perturb=0.03, fix_scale=False, scale=1.08):
+    """An Optimizer::OptimizeSim3 problem as the reference assembles it (Optimizer.cc:1099-1178): the same physical points as
+    map points of two keyframes, each in its own camera frame (p1, p2, float values), their keypoints in both images, a true
+    similarity p1 = s R p2 + t and a perturbed initial g2oS12 (what Sim3Solver's RANSAC hands over).  Outliers are wrong
+    keypoint associations.  Returns a dict in the layout of slamit_sim3_problem."""
+    rs = np.random.RandomState(9000 + seed)
+    f32 = np.float32
+    intr1 = np.array([517.3, 516.5, 318.6, 255.3], f32).astype(np.float64)
+    intr2 = np.array([520.9, 521.0, 325.1, 249.7], f32).astype(np.float64)
+    s_true = 1.0 if fix_scale else scale
+    R, t = se3_exp(np.array([0.05, -0.08, 0.03, 0.4, -0.1, 0.2]))
+    p2 = np.stack([rs.uniform(-2.5, 2.5, n), rs.uniform(-1.8, 1.8, n), rs.uniform(2.5, 9.0, n)], 1)
+    p1 = s_true * (p2 @ R.T) + t + rs.normal(0, 0.01, (n, 3))           # two independent estimates of the same points
+    p1[:, 2] = np.maximum(p1[:, 2], 0.5)
+    p1, p2 = p1.astype(f32).astype(np.float64), p2.astype(f32).astype(np.float64)
+    obs1 = np.stack([intr1[0] * p1[:, 0] / p1[:, 2] + intr1[2], intr1[1] * p1[:, 1] / p1[:, 2] + intr1[3]], 1) + rs.normal(0, 0.7, (n, 2))
+    obs2 = np.stack([intr2[0] * p2[:, 0] / p2[:, 2] + intr2[2], intr2[1] * p2[:, 1] / p2[:, 2] + intr2[3]], 1) + rs.normal(0, 0.7, (n, 2))
+    bad = rs.rand(n) < outlier_frac
+    obs1[bad] += rs.uniform(-60, 60, (int(bad.sum()), 2))
+    scale_f = f32(1.2) ** np.arange(8, dtype=f32)
+    lv1, lv2 = rs.randint(0, 8, n), rs.randint(0, 8, n)
+    isig1 = (f32(1) / (scale_f * scale_f))[lv1].astype(np.float64)
+    isig2 = (f32(1) / (scale_f * scale_f))[lv2].astype(np.float64)
+    dR, dt = se3_exp(rs.normal(0, perturb, 6))
+    R0, t0 = dR @ R, dR @ t + dt
+    s0 = s_true * (1.0 if fix_scale else float(np.exp(rs.normal(0, perturb))))
+    return dict(n=n, p1=p1, p2=p2, obs1=obs1.astype(f32).astype(np.float64), obs2=obs2.astype(f32).astype(np.float64),
+                inv_sigma2_1=isig1, inv_sigma2_2=isig2, intr1=intr1, intr2=intr2, r12=R0.reshape(9), t12=t0, s12=s0,
+                th2=10.0, fix_scale=int(fix_scale), true=dict(R=R, t=t, s=s_true, bad=bad))
