@@ -52,9 +52,15 @@ def load_sim3_golden(path):
     return prob, ref
 
 
-def sim3_close(got, ref, tol=1e-5):
-    """OptimizeSim3 results agree: identical inlier set / counts / iteration counts, S12 within tol (relative)."""
-    assert got["n_inliers"] == ref["n_inliers"] and list(got["n_its"]) == list(ref["n_its"])
+def sim3_close(got, ref, tol=1e-5, strict_its=True):
+    """OptimizeSim3 results agree: identical inlier set / counts / iteration counts, S12 within tol (relative).
+    strict_its=False: a stage that has converged stops on a gain ratio of rounding noise (the Jacobians are central
+    differences with delta 1e-9), so two correct implementations may run a different number of no-op iterations there."""
+    assert got["n_inliers"] == ref["n_inliers"]
+    if strict_its:
+        assert list(got["n_its"]) == list(ref["n_its"])
+    else:
+        assert all(abs(a - b) <= 3 and (a > 0) == (b > 0) for a, b in zip(got["n_its"], ref["n_its"]))
     assert np.array_equal(np.asarray(got["inlier"]), np.asarray(ref["inlier"]))
     assert np.abs(np.asarray(got["r12"]).reshape(3, 3) - np.asarray(ref["r12"]).reshape(3, 3)).max() <= tol
     assert np.abs(np.asarray(got["t12"]) - np.asarray(ref["t12"])).max() <= tol * max(1.0, np.abs(ref["t12"]).max())

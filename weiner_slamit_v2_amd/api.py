@@ -89,6 +89,17 @@ class BowRule(C.Structure):
                 ("kp2_octave", C.c_void_p), ("scale_factor", C.c_float * 16), ("level_sigma2", C.c_float * 16)]
 
 
+class Sim3Problem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("p1", C.c_void_p), ("p2", C.c_void_p), ("obs1", C.c_void_p), ("obs2", C.c_void_p),
+                ("inv_sigma2_1", C.c_void_p), ("inv_sigma2_2", C.c_void_p), ("intr1", C.c_double * 4), ("intr2", C.c_double * 4),
+                ("r12", C.c_double * 9), ("t12", C.c_double * 3), ("s12", C.c_double), ("th2", C.c_double), ("fix_scale", C.c_int32)]
+
+
+class Sim3Result(C.Structure):
+    _fields_ = [("r12", C.c_double * 9), ("t12", C.c_double * 3), ("s12", C.c_double), ("inlier", C.c_void_p), ("n_inliers", C.c_int32),
+                ("n_its", C.c_int32 * 2), ("chi2", C.c_double * 2)]
+
+
 class SearchBatch(C.Structure):
     _fields_ = [("nframes", C.c_int32), ("kp_cap", C.c_int32), ("q_cap", C.c_int32), ("d_n", C.c_void_p),
                 ("d_kps_un", C.c_void_p), ("d_desc", C.c_void_p), ("d_kp_taken", C.c_void_p), ("min_x", C.c_float),
@@ -120,7 +131,7 @@ EXPORTS = [
     "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
     "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_guided_search_workspace", "slamit_guided_search_batch_dev", "slamit_bow_search", "slamit_undistort_points", "slamit_frame_finish",
     "slamit_frame_finish_batch_dev", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
-    "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
+    "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_sim3_optimize", "slamit_sim3_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
 ]
 
 
@@ -163,6 +174,8 @@ def lib():
         L.slamit_guided_search_workspace.restype = sz
         L.slamit_guided_search_batch_dev.argtypes = [i32, C.POINTER(SearchBatch), C.POINTER(SearchRule), vp, vp, vp, vp, sz, vp]
         f32 = C.c_float
+        L.slamit_sim3_optimize_batch.argtypes = [i32, i32, C.POINTER(Sim3Problem), C.POINTER(Sim3Result)]
+        L.slamit_sim3_optimize.argtypes = [i32, C.POINTER(Sim3Problem), C.POINTER(Sim3Result)]
         L.slamit_bow_search.argtypes = [i32, vp, i32, vp, vp, i32, vp, C.POINTER(BowGroups), C.POINTER(BowRule), vp, vp, vp]
         L.slamit_undistort_points.argtypes = [i32, C.POINTER(Camera), vp, i32, vp]
         L.slamit_frame_finish.argtypes = [i32, C.POINTER(Camera), vp, i32, f32, f32, f32, f32, vp, vp, vp]
@@ -599,6 +612,38 @@ class Optimizer:
         _check(lib().slamit_ba_solve(self._h, C.byref(p), C.byref(o), C.byref(r)), "slamit_ba_solve")
         out["stats"] = self._stats(st)
         return out
+
+    @staticmethod
+    def OptimizeSim3(problems, device=0):
+        """Optimizer::OptimizeSim3 for one problem dict or a list of them (synth.synth_sim3 layout: p1, p2, obs1, obs2,
+        inv_sigma2_1, inv_sigma2_2, intr1, intr2, r12, t12, s12, th2, fix_scale).  Returns dict(s) with r12 (3, 3), t12, s12,
+        inlier flags, n_inliers, n_its[2], chi2[2]."""
+        single = isinstance(problems, dict)
+        plist = [problems] if single else list(problems)
+        m = len(plist)
+        P = (Sim3Problem * m)()
+        R = (Sim3Result * m)()
+        keep, flags = [], []
+        for i, pr in enumerate(plist):
+            k = {key: np.ascontiguousarray(pr[key], np.float64) for key in ("p1", "p2", "obs1", "obs2", "inv_sigma2_1", "inv_sigma2_2")}
+            q = P[i]
+            q.n = len(k["inv_sigma2_1"])
+            for key, a in k.items():
+                setattr(q, key, a.ctypes.data)
+            q.intr1 = (C.c_double * 4)(*[float(v) for v in pr["intr1"]])
+            q.intr2 = (C.c_double * 4)(*[float(v) for v in pr["intr2"]])
+            q.r12 = (C.c_double * 9)(*[float(v) for v in np.asarray(pr["r12"]).reshape(9)])
+            q.t12 = (C.c_double * 3)(*[float(v) for v in pr["t12"]])
+            q.s12, q.th2, q.fix_scale = float(pr["s12"]), float(pr["th2"]), int(pr["fix_scale"])
+            fl = np.zeros(max(q.n, 1), np.uint8)
+            R[i].inlier = fl.ctypes.data
+            keep.append(k)
+            flags.append(fl)
+        _check(lib().slamit_sim3_optimize_batch(device, m, P, R), "slamit_sim3_optimize_batch")
+        outs = [{"r12": np.array(R[i].r12[:]).reshape(3, 3), "t12": np.array(R[i].t12[:]), "s12": R[i].s12, "inlier": flags[i][:P[i].n].copy(),
+                 "n_inliers": R[i].n_inliers, "n_its": list(R[i].n_its), "chi2": list(R[i].chi2)} for i in range(m)]
+        del keep
+        return outs[0] if single else outs
 
     @staticmethod
     def PoseOptimization(problems, device=0):
