@@ -962,3 +962,98 @@ def test_shim_search_by_sim3(tmp_path):
     assert nfound > 100 and (vn1 >= 0).sum() > nfound, "test premise: matches, and some that fail the agreement test"
     assert r[1] == nfound
     assert np.array_equal(r[2:2 + n1], exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fix_scale", [False, True])
+def test_shim_optimize_sim3(tmp_path, fix_scale):
+    """Optimizer::OptimizeSim3 through the template: validity tests and camera-frame points on the host, the two-stage
+    optimisation in one device call, vpMatches1 / g2oS12 written back.  Expected = the same problem assembled in numpy and
+    solved by the CPU oracle (itself pinned to the reference's g2o)."""
+    from oracle import bindings as ob
+    from weiner_slamit_v2_amd import synth
+
+    _build()
+    f32 = np.float32
+    rs = np.random.RandomState(91 + fix_scale)
+    npairs, extra = 260, 140
+    # two keyframes looking at the same points; KF2's map points are a scaled / shifted copy (a drifted loop)
+    R1, t1 = synth.se3_exp(np.array([0.02, -0.03, 0.01, 0.1, 0.05, -0.02]))
+    R2, t2 = synth.se3_exp(np.array([-0.04, 0.05, 0.02, -0.3, 0.1, 0.15]))
+    s_true = 1.0 if fix_scale else 1.07
+    Pw1 = np.stack([rs.uniform(-2.5, 2.5, npairs), rs.uniform(-1.8, 1.8, npairs), rs.uniform(3.0, 9.0, npairs)], 1)
+    Pw1 = (Pw1 - t1) @ R1                                   # world positions of KF1's points (seen in front of camera 1)
+    pc1 = Pw1 @ R1.T + t1
+    Rd_, td_ = synth.se3_exp(np.array([0.03, 0.02, -0.04, 0.2, -0.1, 0.05]))
+    pc2 = ((pc1 - td_) @ Rd_) / s_true                      # p_c1 = s R p_c2 + t  with (R, t) = (Rd_, td_)
+    Pw2 = (pc2 - t2) @ R2 + rs.normal(0, 0.01, (npairs, 3))  # KF2's own estimate of the same points
+    K1 = np.array([517.3, 516.5, 318.6, 255.3], f32)
+    K2 = np.array([520.9, 521.0, 325.1, 249.7], f32)
+    pos = np.concatenate([Pw1, Pw2]).astype(f32)            # map points 0..npairs-1 belong to KF1, npairs.. to KF2
+    m = len(pos)
+    cams = [(R1.astype(f32), t1.astype(f32), K1), (R2.astype(f32), t2.astype(f32), K2)]
+
+    def cam_points(k, P):                                    # R * P + t as cv::gemm computes it (double sums, float result)
+        Rk, tk, _ = cams[k]
+        return (P.astype(np.float64) @ Rk.astype(np.float64).T + tk.astype(np.float64)).astype(f32)
+
+    def project(k, pc):
+        Kk = cams[k][2].astype(np.float64)
+        return np.stack([Kk[0] * pc[:, 0] / pc[:, 2] + Kk[2], Kk[1] * pc[:, 1] / pc[:, 2] + Kk[3]], 1)
+
+    n1, n2 = npairs + extra, npairs + extra
+    perm1, perm2 = rs.permutation(n1)[:npairs], rs.permutation(n2)[:npairs]          # keypoint index of pair j in each keyframe
+    xy1 = np.stack([rs.uniform(0, 640, n1), rs.uniform(0, 480, n1)], 1)
+    xy2 = np.stack([rs.uniform(0, 640, n2), rs.uniform(0, 480, n2)], 1)
+    xy1[perm1] = project(0, cam_points(0, pos[:npairs]).astype(np.float64)) + rs.normal(0, 0.7, (npairs, 2))
+    xy2[perm2] = project(1, cam_points(1, pos[npairs:]).astype(np.float64)) + rs.normal(0, 0.7, (npairs, 2))
+    wrong = rs.rand(npairs) < 0.2
+    xy1[perm1[wrong]] += rs.uniform(-50, 50, (int(wrong.sum()), 2))
+    xy1, xy2 = xy1.astype(f32), xy2.astype(f32)
+    oct1, oct2 = rs.randint(0, 8, n1).astype(np.int32), rs.randint(0, 8, n2).astype(np.int32)
+    scale = f32(1.2) ** np.arange(8, dtype=f32)
+    invsig = (f32(1) / (scale * scale)).astype(f32)
+    mp1, mp2 = np.full(n1, -1, np.int32), np.full(n2, -1, np.int32)
+    mp1[perm1] = np.arange(npairs)
+    mp2[perm2] = npairs + np.arange(npairs)
+    bad = (rs.rand(m) < 0.04).astype(np.int32)
+    idx_in_kf2 = np.full(m, -1, np.int32)
+    idx_in_kf2[npairs:] = perm2
+    idx_in_kf2[npairs:][rs.rand(npairs) < 0.03] = -1                                   # the matched point is not (any more) in KF2
+    matches1 = np.full(n1, -1, np.int32)
+    matches1[perm1] = npairs + np.arange(npairs)
+    matches1[perm1[rs.rand(npairs) < 0.1]] = -1                                        # no match for this keypoint
+    mp1[perm1[rs.rand(npairs) < 0.03]] = -1                                            # KF1 has no point there
+    # initial S12: perturbed truth
+    dR, dt = synth.se3_exp(rs.normal(0, 0.02, 6))
+    R0, t0, s0 = dR @ Rd_, dR @ td_ + dt, s_true * (1.0 if fix_scale else 1.03)
+    S12 = np.concatenate([R0.reshape(9), t0, [s0]])
+    th2 = 10.0
+    blob = struct.pack("<iiiif", n1, n2, m, int(fix_scale), th2) + S12.astype(np.float64).tobytes()
+    for (Rk, tk, Kk), xy, octv, mp in ((cams[0], xy1, oct1, mp1), (cams[1], xy2, oct2, mp2)):
+        blob += Kk.tobytes() + Rk.tobytes() + tk.tobytes() + invsig.tobytes() + xy.tobytes() + octv.tobytes() + mp.tobytes()
+    blob += pos.tobytes() + bad.tobytes() + idx_in_kf2.tobytes() + matches1.tobytes()
+    pin, pout = tmp_path / "s.bin", tmp_path / "o.bin"
+    open(pin, "wb").write(blob)
+    subprocess.check_call([EXE, "osim3", str(pin), str(pout)])
+    raw = open(pout, "rb").read()
+    status, nin = struct.unpack_from("<ii", raw, 0)
+    got_m = np.frombuffer(raw, np.int32, n1, 8)
+    got_S = np.frombuffer(raw, np.float64, 13, 8 + 4 * n1)
+    assert status == 0
+    # expected: the reference's validity tests (Optimizer.cc:1099-1136), then the oracle
+    idx = [i for i in range(n1) if matches1[i] >= 0 and mp1[i] >= 0 and not bad[mp1[i]] and not bad[matches1[i]] and idx_in_kf2[matches1[i]] >= 0]
+    idx = np.array(idx)
+    assert 150 < len(idx) < npairs
+    j1, j2 = mp1[idx], matches1[idx]
+    i2 = idx_in_kf2[j2]
+    prob = dict(p1=cam_points(0, pos[j1]).astype(np.float64), p2=cam_points(1, pos[j2]).astype(np.float64), obs1=xy1[idx].astype(np.float64),
+                obs2=xy2[i2].astype(np.float64), inv_sigma2_1=invsig[oct1[idx]].astype(np.float64), inv_sigma2_2=invsig[oct2[i2]].astype(np.float64),
+                intr1=K1.astype(np.float64), intr2=K2.astype(np.float64), r12=R0.reshape(9), t12=t0, s12=s0, th2=th2, fix_scale=int(fix_scale))
+    o = ob.sim3_solve(prob)
+    assert o["n_inliers"] > 100 and (o["inlier"] == 0).sum() > 10
+    exp_m = matches1.copy()
+    exp_m[idx[o["inlier"] == 0]] = -1
+    assert nin == o["n_inliers"] and np.array_equal(got_m, exp_m)
+    assert np.abs(got_S[:9] - o["r12"].reshape(9)).max() < 1e-6 and np.abs(got_S[9:12] - o["t12"]).max() < 1e-6 and abs(got_S[12] - o["s12"]) < 1e-6
+    assert abs(o["s12"] - s_true) < 0.01

@@ -33,6 +33,14 @@ while time.time() < t_end:
     worst = max(worst, dpp)
     if gp["n_inliers"] != op["n_inliers"] or dpp > 1e-5 or not np.array_equal(gp["outlier"], op["outlier"]):
         bad.append(("pose", seed, float(dpp), gp["n_inliers"], op["n_inliers"]))
+    ps = synth.synth_sim3(int(rs.randint(5, 700)), float(rs.choice([0.0, 0.1, 0.3, 0.5])), seed % 100000, float(rs.choice([0.01, 0.03, 0.08])),
+                          fix_scale=bool(rs.rand() < 0.3))
+    gs = api.Optimizer.OptimizeSim3(ps)
+    os_ = ob.sim3_solve(ps)
+    ds = max(np.abs(gs["r12"] - os_["r12"]).max(), np.abs(gs["t12"] - os_["t12"]).max() / max(np.abs(os_["t12"]).max(), 1.0), abs(gs["s12"] - os_["s12"]))
+    worst = max(worst, ds)
+    if gs["n_inliers"] != os_["n_inliers"] or ds > 1e-5 or not np.array_equal(gs["inlier"], os_["inlier"]):
+        bad.append(("sim3", seed, float(ds), gs["n_inliers"], os_["n_inliers"], gs["n_its"], os_["n_its"]))
 print("iterations %d, failures %d, worst relative difference %.2e" % (it, len(bad), worst))
 for x in bad[:20]:
     print(x)

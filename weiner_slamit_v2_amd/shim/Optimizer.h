@@ -67,6 +67,15 @@ public:
         BundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), nIterations, pbStopFlag, nLoopKF, bRobust);
     }
 
+    // Optimizer::OptimizeSim3 (Optimizer.cc:1046-1247; LoopClosing::ComputeSim3): the validity tests and the camera-frame
+    // points on the host, the whole two-stage optimisation in one slamit_sim3_optimize call.  Members used: KeyFrame : mK,
+    // GetRotation(), GetTranslation(), GetMapPointMatches(), mvKeysUn, mvInvLevelSigma2 ; MapPoint : isBad(), GetWorldPos(),
+    // GetIndexInKeyFrame(pKF).  Sim3T is the caller's g2o::Sim3 (rotation().toRotationMatrix()(r, c), translation()[i],
+    // scale(), constructible from (Eigen::Matrix3d, Eigen::Vector3d, double)) or any type for which the two
+    // slamit_shim_sim3_{get,set} overloads exist.
+    template <class KeyFrameT, class MapPointT, class Sim3T>
+    static int OptimizeSim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches1, Sim3T& g2oS12, const float th2, const bool bFixScale);
+
     // POD form: the window already flattened (what the template above produces).
     static int LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, const volatile bool* stop, slamit_ba_result& res);
     static int SolvePOD(const slamit_ba_problem& prob, const slamit_ba_opts& opts, slamit_ba_result& res);
@@ -193,6 +202,70 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std
         if (nLoopKF == 0) { mps[p]->SetWorldPos(X); mps[p]->UpdateNormalAndDepth(); }
         else { mps[p]->mPosGBA = X.clone(); mps[p]->mnBAGlobalForKF = nLoopKF; }
     }
+}
+
+// Access to the caller's similarity type: g2o::Sim3 by default; other types overload these two.
+template <class Sim3T>
+inline void slamit_shim_sim3_get(const Sim3T& S, double R[9], double t[3], double& s) {
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = S.rotation().toRotationMatrix()(r, c); t[r] = S.translation()[r]; }
+    s = S.scale();
+}
+template <class Sim3T>
+inline void slamit_shim_sim3_set(Sim3T& S, const double R[9], const double t[3], double s) {
+    typename Sim3T::RotationMatrix Rm;   // (for g2o::Sim3 define this alias next to the class, or overload this function)
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rm(r, c) = R[3 * r + c];
+    S = Sim3T(Rm, typename Sim3T::Translation(t[0], t[1], t[2]), s);
+}
+
+template <class KeyFrameT, class MapPointT, class Sim3T>
+int Optimizer::OptimizeSim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches1, Sim3T& g2oS12, const float th2, const bool bFixScale) {
+    const cv::Mat& K1 = pKF1->mK;
+    const cv::Mat& K2 = pKF2->mK;
+    const cv::Mat R1w = pKF1->GetRotation(), t1w = pKF1->GetTranslation(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+    const int N = (int)vpMatches1.size();
+    const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    std::vector<double> p1, p2, o1, o2, w1, w2;
+    std::vector<int> vnIndexEdge;
+    for (int i = 0; i < N; i++) {   // Optimizer.cc:1099-1178
+        if (!vpMatches1[i]) continue;
+        MapPointT* pMP1 = vpMapPoints1[i];
+        MapPointT* pMP2 = vpMatches1[i];
+        const int i2 = pMP2->GetIndexInKeyFrame(pKF2);
+        if (!(pMP1 && pMP2)) continue;
+        if (!(!pMP1->isBad() && !pMP2->isBad() && i2 >= 0)) continue;
+        const cv::Mat P3D1w = pMP1->GetWorldPos(), P3D2w = pMP2->GetWorldPos();
+        for (int r = 0; r < 3; ++r) {   // P3Dc = Rw * P3Dw + tw as cv::gemm computes a CV_32F product (sums in double), widened like toVector3d
+            double a = 0, b = 0;
+            for (int c = 0; c < 3; ++c) {
+                a += (double)R1w.template at<float>(r, c) * (double)P3D1w.template at<float>(c, 0);
+                b += (double)R2w.template at<float>(r, c) * (double)P3D2w.template at<float>(c, 0);
+            }
+            p1.push_back((double)(float)(a + (double)t1w.template at<float>(r, 0)));
+            p2.push_back((double)(float)(b + (double)t2w.template at<float>(r, 0)));
+        }
+        const cv::KeyPoint& kpUn1 = pKF1->mvKeysUn[i];
+        const cv::KeyPoint& kpUn2 = pKF2->mvKeysUn[i2];
+        o1.push_back(kpUn1.pt.x); o1.push_back(kpUn1.pt.y);
+        o2.push_back(kpUn2.pt.x); o2.push_back(kpUn2.pt.y);
+        w1.push_back(pKF1->mvInvLevelSigma2[kpUn1.octave]);
+        w2.push_back(pKF2->mvInvLevelSigma2[kpUn2.octave]);
+        vnIndexEdge.push_back(i);
+    }
+    slamit_sim3_problem P;
+    P.n = (int32_t)vnIndexEdge.size();
+    P.p1 = p1.data(); P.p2 = p2.data(); P.obs1 = o1.data(); P.obs2 = o2.data(); P.inv_sigma2_1 = w1.data(); P.inv_sigma2_2 = w2.data();
+    P.intr1[0] = K1.template at<float>(0, 0); P.intr1[1] = K1.template at<float>(1, 1); P.intr1[2] = K1.template at<float>(0, 2); P.intr1[3] = K1.template at<float>(1, 2);
+    P.intr2[0] = K2.template at<float>(0, 0); P.intr2[1] = K2.template at<float>(1, 1); P.intr2[2] = K2.template at<float>(0, 2); P.intr2[3] = K2.template at<float>(1, 2);
+    slamit_shim_sim3_get(g2oS12, P.r12, P.t12, P.s12);
+    P.th2 = th2; P.fix_scale = bFixScale ? 1 : 0;
+    std::vector<uint8_t> inlier(vnIndexEdge.size() + 1);
+    slamit_sim3_result R;
+    R.inlier = inlier.data();
+    if ((lastStatus() = slamit_sim3_optimize(deviceRef(), &P, &R)) != SLAMIT_OK) return 0;
+    for (size_t k = 0; k < vnIndexEdge.size(); ++k)
+        if (!inlier[k]) vpMatches1[vnIndexEdge[k]] = static_cast<MapPointT*>(NULL);
+    if (R.n_its[1] > 0 || R.n_inliers > 0) slamit_shim_sim3_set(g2oS12, R.r12, R.t12, R.s12);   // the early return 0 leaves g2oS12 alone (:1212-1213)
+    return R.n_inliers;
 }
 
 template <class FrameT>

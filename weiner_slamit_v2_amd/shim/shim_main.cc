@@ -11,6 +11,7 @@
 //     shim_test init <problem.bin> <out.bin>
 //     shim_test bow <problem.bin> <out.bin>
 //     shim_test sim3 <problem.bin> <out.bin>
+//     shim_test osim3 <problem.bin> <out.bin>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -501,7 +502,7 @@ struct MockFusePoint {
     void AddObservation(MockFuseKF*, size_t idx) { addedAt = (int)idx; inKF = true; ++nobs; }
 };
 struct MockFuseKF {
-    cv::Mat R, t, O, mDescriptors;
+    cv::Mat R, t, O, mDescriptors, mK;
     float fx, fy, cx, cy, mfLogScaleFactor;
     float mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
     std::vector<float> mvScaleFactors, mvInvLevelSigma2, mvuRight;
@@ -790,6 +791,54 @@ static int run_sim3(int argc, char** argv) {
     return 0;
 }
 
+// ---- Optimizer::OptimizeSim3 through the template ----------------------------------------------------------------
+struct MockSim3 { double R[9], t[3], s; };
+inline void slamit_shim_sim3_get(const MockSim3& S, double R[9], double t[3], double& s) { memcpy(R, S.R, 72); memcpy(t, S.t, 24); s = S.s; }
+inline void slamit_shim_sim3_set(MockSim3& S, const double R[9], const double t[3], double s) { memcpy(S.R, R, 72); memcpy(S.t, t, 24); S.s = s; }
+// problem.bin: int32 n1 n2 m fix_scale ; float th2 ; double S12[13] (R, t, s) ; per keyframe: float K[4] (fx fy cx cy) R[9] t[3] invsig[8],
+//   keypoints float xy[2n] int32 octave[n] int32 mp[n] (own map point id or -1) ; map points: float pos[3m], int32 bad[m] idx_in_kf2[m] ;
+//   int32 matches1[n1] (map point id of the KF2 point matched to keypoint i of KF1, or -1)
+// out.bin: int32 status n_inliers ; int32 matches1[n1] ; double S12[13]
+static int run_osim3(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<unsigned char> raw = slurp(argv[2]);
+    Reader Rd{raw.data()};
+    const int n[2] = {Rd.get<int>(), Rd.get<int>()};
+    const int m = Rd.get<int>(), fix = Rd.get<int>();
+    const float th2 = Rd.get<float>();
+    MockSim3 S12;
+    { const double* v = Rd.arr<double>(13); memcpy(S12.R, v, 72); memcpy(S12.t, v + 9, 24); S12.s = v[12]; }
+    MockFuseKF KF[2];
+    const int* mpk[2];
+    for (int k = 0; k < 2; ++k) {
+        const float* K = Rd.arr<float>(4); const float* Rv = Rd.arr<float>(9); const float* tv = Rd.arr<float>(3); const float* isg = Rd.arr<float>(8);
+        const float* xy = Rd.arr<float>(2 * (size_t)n[k]); const int* oct = Rd.arr<int>(n[k]); mpk[k] = Rd.arr<int>(n[k]);
+        KF[k].mK = cv::Mat::zeros(3, 3, CV_32F);
+        KF[k].mK.at<float>(0, 0) = K[0]; KF[k].mK.at<float>(1, 1) = K[1]; KF[k].mK.at<float>(0, 2) = K[2]; KF[k].mK.at<float>(1, 2) = K[3]; KF[k].mK.at<float>(2, 2) = 1.f;
+        KF[k].R = cv::Mat(3, 3, CV_32F); KF[k].t = mat_from(tv, 3);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) KF[k].R.at<float>(r, c) = Rv[3 * r + c];
+        KF[k].mvInvLevelSigma2.assign(isg, isg + 8);
+        KF[k].mvKeysUn.resize(n[k]);
+        for (int i = 0; i < n[k]; ++i) KF[k].mvKeysUn[i] = cv::KeyPoint(xy[2 * i], xy[2 * i + 1], 31.f, -1.f, 0, oct[i]);
+    }
+    const float* pos = Rd.arr<float>(3 * (size_t)m); const int* bad = Rd.arr<int>(m); const int* idx2 = Rd.arr<int>(m);
+    std::vector<MockFusePoint> pts(m);
+    for (int j = 0; j < m; ++j) { pts[j].id = j; pts[j].bad = bad[j] != 0; pts[j].idxInKF2 = idx2[j]; pts[j].pos = mat_from(pos + 3 * (size_t)j, 3); }
+    for (int k = 0; k < 2; ++k) { KF[k].mps.assign(n[k], (MockFusePoint*)0); for (int i = 0; i < n[k]; ++i) if (mpk[k][i] >= 0) KF[k].mps[i] = &pts[mpk[k][i]]; }
+    const int* m1 = Rd.arr<int>(n[0]);
+    std::vector<MockFusePoint*> vpMatches1(n[0], (MockFusePoint*)0);
+    for (int i = 0; i < n[0]; ++i) if (m1[i] >= 0) vpMatches1[i] = &pts[m1[i]];
+    const int nin = Optimizer::OptimizeSim3(&KF[0], &KF[1], vpMatches1, S12, th2, fix != 0);
+    const int status = Optimizer::LastStatus();
+    if (status != 0) fprintf(stderr, "osim3 failed: %s\n", slamit_last_error());
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(&status, 4, 1, f); fwrite(&nin, 4, 1, f);
+    for (int i = 0; i < n[0]; ++i) { int id = vpMatches1[i] ? vpMatches1[i]->id : -1; fwrite(&id, 4, 1, f); }
+    fwrite(S12.R, 8, 9, f); fwrite(S12.t, 8, 3, f); fwrite(&S12.s, 8, 1, f);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
@@ -803,5 +852,6 @@ int main(int argc, char** argv) {
     if (mode == "init") return run_init(argc, argv);
     if (mode == "bow") return run_bow(argc, argv);
     if (mode == "sim3") return run_sim3(argc, argv);
+    if (mode == "osim3") return run_osim3(argc, argv);
     return 2;
 }
