@@ -280,34 +280,33 @@ int slamit_pose_optimize_batch(int device, int nframes, const slamit_pose_proble
     if (nframes < 0 || (nframes && (!probs || !results))) return slamit_fail(SLAMIT_ERR_ARG, "slamit_pose_optimize_batch: bad argument");
     if (nframes == 0) return SLAMIT_OK;
     HIP_TRY(hipSetDevice(device));
-    size_t total = 0;
+    // one slab per host thread (slamit_internal.h): [doubles of every frame | ints | PoseFrame records | flags], one copy each way
+    size_t total = 0, flag_total = 0;
     int nmax = 1;
-    std::vector<size_t> off(nframes);
+    std::vector<size_t> off(nframes), foff(nframes);
     for (int f = 0; f < nframes; ++f) {
         const slamit_pose_problem& P = probs[f];
         if (P.n < 0 || !P.pose || !P.intr || (P.n && (!P.xw || !P.uv || !P.inv_sigma2)) || !results[f].pose || (P.n && !results[f].outlier))
             return slamit_fail(SLAMIT_ERR_ARG, "slamit_pose_optimize_batch: null array");
-        off[f] = total;
+        off[f] = total; foff[f] = flag_total;
         // per frame: pose 12 | intr 4 | xw 3n | uv 2n | w n | chi2 n | pose_out 12 | chi2_round 4   (doubles)
         total += 32 + (size_t)7 * P.n;
+        flag_total += ((size_t)P.n + 15) & ~(size_t)7;
         nmax = std::max(nmax, (int)P.n);
     }
-    double* d_buf = nullptr;
-    uint8_t* d_flags = nullptr;
-    int32_t* d_ints = nullptr;
-    PoseFrame* d_frames = nullptr;
-    size_t flag_total = 0;
-    std::vector<size_t> foff(nframes);
-    for (int f = 0; f < nframes; ++f) { foff[f] = flag_total; flag_total += (size_t)probs[f].n + 8; }
-    hipError_t e = hipMalloc((void**)&d_buf, sizeof(double) * total);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_flags, flag_total);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_ints, sizeof(int32_t) * 5 * nframes);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_frames, sizeof(PoseFrame) * nframes);
-    std::vector<PoseFrame> fr(nframes);
-    std::vector<double> stage(total, 0.0);
-    for (int f = 0; f < nframes && e == hipSuccess; ++f) {
+    const size_t o_ints = sizeof(double) * total, o_frames = (o_ints + sizeof(int32_t) * 5 * nframes + 15) & ~(size_t)15;
+    const size_t o_flags = o_frames + sizeof(PoseFrame) * nframes, bytes = o_flags + flag_total;
+    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    hipError_t e = slamit_scratch_reserve(S, device, bytes);
+    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_pose_optimize_batch");
+    double* stage = reinterpret_cast<double*>(S.host);
+    double* d_buf = reinterpret_cast<double*>(S.dev);
+    int32_t* d_ints = reinterpret_cast<int32_t*>(S.dev + o_ints);
+    PoseFrame* fr = reinterpret_cast<PoseFrame*>(S.host + o_frames);
+    uint8_t* d_flags = S.dev + o_flags;
+    for (int f = 0; f < nframes; ++f) {
         const slamit_pose_problem& P = probs[f];
-        double* h = stage.data() + off[f];
+        double* h = stage + off[f];
         double* d = d_buf + off[f];
         const size_t n = P.n;
         memcpy(h, P.pose, 96); memcpy(h + 12, P.intr, 32);
@@ -318,28 +317,26 @@ int slamit_pose_optimize_batch(int device, int nframes, const slamit_pose_proble
         F.outlier = d_flags + foff[f];
         F.n_inliers = d_ints + 5 * f; F.n_its = d_ints + 5 * f + 1;
     }
-    if (e == hipSuccess) e = hipMemcpy(d_buf, stage.data(), sizeof(double) * total, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_frames, fr.data(), sizeof(PoseFrame) * nframes, hipMemcpyHostToDevice);
+    e = hipMemcpyAsync(S.dev, S.host, o_flags, hipMemcpyHostToDevice, S.st);
     if (e == hipSuccess) {
         if (nmax > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pose_opt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, nmax + 16);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(pose_opt_kernel, dim3(nframes), dim3(256), (size_t)nmax + 16, 0, d_frames);
+            hipLaunchKernelGGL(pose_opt_kernel, dim3(nframes), dim3(256), (size_t)nmax + 16, S.st, reinterpret_cast<const PoseFrame*>(S.dev + o_frames));
             e = hipGetLastError();
         }
     }
-    std::vector<int32_t> ints(5 * (size_t)nframes);
-    if (e == hipSuccess) e = hipMemcpy(stage.data(), d_buf, sizeof(double) * total, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(ints.data(), d_ints, sizeof(int32_t) * 5 * nframes, hipMemcpyDeviceToHost);
-    for (int f = 0; f < nframes && e == hipSuccess; ++f) {
+    if (e == hipSuccess) e = hipMemcpyAsync(S.host, S.dev, bytes, hipMemcpyDeviceToHost, S.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S.st);
+    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_pose_optimize_batch");
+    const int32_t* ints = reinterpret_cast<const int32_t*>(S.host + o_ints);
+    for (int f = 0; f < nframes; ++f) {
         const size_t n = probs[f].n;
-        const double* h = stage.data() + off[f];
+        const double* h = stage + off[f];
         memcpy(results[f].pose, h + 16 + 7 * n, 96);
         for (int r = 0; r < 4; ++r) { results[f].chi2[r] = h[28 + 7 * n + r]; results[f].n_its[r] = ints[5 * f + 1 + r]; }
         results[f].n_inliers = ints[5 * f];
-        if (n) e = hipMemcpy(results[f].outlier, d_flags + foff[f], n, hipMemcpyDeviceToHost);
+        if (n) memcpy(results[f].outlier, S.host + o_flags + foff[f], n);
     }
-    hipFree(d_buf); hipFree(d_flags); hipFree(d_ints); hipFree(d_frames);
-    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_pose_optimize_batch");
     return SLAMIT_OK;
 }
 

@@ -369,23 +369,24 @@ int slamit_sim3_optimize_batch(int device, int nprob, const slamit_sim3_problem*
         if (!(P.s12 > 0) || !(P.th2 > 0)) return slamit_fail(SLAMIT_ERR_ARG, "slamit_sim3_optimize_batch: scale and th2 must be positive");
         off[f] = total; foff[f] = flag_total;
         total += (size_t)14 * P.n + 16;          // p1 3n | p2 3n | o1 2n | o2 2n | w1 n | w2 n | chi12 n | chi21 n | out 16   (doubles)
-        flag_total += (size_t)P.n + 8;
+        flag_total += ((size_t)P.n + 15) & ~(size_t)7;
         nmax = std::max(nmax, (int)P.n);
     }
     HIP_TRY(hipSetDevice(device));
-    double* d_buf = nullptr;
-    uint8_t* d_flags = nullptr;
-    int32_t* d_ints = nullptr;
-    Sim3Prob* d_probs = nullptr;
-    hipError_t e = hipMalloc((void**)&d_buf, sizeof(double) * total);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_flags, flag_total);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_ints, sizeof(int32_t) * 4 * nprob);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_probs, sizeof(Sim3Prob) * nprob);
-    std::vector<Sim3Prob> pr(nprob);
-    std::vector<double> stage(total, 0.0);
-    for (int f = 0; f < nprob && e == hipSuccess; ++f) {
+    // one slab per host thread (slamit_internal.h): [doubles of every problem | ints | Sim3Prob records | flags], one copy each way
+    const size_t o_ints = sizeof(double) * total, o_probs = (o_ints + sizeof(int32_t) * 4 * nprob + 15) & ~(size_t)15;
+    const size_t o_flags = o_probs + sizeof(Sim3Prob) * nprob, bytes = o_flags + flag_total;
+    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    hipError_t e = slamit_scratch_reserve(S, device, bytes);
+    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_sim3_optimize_batch");
+    double* stage = reinterpret_cast<double*>(S.host);
+    double* d_buf = reinterpret_cast<double*>(S.dev);
+    int32_t* d_ints = reinterpret_cast<int32_t*>(S.dev + o_ints);
+    Sim3Prob* pr = reinterpret_cast<Sim3Prob*>(S.host + o_probs);
+    uint8_t* d_flags = S.dev + o_flags;
+    for (int f = 0; f < nprob; ++f) {
         const slamit_sim3_problem& P = probs[f];
-        double* h = stage.data() + off[f];
+        double* h = stage + off[f];
         double* d = d_buf + off[f];
         const size_t n = P.n;
         if (n) {
@@ -422,21 +423,21 @@ int slamit_sim3_optimize_batch(int device, int nprob, const slamit_sim3_problem*
         Q.inlier = (SIM3_G uint8_t*)(d_flags + foff[f]);
         Q.ints = (SIM3_G int32_t*)(d_ints + 4 * f);
     }
-    if (e == hipSuccess) e = hipMemcpy(d_buf, stage.data(), sizeof(double) * total, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_probs, pr.data(), sizeof(Sim3Prob) * nprob, hipMemcpyHostToDevice);
+    e = hipMemcpyAsync(S.dev, S.host, o_flags, hipMemcpyHostToDevice, S.st);
     if (e == hipSuccess) {
         if (nmax > 32 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sim3_opt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, nmax + 16);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(sim3_opt_kernel, dim3(nprob), dim3(256), (size_t)nmax + 16, 0, d_probs);
+            hipLaunchKernelGGL(sim3_opt_kernel, dim3(nprob), dim3(256), (size_t)nmax + 16, S.st, reinterpret_cast<const Sim3Prob*>(S.dev + o_probs));
             e = hipGetLastError();
         }
     }
-    std::vector<int32_t> ints(4 * (size_t)nprob);
-    if (e == hipSuccess) e = hipMemcpy(stage.data(), d_buf, sizeof(double) * total, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(ints.data(), d_ints, sizeof(int32_t) * 4 * nprob, hipMemcpyDeviceToHost);
-    for (int f = 0; f < nprob && e == hipSuccess; ++f) {
+    if (e == hipSuccess) e = hipMemcpyAsync(S.host, S.dev, bytes, hipMemcpyDeviceToHost, S.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S.st);
+    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_sim3_optimize_batch");
+    const int32_t* ints = reinterpret_cast<const int32_t*>(S.host + o_ints);
+    for (int f = 0; f < nprob; ++f) {
         const size_t n = probs[f].n;
-        const double* o = stage.data() + off[f] + 14 * n;
+        const double* o = stage + off[f] + 14 * n;
         memcpy(results[f].r12, o, 72); memcpy(results[f].t12, o + 9, 24);
         results[f].s12 = o[12];
         results[f].chi2[0] = o[13]; results[f].chi2[1] = o[14];
@@ -445,10 +446,8 @@ int slamit_sim3_optimize_batch(int device, int nprob, const slamit_sim3_problem*
             memcpy(results[f].r12, probs[f].r12, 72); memcpy(results[f].t12, probs[f].t12, 24);
             results[f].s12 = probs[f].s12;
         }
-        if (n) e = hipMemcpy(results[f].inlier, d_flags + foff[f], n, hipMemcpyDeviceToHost);
+        if (n) memcpy(results[f].inlier, S.host + o_flags + foff[f], n);
     }
-    hipFree(d_buf); hipFree(d_flags); hipFree(d_ints); hipFree(d_probs);
-    if (e != hipSuccess) return slamit_fail_hip(e, "slamit_sim3_optimize_batch");
     return SLAMIT_OK;
 }
 
