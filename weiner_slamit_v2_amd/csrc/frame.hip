@@ -140,18 +140,23 @@ extern "C" int slamit_undistort_points(int device, const slamit_camera* cam, con
     if (!cam || n < 0 || (n && (!xy_in || !xy_out))) return slamit_fail(SLAMIT_ERR_ARG, "slamit_undistort_points: bad argument");
     if (n == 0) return SLAMIT_OK;
     HIP_TRY(hipSetDevice(device));
-    float *din = nullptr, *dout = nullptr;
-    hipError_t e = hipMalloc((void**)&din, 8 * (size_t)n);
-    if (e == hipSuccess) e = hipMalloc((void**)&dout, 8 * (size_t)n);
-    if (e == hipSuccess) e = hipMemcpy(din, xy_in, 8 * (size_t)n, hipMemcpyHostToDevice);
+    // one pinned staging block + one device slab per host thread (slamit_internal.h): [in | out], one copy each way
+    const size_t half = (8 * (size_t)n + 255) & ~(size_t)255;
+    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    hipError_t e = slamit_scratch_reserve(S, device, 2 * half);
+    if (e == hipSuccess) {
+        memcpy(S.host, xy_in, 8 * (size_t)n);
+        e = hipMemcpyAsync(S.dev, S.host, 8 * (size_t)n, hipMemcpyHostToDevice, S.st);
+    }
     if (e == hipSuccess) {
         CamD c = make_cam(cam);
         c.identity = 0;   // cv::undistortPoints itself has no shortcut
-        hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c, din, n, dout);
+        hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, S.st, c, reinterpret_cast<const float*>(S.dev), n, reinterpret_cast<float*>(S.dev + half));
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(xy_out, dout, 8 * (size_t)n, hipMemcpyDeviceToHost);
-    hipFree(din); hipFree(dout);
+    if (e == hipSuccess) e = hipMemcpyAsync(S.host + half, S.dev + half, 8 * (size_t)n, hipMemcpyDeviceToHost, S.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S.st);
+    if (e == hipSuccess) memcpy(xy_out, S.host + half, 8 * (size_t)n);
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_undistort_points");
     return SLAMIT_OK;
 }
@@ -177,22 +182,28 @@ extern "C" int slamit_frame_finish(int device, const slamit_camera* cam, const s
     if (n > SLAMIT_FRAME_MAX_KP) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_frame_finish: more than SLAMIT_FRAME_MAX_KP keypoints");
     HIP_TRY(hipSetDevice(device));
     const int cap = std::max(n, 1);
-    slamit_kp *dk = nullptr, *du = nullptr;
-    int *dcs = nullptr, *dci = nullptr;
-    hipError_t e = hipMalloc((void**)&dk, sizeof(slamit_kp) * (size_t)cap);
-    if (e == hipSuccess) e = hipMalloc((void**)&du, sizeof(slamit_kp) * (size_t)cap);
-    if (e == hipSuccess) e = hipMalloc((void**)&dcs, sizeof(int) * (FG_CELLS + 1));
-    if (e == hipSuccess) e = hipMalloc((void**)&dci, sizeof(int) * (size_t)cap);
-    if (e == hipSuccess && n) e = hipMemcpy(dk, kps, sizeof(slamit_kp) * (size_t)n, hipMemcpyHostToDevice);
+    // one pinned staging block + one device slab per host thread: [keypoints in | keypoints out | cell_start | cell_items]
+    const size_t kb = (sizeof(slamit_kp) * (size_t)cap + 255) & ~(size_t)255, cs = (sizeof(int) * (FG_CELLS + 1) + 255) & ~(size_t)255;
+    const size_t o_un = kb, o_cs = 2 * kb, o_ci = o_cs + cs, bytes = o_ci + sizeof(int) * (size_t)cap;
+    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    hipError_t e = slamit_scratch_reserve(S, device, bytes);
+    if (e == hipSuccess && n) {
+        memcpy(S.host, kps, sizeof(slamit_kp) * (size_t)n);
+        e = hipMemcpyAsync(S.dev, S.host, sizeof(slamit_kp) * (size_t)n, hipMemcpyHostToDevice, S.st);
+    }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(frame_finish_kernel, dim3(1), dim3(FF_THREADS), sizeof(short) * (size_t)cap, 0, make_cam(cam), dk,
-                           (const int*)nullptr, n, cap, min_x, min_y, inv_w, inv_h, du, dcs, dci);
+        hipLaunchKernelGGL(frame_finish_kernel, dim3(1), dim3(FF_THREADS), sizeof(short) * (size_t)cap, S.st, make_cam(cam),
+                           reinterpret_cast<const slamit_kp*>(S.dev), (const int*)nullptr, n, cap, min_x, min_y, inv_w, inv_h,
+                           reinterpret_cast<slamit_kp*>(S.dev + o_un), reinterpret_cast<int*>(S.dev + o_cs), reinterpret_cast<int*>(S.dev + o_ci));
         e = hipGetLastError();
     }
-    if (e == hipSuccess && n) e = hipMemcpy(kps_un, du, sizeof(slamit_kp) * (size_t)n, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(cell_start, dcs, sizeof(int) * (FG_CELLS + 1), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && n) e = hipMemcpy(cell_items, dci, sizeof(int) * (size_t)std::min(n, cell_start[FG_CELLS]), hipMemcpyDeviceToHost);
-    hipFree(dk); hipFree(du); hipFree(dcs); hipFree(dci);
+    if (e == hipSuccess) e = hipMemcpyAsync(S.host + o_un, S.dev + o_un, bytes - o_un, hipMemcpyDeviceToHost, S.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S.st);
+    if (e == hipSuccess) {
+        if (n) memcpy(kps_un, S.host + o_un, sizeof(slamit_kp) * (size_t)n);
+        memcpy(cell_start, S.host + o_cs, sizeof(int) * (FG_CELLS + 1));
+        if (n) memcpy(cell_items, S.host + o_ci, sizeof(int) * (size_t)std::min(n, cell_start[FG_CELLS]));
+    }
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_frame_finish");
     return SLAMIT_OK;
 }

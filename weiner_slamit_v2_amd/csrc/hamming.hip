@@ -11,6 +11,7 @@
 // tiles of 256 rows (8 KB), read as broadcast ds_read_b128; distance = 8 x (v_xor + v_bcnt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -186,20 +187,29 @@ int slamit_distinctive_batch(const uint8_t* desc, const int32_t* offsets, int np
     }
     const int total = offsets[npoints];
     if (total && !desc) return slamit_fail(SLAMIT_ERR_ARG, "slamit_distinctive_batch: null descriptors");
-    uint8_t* dd = nullptr;
-    int *doff = nullptr, *dout = nullptr;
-    hipError_t e = hipMalloc((void**)&dd, std::max<size_t>((size_t)total * 32, 32));
-    if (e == hipSuccess) e = hipMalloc((void**)&doff, sizeof(int) * ((size_t)npoints + 1));
-    if (e == hipSuccess) e = hipMalloc((void**)&dout, sizeof(int) * 2 * (size_t)npoints);
-    if (e == hipSuccess && total) e = hipMemcpy(dd, desc, (size_t)total * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(doff, offsets, sizeof(int) * ((size_t)npoints + 1), hipMemcpyHostToDevice);
+    // one pinned staging block + one device slab per host thread (slamit_internal.h): [descriptors | offsets | out], one copy each way
+    const size_t o_off = ((size_t)total * 32 + 255) & ~(size_t)255, o_out = o_off + ((sizeof(int) * ((size_t)npoints + 1) + 255) & ~(size_t)255);
+    const size_t bytes = o_out + sizeof(int) * 2 * (size_t)npoints;
+    int cur_dev = 0;
+    hipGetDevice(&cur_dev);
+    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    hipError_t e = slamit_scratch_reserve(S, cur_dev, bytes);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(distinctive_kernel, dim3(npoints), dim3(64), 0, 0, dd, doff, dout, dout + npoints);
+        if (total) memcpy(S.host, desc, (size_t)total * 32);
+        memcpy(S.host + o_off, offsets, sizeof(int) * ((size_t)npoints + 1));
+        e = hipMemcpyAsync(S.dev, S.host, o_out, hipMemcpyHostToDevice, S.st);
+    }
+    if (e == hipSuccess) {
+        int* dout = reinterpret_cast<int*>(S.dev + o_out);
+        hipLaunchKernelGGL(distinctive_kernel, dim3(npoints), dim3(64), 0, S.st, S.dev, reinterpret_cast<const int*>(S.dev + o_off), dout, dout + npoints);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(best_idx, dout, sizeof(int) * npoints, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(best_median, dout + npoints, sizeof(int) * npoints, hipMemcpyDeviceToHost);
-    hipFree(dd); hipFree(doff); hipFree(dout);
+    if (e == hipSuccess) e = hipMemcpyAsync(S.host + o_out, S.dev + o_out, bytes - o_out, hipMemcpyDeviceToHost, S.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S.st);
+    if (e == hipSuccess) {
+        memcpy(best_idx, S.host + o_out, sizeof(int) * npoints);
+        memcpy(best_median, S.host + o_out + sizeof(int) * npoints, sizeof(int) * npoints);
+    }
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_distinctive_batch");
     return SLAMIT_OK;
 }
@@ -228,22 +238,30 @@ int slamit_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_best2: bad argument");
     if (nq == 0) return SLAMIT_OK;
     if (nt > SLAMIT_HAMMING_MAX_TRAIN) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_hamming_best2: more than SLAMIT_HAMMING_MAX_TRAIN train descriptors");
-    uint8_t *dq = nullptr, *dt = nullptr;
-    int* dout = nullptr;
-    hipError_t e = hipMalloc((void**)&dq, (size_t)nq * 32);
-    if (e == hipSuccess) e = hipMalloc((void**)&dt, std::max<size_t>((size_t)nt * 32, 32));
-    if (e == hipSuccess) e = hipMalloc((void**)&dout, sizeof(int) * 3 * (size_t)nq);
-    if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nt) e = hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice);
+    // one pinned staging block + one device slab per host thread: [query | train | out], one copy each way
+    const size_t o_t = ((size_t)nq * 32 + 255) & ~(size_t)255, o_out = o_t + ((std::max<size_t>((size_t)nt * 32, 32) + 255) & ~(size_t)255);
+    const size_t bytes = o_out + sizeof(int) * 3 * (size_t)nq;
+    int cur_dev = 0;
+    hipGetDevice(&cur_dev);
+    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    hipError_t e = slamit_scratch_reserve(S, cur_dev, bytes);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + HM_QPB - 1) / HM_QPB, 1), dim3(256), 0, 0, dq, (const int*)nullptr, nq,
-                           (size_t)0, dt, (const int*)nullptr, nt, (size_t)0, dout, dout + nq, dout + 2 * (size_t)nq, (size_t)0);
+        memcpy(S.host, q, (size_t)nq * 32);
+        if (nt) memcpy(S.host + o_t, t, (size_t)nt * 32);
+        e = hipMemcpyAsync(S.dev, S.host, o_out, hipMemcpyHostToDevice, S.st);
+    }
+    if (e == hipSuccess) {
+        int* dout = reinterpret_cast<int*>(S.dev + o_out);
+        hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + HM_QPB - 1) / HM_QPB, 1), dim3(256), 0, S.st, S.dev, (const int*)nullptr, nq,
+                           (size_t)0, S.dev + o_t, (const int*)nullptr, nt, (size_t)0, dout, dout + nq, dout + 2 * (size_t)nq, (size_t)0);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(best_idx, dout, sizeof(int) * nq, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(best, dout + nq, sizeof(int) * nq, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(second, dout + 2 * (size_t)nq, sizeof(int) * nq, hipMemcpyDeviceToHost);
-    hipFree(dq); hipFree(dt); hipFree(dout);
+    if (e == hipSuccess) e = hipMemcpyAsync(S.host + o_out, S.dev + o_out, bytes - o_out, hipMemcpyDeviceToHost, S.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S.st);
+    if (e == hipSuccess) {
+        const int* o = reinterpret_cast<const int*>(S.host + o_out);
+        memcpy(best_idx, o, sizeof(int) * nq); memcpy(best, o + nq, sizeof(int) * nq); memcpy(second, o + 2 * (size_t)nq, sizeof(int) * nq);
+    }
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_hamming_best2");
     return SLAMIT_OK;
 }
