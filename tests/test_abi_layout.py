@@ -58,6 +58,9 @@ def test_struct_layouts_match_the_header():
         printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(slamit_kp), sizeof(slamit_orb_params), sizeof(slamit_ba_problem),
                sizeof(slamit_ba_opts), sizeof(slamit_ba_stats), sizeof(slamit_ba_result), offsetof(slamit_ba_stats, lambda),
                offsetof(slamit_ba_opts, stop));
+        printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(slamit_search_rule), sizeof(slamit_search_batch), sizeof(slamit_frame_view),
+               sizeof(slamit_search_queries), sizeof(slamit_camera), sizeof(slamit_bow_groups), sizeof(slamit_bow_rule), offsetof(slamit_bow_rule, kp1_xy),
+               sizeof(slamit_sim3_problem), offsetof(slamit_sim3_problem, fix_scale), sizeof(slamit_sim3_result), offsetof(slamit_sim3_result, inlier));
         return 0;
     }'''
     d = os.path.join(ROOT, "gpurun_out")
@@ -71,6 +74,10 @@ def test_struct_layouts_match_the_header():
     assert sizes[1] == C.sizeof(api.OrbParams) and sizes[2] == C.sizeof(api.BaProblem)
     assert sizes[3] == C.sizeof(api.BaOpts) and sizes[4] == C.sizeof(api.BaStats) and sizes[5] == C.sizeof(api.BaResult)
     assert sizes[6] == api.BaStats.lambda_.offset and sizes[7] == api.BaOpts.stop.offset
+    want = [C.sizeof(api.SearchRule), C.sizeof(api.SearchBatch), C.sizeof(api.FrameView), C.sizeof(api.SearchQueries), C.sizeof(api.Camera),
+            C.sizeof(api.BowGroups), C.sizeof(api.BowRule), api.BowRule.kp1_xy.offset, C.sizeof(api.Sim3Problem), api.Sim3Problem.fix_scale.offset,
+            C.sizeof(api.Sim3Result), api.Sim3Result.inlier.offset]
+    assert sizes[8:] == want
 
 
 def test_product_never_touches_the_oracle():
