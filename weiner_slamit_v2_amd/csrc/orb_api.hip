@@ -126,6 +126,7 @@ struct slamit_orb {
     slamit_kp* d_out_kps;
     uint8_t* d_out_desc;
     int* d_out_n;
+    uint8_t* h_out;   // pinned: [n per frame | keypoints | descriptors] of a whole batch, so the readback is one stream op chain + one sync
     uint8_t* d_scratch;  // padded plane / debug scratch
     size_t scratch_bytes;
     // optional per-stage hipEvent timing (slamit_orb_profile)
@@ -144,7 +145,7 @@ static void orb_free(slamit_orb* h) {
     hipSetDevice(h->device);
     hipFree(h->d_levels); hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cand); hipFree(h->d_ws_xy);
     hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_blur_tiles); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
-    hipFree(h->d_out_desc); hipFree(h->d_out_n); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
+    hipFree(h->d_out_desc); hipFree(h->d_out_n); if (h->h_out) hipHostFree(h->h_out); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
     for (int l = 0; l < ORB_MAX_LEVELS; ++l) { hipFree(h->d_rs_col[l]); hipFree(h->d_rs_row[l]); }
@@ -276,6 +277,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
     ALLOC(h->d_out_kps, sizeof(slamit_kp) * (size_t)h->max_out * B);
     ALLOC(h->d_out_desc, (size_t)SLAMIT_DESC_BYTES * h->max_out * B);
     ALLOC(h->d_out_n, sizeof(int) * B);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, 256 + (size_t)B * 256 + (sizeof(slamit_kp) + SLAMIT_DESC_BYTES) * (size_t)h->max_out * B, hipHostMallocDefault);
     h->scratch_bytes = std::max<size_t>((size_t)(p->width + 38) * (p->height + 38),
                                         (sizeof(unsigned long long) + 3 * sizeof(int)) * (h->cand_frame_stride + 64));
     ALLOC(h->d_scratch, h->scratch_bytes);
@@ -549,18 +551,22 @@ int slamit_orb_extract_batch(slamit_orb* h, const uint8_t* gray, size_t stride, 
     int rc = slamit_orb_extract_batch_dev(h, h->d_in, h->d_in_stride, h->d_in_frame, nframes, h->d_out_kps, h->d_out_desc,
                                           h->max_out, h->d_out_n, h->stream);
     if (rc != SLAMIT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(n_out, h->d_out_n, sizeof(int) * nframes, hipMemcpyDeviceToHost, h->stream));
+    // readback through the pinned block: counts, keypoints and descriptors are three copies on the stream and ONE
+    // synchronisation (copying by the exact counts needs the counts on the host first, i.e. a second round trip)
+    const size_t o_k = ((sizeof(int) * (size_t)nframes + 255) & ~(size_t)255), kb = sizeof(slamit_kp) * (size_t)h->max_out * nframes;
+    const size_t o_d = (o_k + kb + 255) & ~(size_t)255, db = (size_t)SLAMIT_DESC_BYTES * h->max_out * nframes;
+    HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out_n, sizeof(int) * nframes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_out + o_k, h->d_out_kps, kb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_out + o_d, h->d_out_desc, db, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    memcpy(n_out, h->h_out, sizeof(int) * nframes);
     for (int f = 0; f < nframes; ++f) {
-        int n = n_out[f];
+        const int n = n_out[f];
         if (n > 0) {
-            HIP_TRY(hipMemcpyAsync(kps + (size_t)f * cap, h->d_out_kps + (size_t)f * h->max_out, sizeof(slamit_kp) * n,
-                                   hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipMemcpyAsync(desc + (size_t)f * cap * SLAMIT_DESC_BYTES, h->d_out_desc + (size_t)f * h->max_out * SLAMIT_DESC_BYTES,
-                                   (size_t)SLAMIT_DESC_BYTES * n, hipMemcpyDeviceToHost, h->stream));
+            memcpy(kps + (size_t)f * cap, h->h_out + o_k + sizeof(slamit_kp) * (size_t)f * h->max_out, sizeof(slamit_kp) * n);
+            memcpy(desc + (size_t)f * cap * SLAMIT_DESC_BYTES, h->h_out + o_d + (size_t)SLAMIT_DESC_BYTES * f * h->max_out, (size_t)SLAMIT_DESC_BYTES * n);
         }
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
     return SLAMIT_OK;
 }
 
