@@ -350,6 +350,7 @@ extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, cons
         if (S.st) hipStreamSynchronize(S.st);
         if (S.host) hipHostFree(S.host);
         if (S.dev) hipFree(S.dev);
+        if (S.st && S.device != device) { hipStreamDestroy(S.st); S.st = nullptr; }   // a stream belongs to the device it was created on
         S.host = nullptr; S.dev = nullptr; S.host_bytes = S.dev_bytes = 0; S.device = device;
         if (!S.st) HIP_TRY(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
         HIP_TRY(hipHostMalloc((void**)&S.host, io_bytes + io_bytes / 2, hipHostMallocDefault));

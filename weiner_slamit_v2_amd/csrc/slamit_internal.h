@@ -22,9 +22,10 @@ inline hipError_t slamit_scratch_reserve(SlamitScratch& S, int device, size_t by
     if (S.st) hipStreamSynchronize(S.st);
     if (S.host) hipHostFree(S.host);
     if (S.dev) hipFree(S.dev);
+    if (S.st && S.device != device) { hipStreamDestroy(S.st); S.st = nullptr; }   // a stream belongs to the device it was created on
     S.host = nullptr; S.dev = nullptr; S.host_bytes = S.dev_bytes = 0; S.device = device;
     hipError_t e = hipSuccess;
-    if (!S.st) e = hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking);
+    if (!S.st) e = hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking);   // the caller has made `device` current
     const size_t want = bytes + bytes / 2 + 4096;
     if (e == hipSuccess) e = hipHostMalloc((void**)&S.host, want, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&S.dev, want);
