@@ -94,10 +94,21 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// Sum over the 64 lanes, the same value in every lane, in a fixed order: four DPP exchanges make every 16-lane row hold its
+// row sum (xor 1, xor 2, half-row mirror, row mirror), four v_readlane pairs join the rows.  (The ds_bpermute form of
+// __shfl_xor is an LDS round trip per step: twelve of them per sum, and the optimisers reduce 27-35 sums per iteration.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_xchg_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    v += dpp_xchg_d<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_xchg_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_xchg_d<0x141>(v);   // row_half_mirror
+    v += dpp_xchg_d<0x140>(v);   // row_mirror
+    return ((readlane_d(v, 0) + readlane_d(v, 16)) + readlane_d(v, 32)) + readlane_d(v, 48);
 }
 
 #endif
