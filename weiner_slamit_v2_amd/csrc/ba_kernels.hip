@@ -103,9 +103,12 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
 // ---- S2: landmark blocks Hll, bl: BA_PG lanes per point (lane g takes edges g, g + BA_PG, ... of the point's list, then a
 // fixed xor-shuffle tree), so a 50-observation point is 7 serial edges instead of 50 and a wave covers 8 points -------
 #define BA_PG 8
-__device__ __forceinline__ double group_sum(double v) {   // sum over the BA_PG consecutive lanes of a point group
-#pragma unroll
-    for (int d = 1; d < BA_PG; d <<= 1) v += __shfl_xor(v, d, 64);
+__device__ __forceinline__ double group_sum(double v) {   // sum over the BA_PG = 8 consecutive lanes of a point group
+    // the xor-1 / xor-2 / xor-4 tree as three DPP exchanges (bit-identical to the __shfl_xor form, without its LDS round trips;
+    // after the first two steps a quad is uniform, so the half-row mirror is as good a partner as lane ^ 4)
+    v += dpp_xchg_d<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_xchg_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_xchg_d<0x141>(v);   // row_half_mirror
     return v;
 }
 

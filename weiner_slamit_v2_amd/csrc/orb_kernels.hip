@@ -984,6 +984,16 @@ static DiscTable make_disc() {
 
 #define IC_KP_PER_WAVE 4
 
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int wave_sum_i32(int v) {   // the same value in every lane; no LDS round trips (ds_bpermute) involved
+    v += dpp_i32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_i32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_i32<0x141>(v);   // row_half_mirror
+    v += dpp_i32<0x140>(v);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 __global__ __launch_bounds__(256) void ic_angle_kernel(
     const OrbLevel* __restrict__ levels, int nlevels,
     const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
@@ -1025,11 +1035,7 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
         int m10 = 0, m01 = 0;
 #pragma unroll
         for (int j = 0; j < 12; ++j) { m10 += __mul24(wu[j], val[k][j]); m01 += __mul24(wv[j], val[k][j]); }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            m10 += __shfl_xor(m10, d, WAVE);
-            m01 += __shfl_xor(m01, d, WAVE);
-        }
+        m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);   // DPP row sums + v_readlane (integer: any order is exact)
         if (lane == k) { my10 = m10; my01 = m01; }
     }
     if (lane < IC_KP_PER_WAVE && i0 + lane < count) {
