@@ -635,13 +635,16 @@ __device__ int block_exclusive_scan(int* a, int len, int* wave_tmp /*[NT / 64]*/
     const int lo = min(tid * C, len), hi = min(lo + C, len);
     int sum = 0;
     for (int i = lo; i < hi; ++i) sum += a[i];
-    // inclusive scan of `sum` across the wave
+    // inclusive scan of `sum` across the wave: four DPP row shifts scan each 16-lane row, two row broadcasts carry the row
+    // totals on (lane 15 -> rows 1 and 3, lane 31 -> rows 2 and 3); shifted-out and masked-off lanes contribute the 0 of `old`.
+    // (As six __shfl_up steps this was six dependent ds_bpermute round trips on the kernel's critical path.)
     int incl = sum;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int t = __shfl_up(incl, d, WAVE);
-        if ((tid & 63) >= d) incl += t;
-    }
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);   // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);   // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);   // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);   // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
     if ((tid & 63) == 63) wave_tmp[tid >> 6] = incl;
     __syncthreads();
     int wbase = 0, total = 0;
