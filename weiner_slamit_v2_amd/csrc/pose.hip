@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void pose_opt_kernel(const PoseFrame* frames) 
             int lm_nBad = 0;
             bool ok = true;
             for (int it = 0; it < 10 && ok; ++it) {
-                const double currentChi0 = pose_errors(F, sT, s_act, robust, delta, sh);
+                // g2o re-evaluates the errors at the top of every iteration; after an accepted trial (the only way to get here
+                // with it > 0) they are the ones that trial just computed at this very pose: same bits, one pass saved
+                const double currentChi0 = it == 0 ? pose_errors(F, sT, s_act, robust, delta, sh) : s_cur;
                 // ---- normal equations H (21 unique), b (6): per-thread partials, shuffle tree, 4 waves in order ----
                 double h[21], bb[6];
                 for (int i = 0; i < 21; ++i) h[i] = 0;

@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void sim3_opt_kernel(const Sim3Prob* probs) {
             int lm_nBad = 0;
             bool ok = true;
             for (int it = 0; it < iterations && ok; ++it) {
-                const double currentChi0 = sim3_errors(P, sS, s_act, delta, sSi, sh);
+                // g2o re-evaluates the errors at the top of every iteration; after an accepted trial (the only way to get here
+                // with it > 0) errors, chi2 and S^-1 are the ones that trial just computed at this very S: one pass saved
+                const double currentChi0 = it == 0 ? sim3_errors(P, sS, s_act, delta, sSi, sh) : s_cur;
                 // the 14 perturbed similarities of g2o's numeric differentiation and their inverses
                 if (tid < 14) {
                     double Sp[8], add[7] = {0, 0, 0, 0, 0, 0, 0};
