@@ -219,7 +219,7 @@ def synth_pose(n=400, outlier_frac=0.15, seed=7, perturb=0.02):
             "inv_sigma2": f32(inv_sig), "truth_pose": np.concatenate([R.reshape(-1), t]), "truth_outlier": bad}
 
 
-def synth_search(n_kp=1500, m=600, seed=0, width=640, height=480, th=3.0, crowd=False):
+def synth_search(n_kp=1500, m=600, seed=0, width=640, height=480, th=3.0, crowd=False, retarget=True):
     """A guided-search problem in the shape Tracking::SearchLocalPoints hands to
     ORBmatcher::SearchByProjection: a frame's undistorted keypoints + grid constants, and map-point
     queries projected near some of them (several queries may aim at the same keypoint, which is what
@@ -239,7 +239,8 @@ def synth_search(n_kp=1500, m=600, seed=0, width=640, height=480, th=3.0, crowd=
     taken = (rs.rand(n_kp) < 0.15).astype(np.uint8)
     scale = np.float32(1.2) ** np.arange(8, dtype=np.float32)
     tgt = rs.randint(0, max(n_kp, 1), m) if n_kp else np.zeros(m, np.int64)
-    tgt[m // 2:] = tgt[:m - m // 2][rs.permutation(m - m // 2)]        # second half re-targets the first half
+    if retarget:
+        tgt[m // 2:] = tgt[:m - m // 2][rs.permutation(m - m // 2)]    # second half re-targets the first half (worst case for the ordered walk)
     uvr = np.zeros((m, 3), np.float32)
     lmin, lmax = np.zeros(m, np.int32), np.zeros(m, np.int32)
     qdesc = np.zeros((m, 32), np.uint8)
