@@ -379,19 +379,15 @@ extern "C" int slamit_diag_fast(unsigned long long* out, int reset) {
 #define FD_FLUSH(npx)
 #endif
 
+// The work of one wavefront on one cell.  `fsm` is the workgroup's dynamic LDS; the wave's slice is carved inside.
 template <int PITCH>
-__global__ __launch_bounds__(256) void fast_cells_kernel(
-    const FastTab tab, const uint4* __restrict__ cells, int nlevels, int ncells,
+__device__ __forceinline__ void fast_cell_wave(
+    uint8_t* fsm, const int lane, const int wv, const int frame, const int cell,
+    const FastTab& tab, const uint4* __restrict__ cells, int nlevels,
     const uint8_t* __restrict__ img0, unsigned img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr,
     unsigned long long* __restrict__ cand, size_t cand_frame_stride,
     int* __restrict__ cand_count, int iniTh, int minTh, int tile_rows, int sc_rows, int kp_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int frame = blockIdx.y;
-    const int cell = blockIdx.x * 4 + wv;
-    if (cell >= ncells) return;
     FD_DECL;
     // per-wave LDS carve: image tile | score tile | survivor list | keypoint list
     const int tile_bytes = (tile_rows * PITCH + 16 + 15) & ~15, sc_bytes = sc_rows * PITCH;
@@ -598,6 +594,43 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     }
     FD_STAMP(4);
     FD_FLUSH(sw * sh);
+}
+
+template <int PITCH>
+__global__ __launch_bounds__(256) void fast_cells_kernel(
+    const FastTab tab, const uint4* __restrict__ cells, int nlevels, int ncells,
+    const uint8_t* __restrict__ img0, unsigned img0_stride, size_t img0_frame,
+    const uint8_t* __restrict__ pyr,
+    unsigned long long* __restrict__ cand, size_t cand_frame_stride,
+    int* __restrict__ cand_count, int iniTh, int minTh, int tile_rows, int sc_rows, int kp_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cell = blockIdx.x * 4 + wv;
+    if (cell >= ncells) return;
+    fast_cell_wave<PITCH>(fsm, lane, wv, blockIdx.y, cell, tab, cells, nlevels, img0, img0_stride, img0_frame, pyr, cand,
+                          cand_frame_stride, cand_count, iniTh, minTh, tile_rows, sc_rows, kp_cap);
+}
+
+// The minThFAST retry of the cells the strip kernel (orb_fast_strip.hip) left without a corner: a fixed grid of waves
+// walks the list of (frame << 20 | cell) entries; every listed cell is processed at the single threshold `th`.
+template <int PITCH>
+__global__ __launch_bounds__(256) void fast_cells_listed_kernel(
+    const FastTab tab, const uint4* __restrict__ cells, int nlevels, const uint32_t* __restrict__ list, const int* __restrict__ list_count,
+    const uint8_t* __restrict__ img0, unsigned img0_stride, size_t img0_frame,
+    const uint8_t* __restrict__ pyr,
+    unsigned long long* __restrict__ cand, size_t cand_frame_stride,
+    int* __restrict__ cand_count, int th, int tile_rows, int sc_rows, int kp_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = *list_count, nwaves = gridDim.x * 4;
+    for (int i = blockIdx.x * 4 + wv; i < n; i += nwaves) {
+        const uint32_t e = list[i];
+        fast_cell_wave<PITCH>(fsm, lane, wv, (int)(e >> 20), (int)(e & 0xFFFFFu), tab, cells, nlevels, img0, img0_stride, img0_frame, pyr,
+                              cand, cand_frame_stride, cand_count, th, th, tile_rows, sc_rows, kp_cap);
+        wave_sync_lds();   // the next cell reuses this wave's LDS slice
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -937,7 +970,7 @@ __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
     int* __restrict__ cand_count,
     uint32_t* __restrict__ ws_xy, uint16_t* __restrict__ ws_node,
     OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, int* __restrict__ kp_count,
-    int node_cap, int key_cap, int level_override /* -1: blockIdx.x */) {
+    int node_cap, int key_cap, int level_override /* -1: blockIdx.x */, int* __restrict__ fb_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // node arrays | k_xy[key_cap] | k_nd[key_cap]
     __shared__ int wave_tmp[OCT_THREADS / 64];
     __shared__ int s_vars[4];
@@ -953,6 +986,8 @@ __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
     // per call) and keep the count in the line's second word for slamit_orb_debug_candidates
     __syncthreads();
     if (threadIdx.x == 0) { cand_count[kidx * ORB_CC_PAD] = 0; cand_count[kidx * ORB_CC_PAD + 1] = n_raw; }
+    // likewise the length of the FAST pass's list of cells for the minThFAST retry (its reader has finished)
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && fb_count) { fb_count[1] = fb_count[0]; fb_count[0] = 0; }
     const unsigned long long* K = cand + L.cand_off + (size_t)frame * cand_frame_stride;
     OrbLevelKp* OUT = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
     if (n_keys == 0) {
@@ -1373,9 +1408,15 @@ size_t orbk_fast_smem(int max_wcell, int max_hcell) {
 
 hipError_t orbk_fast_prepare(int max_wcell, int max_hcell) {
     const int smem = (int)orbk_fast_smem(max_wcell, max_hcell);
-    if (fast_pitch(max_wcell) == 48)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<72>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e;
+    if (fast_pitch(max_wcell) == 48) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_listed_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<72>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_listed_kernel<72>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    return e;
 }
 
 // Cell table: the non-empty FAST cells of every level in the reference's visiting order (level, row, column;
@@ -1431,6 +1472,29 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
                            sc_rows, kp_cap);
 }
 
+void orbk_fast_listed(hipStream_t st, const OrbLevel* host_levels, int nlevels, const uint32_t* d_cells, const uint32_t* d_list,
+                      const int* d_list_count, const uint8_t* img0, size_t img0_stride, size_t img0_frame, const uint8_t* pyr,
+                      unsigned long long* cand, size_t cand_frame_stride, int* cand_count, int th, int max_wcell, int max_hcell) {
+    const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
+    const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
+    const size_t smem = orbk_fast_smem(max_wcell, max_hcell);
+    FastTab tab = {};
+    for (int l = 0; l < nlevels && l < ORB_MAX_LEVELS; ++l) {
+        const OrbLevel& S = host_levels[l];
+        FastLevel& D = tab.lv[l];
+        D.cell_base = S.cell_base; D.nCols = S.nCols; D.wCell = S.wCell; D.hCell = S.hCell;
+        D.maxBorderX = S.maxBorderX; D.maxBorderY = S.maxBorderY; D.stride = S.stride; D.cand_cap = S.cand_cap;
+        D.plane_off = S.plane_off; D.plane_bytes = S.plane_bytes; D.cand_off = S.cand_off;
+    }
+    const dim3 grid(512);   // 2048 waves walk the list
+    if (fast_pitch(max_wcell) == 48)
+        hipLaunchKernelGGL(fast_cells_listed_kernel<48>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, d_list,
+                           d_list_count, img0, (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, th, tile_rows, sc_rows, kp_cap);
+    else
+        hipLaunchKernelGGL(fast_cells_listed_kernel<72>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, d_list,
+                           d_list_count, img0, (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, th, tile_rows, sc_rows, kp_cap);
+}
+
 // candidates kept in LDS: as many as fit beside the node arrays in half a CU's LDS (lists above that use the HBM workspace)
 int orbk_octree_key_cap(int node_cap) {
     const long room = (long)OCT_LDS_BUDGET - (long)orbk_octree_node_bytes(node_cap);
@@ -1446,11 +1510,11 @@ hipError_t orbk_octree_prepare(int node_cap) {
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
                  size_t cand_frame_stride, int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
                  OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int nframes,
-                 int level_override) {
+                 int level_override, int* fb_count) {
     dim3 grid(level_override >= 0 ? 1 : nlevels, nframes);
     hipLaunchKernelGGL(octree_kernel, grid, dim3(OCT_THREADS), orbk_octree_smem(node_cap), st, levels, nlevels, cand,
                        cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
-                       orbk_octree_key_cap(node_cap), level_override);
+                       orbk_octree_key_cap(node_cap), level_override, fb_count);
 }
 
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0,
