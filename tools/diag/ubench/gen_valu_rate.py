@@ -127,9 +127,17 @@ int main() {{
     printf("%-22s %8s %8s %8s %8s   (cycles per wave-instruction per SIMD; 1/2/4/8 waves per SIMD)\\n", "op", "w1", "w2", "w4", "w8");
     for (size_t k = 0; k < sizeof(KS) / sizeof(KS[0]); ++k) {{
         printf("%-22s", NAMES[k]);
+        double wall4 = 0;
         for (int w = 1; w <= 8; w *= 2) {{
             const int blocks = 256 * w;   // 256-thread blocks: one wave per SIMD each
             hipLaunchKernelGGL(KS[k], dim3(blocks), dim3(256), 0, 0, d, 8);   // warm
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(KS[k], dim3(blocks), dim3(256), 0, 0, d, ITER * 8);
+            hipEventRecord(e1, 0);
+            CK(hipDeviceSynchronize());
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            if (w == 4) wall4 = (double)ms * 1e6 / ((double)ITER * 8 * NCH * NINST[k] * w);   // ns per wave-instruction per SIMD
             hipLaunchKernelGGL(KS[k], dim3(blocks), dim3(256), 0, 0, d, ITER);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(h.data(), d, 8 * 4 * blocks, hipMemcpyDeviceToHost));
@@ -138,7 +146,7 @@ int main() {{
             // every wave issues ITER * NCH * NINST instructions in `med` cycles beside w - 1 others on its SIMD
             printf(" %8.2f", med / ((double)ITER * NCH * NINST[k] * w));
         }}
-        printf("\\n");
+        printf("   wall@w4 %.3f ns/instr/SIMD\\n", wall4);
         fflush(stdout);
     }}
     return 0;

@@ -302,10 +302,11 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         h->fast_cells = empty ? 0 : orbk_fast_cells(h->levels.data(), nl, cells);
         ALLOC(h->d_cells, sizeof(uint32_t) * std::max<size_t>(cells.size(), 8));
         if (e == hipSuccess && !cells.empty()) e = hipMemcpy(h->d_cells, cells.data(), sizeof(uint32_t) * cells.size(), hipMemcpyHostToDevice);
-        // strip FAST: SLAMIT_FAST_CELLS=1 keeps the per-cell kernel for every cell (A/B runs, diagnostics)
+        // strip FAST (orb_fast_strip.hip) is opt-in, SLAMIT_FAST_STRIP=1: bit-identical, but it issues more instructions
+        // than the per-cell kernel (measured) and is kept for A/B runs only
         std::vector<uint32_t> jobs;
         h->fast_jobs = 0;
-        if (!empty && !getenv("SLAMIT_FAST_CELLS") && orbk_fast_strip_supported(h->levels.data(), nl) && h->fast_cells < (1 << 20) && p->max_batch < 4096)
+        if (!empty && getenv("SLAMIT_FAST_STRIP") && orbk_fast_strip_supported(h->levels.data(), nl) && h->fast_cells < (1 << 20) && p->max_batch < 4096)
             h->fast_jobs = std::max(orbk_fast_strip_jobs(h->levels.data(), nl, jobs), 0);
         ALLOC(h->d_jobs, sizeof(uint32_t) * std::max<size_t>(jobs.size(), 8));
         if (e == hipSuccess && h->fast_jobs > 0) e = hipMemcpy(h->d_jobs, jobs.data(), sizeof(uint32_t) * jobs.size(), hipMemcpyHostToDevice);

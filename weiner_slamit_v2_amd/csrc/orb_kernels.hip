@@ -359,7 +359,29 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
 }
 
-#define FAST_LIST_CAP 448   // flushed to the scoring step whenever fewer than 256 slots are free
+#define FAST_LIST_CAP 640   // two stacks of pre-test survivors (brighter / darker), each < 64 left over + <= 256 of a step
+
+// gfx950's three-input packed f16 min / max: two pixels per lane; the lanes hold the integers 0 .. 255 (f16 denormals) and their negatives
+__device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_min3_neghi_f16(uint32_t a, uint32_t b, uint32_t c) {   // high halves enter negated
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3 neg_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max_f16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 #ifdef FAST_DIAG   // diagnostic builds only (tools/diag): per-phase wave cycles, one record per wave
 #define FD_MAXW 65536
@@ -394,8 +416,9 @@ __device__ __forceinline__ void fast_cell_wave(
     const int per_wave = (tile_bytes + sc_bytes + 2 * FAST_LIST_CAP + 2 * kp_cap + 15) & ~15;
     uint8_t* tile = fsm + wv * per_wave;
     uint8_t* sc = tile + tile_bytes;
-    unsigned short* s_list = reinterpret_cast<unsigned short*>(sc + sc_bytes);
-    unsigned short* s_kp = s_list + FAST_LIST_CAP;
+    unsigned short* s_listB = reinterpret_cast<unsigned short*>(sc + sc_bytes);
+    unsigned short* s_listD = s_listB + FAST_LIST_CAP / 2;
+    unsigned short* s_kp = s_listB + FAST_LIST_CAP;
 
     // the cell's geometry and every division it needs, precomputed on the host (orbk_fast_cells): two scalar
     // 16-byte loads instead of ~400 instructions of level search and integer division per wave
@@ -404,7 +427,7 @@ __device__ __forceinline__ void fast_cell_wave(
     const int iniX = (int)(ca.y & 0xFFFFu), iniY = (int)(ca.y >> 16);
     const int cw = (int)(ca.z & 255u), ch = (int)((ca.z >> 8) & 255u);
     const int nd = (int)((ca.z >> 16) & 255u), rows_per_it = (int)(ca.z >> 24);
-    const unsigned inv_nd = ca.w, inv_g = cb.x, inv_sw = cb.y, inv_cw = cb.z;
+    const unsigned inv_nd = ca.w, inv_g = cb.x, inv_cw = cb.z;   // (cb.y: magic of sw, unused since entries are y << 6 | x)
     const FastLevel& L = tab.lv[level];
     const int sw = cw - 6, sh = ch - 6;  // scan area = FAST's [3, n-3)
 
@@ -469,9 +492,10 @@ __device__ __forceinline__ void fast_cell_wave(
     // minThFAST (ORBextractor.cc:827-833).  Per attempt:
     //  A. compass pre-test, 4 pixels per lane with byte-parallel arithmetic (necessary condition: a
     //     9-arc of the 16-ring always holds two adjacent compass pixels, so two adjacent ones must
-    //     both be brighter than v+t or both darker than v-t); survivors are compacted into a list,
-    //  B. the exact score of every survivor, all lanes busy; stored if >= t,
-    //  C. NMS (strict >, 8 neighbours, zeros outside the scan area / below t) over the score tile.
+    //     both be brighter than v+t or both darker than v-t); survivors are compacted into a ring list,
+    //     with the polarity that passed (a pixel that passed both is listed twice),
+    //  B. the exact score of the listed pixels, 128 per pass and TWO per lane on packed 16-bit lanes; stored if >= t,
+    //  C. NMS (strict >, 8 neighbours, zeros outside the scan area / below t) byte-parallel over the score tile.
     int th = iniTh;
     int nkp = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -479,97 +503,136 @@ __device__ __forceinline__ void fast_cell_wave(
         // (a + ~c + r) >> 1 per byte with a 9-bit intermediate; with r = parity of t the test becomes
         // d >= K on bytes, and a second lerp against 256 - K leaves the answer in each byte's MSB.
         const int T = th + 256;
-        const unsigned rb = (T & 1) ? 0x01010101u : 0u;
+        const unsigned rnd = (T & 1) ? 0x01010101u : 0u;
         const int Kv = (T + 1) >> 1;                       // 129..256
         const unsigned kc = (unsigned)(256 - Kv) * 0x01010101u;
-        int nlist = 0;
-        for (int i0 = 0; i0 < nitems || nlist > 0; i0 += WAVE) {
-            if (i0 < nitems) {
-                const int it = i0 + lane;
-                unsigned flags = 0;
-                int y = 0, x0 = 0;
-                if (it < nitems) {
-                    y = (int)(__umul24(it, inv_g) >> 20);
-                    x0 = (it - y * ngrp) * 4;
-                    const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(y + 3) * PITCH + x0 + SC_COL0]);
-                    const unsigned C = rowc[0], Dm = rowc[-1], Dp = rowc[1];
-                    const unsigned N = *reinterpret_cast<const uint32_t*>(&tile[y * PITCH + x0 + SC_COL0]);
-                    const unsigned S = *reinterpret_cast<const uint32_t*>(&tile[(y + 6) * PITCH + x0 + SC_COL0]);
-                    const unsigned E = __builtin_amdgcn_alignbyte(Dp, C, 3);   // columns x0+3 .. x0+6
-                    const unsigned Wv = __builtin_amdgcn_alignbyte(C, Dm, 1);  // columns x0-3 .. x0
-                    const unsigned nC = ~C;
-#define BRIGHT(a) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp((a), nC, rb), kc, 0u)
-#define DARK(a) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~(a), rb), kc, 0u)
-                    const unsigned bN = BRIGHT(N), bE = BRIGHT(E), bS = BRIGHT(S), bW = BRIGHT(Wv);
-                    const unsigned dN = DARK(N), dE = DARK(E), dS = DARK(S), dW = DARK(Wv);
+        int nB = 0, nD = 0;   // survivor stacks: brighter-than-centre / darker-than-centre candidates, entry = y << 6 | x
+        for (int i0 = 0; i0 < nitems; i0 += WAVE) {
+            const int it = i0 + lane;
+            unsigned pb = 0, pd = 0;
+            unsigned e0 = 0;
+            if (it < nitems) {
+                const int y = (int)(__umul24(it, inv_g) >> 20);
+                const int x0 = (it - y * ngrp) * 4;
+                e0 = (unsigned)((y << 6) | x0);
+                const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(y + 3) * PITCH + x0 + SC_COL0]);
+                const unsigned C = rowc[0], Dm = rowc[-1], Dp = rowc[1];
+                const unsigned N = *reinterpret_cast<const uint32_t*>(&tile[y * PITCH + x0 + SC_COL0]);
+                const unsigned S = *reinterpret_cast<const uint32_t*>(&tile[(y + 6) * PITCH + x0 + SC_COL0]);
+                const unsigned E = __builtin_amdgcn_alignbyte(Dp, C, 3);   // columns x0+3 .. x0+6
+                const unsigned Wv = __builtin_amdgcn_alignbyte(C, Dm, 1);  // columns x0-3 .. x0
+                const unsigned nC = ~C;
+#define BRIGHT(a) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp((a), nC, rnd), kc, 0u)
+#define DARK(a) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~(a), rnd), kc, 0u)
+                const unsigned bN = BRIGHT(N), bE = BRIGHT(E), bS = BRIGHT(S), bW = BRIGHT(Wv);
+                const unsigned dN = DARK(N), dE = DARK(E), dS = DARK(S), dW = DARK(Wv);
 #undef BRIGHT
 #undef DARK
-                    // two adjacent compass points of one polarity: NE | ES | SW | WN == (N | S) & (E | W)
-                    flags = (((bN | bS) & (bE | bW)) | ((dN | dS) & (dE | dW))) & 0x80808080u;
-                    const int over = x0 + 4 - sw;            // pixels of this group beyond the scan row (0..3)
-                    if (over > 0) flags &= 0x80808080u >> (8 * over);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int pass = (flags >> (8 * j + 7)) & 1u;
-                    const unsigned long long m = __ballot(pass);
-                    if (pass) s_list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(y * sw + x0 + j);
-                    nlist += __popcll(m);
-                }
+                // two adjacent compass points of one polarity: NE | ES | SW | WN == (N | S) & (E | W); v_bitop3 is full rate
+                unsigned vmask = 0x80808080u;
+                const int over = x0 + 4 - sw;            // pixels of this group beyond the scan row (0..3)
+                if (over > 0) vmask >>= 8 * over;
+                pb = __builtin_amdgcn_bitop3_b32(bN | bS, bE, bW, 0xE0) & vmask;
+                pd = __builtin_amdgcn_bitop3_b32(dN | dS, dE, dW, 0xE0) & vmask;
             }
-            // score the listed pixels once the list could overflow, and at the end
-            if (nlist > FAST_LIST_CAP - 256 || i0 + WAVE >= nitems) {
+            // compaction: one ballot per pixel slot and polarity; a pixel that passed both tests is on both stacks
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool pass = (pb & (0x80u << (8 * j))) != 0u;
+                const unsigned long long mk = __ballot(pass);
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)nB));
+                if (pass) s_listB[pos] = (unsigned short)(e0 + j);
+                nB += __popcll(mk);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool pass = (pd & (0x80u << (8 * j))) != 0u;
+                const unsigned long long mk = __ballot(pass);
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)nD));
+                if (pass) s_listD[pos] = (unsigned short)(e0 + j);
+                nD += __popcll(mk);
+            }
+            // scoring: 64 + 64 candidates per pass off the tops of the stacks, whenever one of them holds 64 (after the
+            // last step: until both are empty).  TWO pixels per lane on packed 16-bit lanes: the low half holds the ring of
+            // a "brighter" candidate, the high half that of a "darker" one, whose values enter the first stage NEGATED
+            // (neg_hi): min / max then compute  max over the 16 arcs of (min over the arc's 9 pixels)  in the low half and
+            // -(min over arcs of max over arc)  in the high half.  The lanes hold the integers 0 .. 255 as f16 bit
+            // patterns (denormals, kept by the default FP mode) and are only compared.
+            const bool last = i0 + WAVE >= nitems;
+            while (nB >= 64 || nD >= 64 || (last && (nB | nD) != 0)) {
                 wave_sync_lds();
                 FD_STAMP(1);
+                const int tb = min(nB, 64), td = min(nD, 64);
 #ifdef FAST_DIAG
-                fd_surv += nlist;
+                fd_surv += tb + td;
 #endif
-                for (int i = lane; i < nlist; i += WAVE) {
-                    const int p = s_list[i];
-                    const int y = (int)(__umul24(p, inv_sw) >> 20);
-                    const int x = p - y * sw;
-                    const int S = fast_score<PITCH>(&tile[(y + 3) * PITCH + x + SC_COL0]);
-                    sc[(y + 1) * PITCH + x + SC_COL0] = (uint8_t)(S >= th ? S : 0);
-                }
+                const bool vlo = lane < tb, vhi = lane < td;
+                // lanes without an entry score pixel (0, 0) and do not store
+                const unsigned elo = vlo ? s_listB[nB - tb + lane] : 0u;
+                const unsigned ehi = vhi ? s_listD[nD - td + lane] : 0u;
+                const unsigned ylo = elo >> 6, xlo = elo & 63u, yhi = ehi >> 6, xhi = ehi & 63u;
+                // top-left corner of the 7x7 neighbourhood of scan pixel (x, y): tile row y, column x + SC_COL0 - 3
+                const uint8_t* qlo = tile + (__umul24(ylo, PITCH) + xlo + (SC_COL0 - 3));
+                const uint8_t* qhi = tile + (__umul24(yhi, PITCH) + xhi + (SC_COL0 - 3));
+#define PX(dx, dy) (((uint32_t)qhi[((dy) + 3) * PITCH + (dx) + 3] << 16) | (uint32_t)qlo[((dy) + 3) * PITCH + (dx) + 3])
+                uint32_t r[16];
+                r[0] = PX(0, 3);    r[1] = PX(1, 3);    r[2] = PX(2, 2);    r[3] = PX(3, 1);
+                r[4] = PX(3, 0);    r[5] = PX(3, -1);   r[6] = PX(2, -2);   r[7] = PX(1, -3);
+                r[8] = PX(0, -3);   r[9] = PX(-1, -3);  r[10] = PX(-2, -2); r[11] = PX(-3, -1);
+                r[12] = PX(-3, 0);  r[13] = PX(-3, 1);  r[14] = PX(-2, 2);  r[15] = PX(-1, 3);
+                const uint32_t ctr = PX(0, 0);
+#undef PX
+                uint32_t lo3[16], l9[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lo3[k] = pk_min3_neghi_f16(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) l9[k] = pk_min3_f16(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+                const uint32_t m = pk_max_f16(
+                    pk_max3_f16(pk_max3_f16(l9[0], l9[1], l9[2]), pk_max3_f16(l9[3], l9[4], l9[5]), pk_max3_f16(l9[6], l9[7], l9[8])),
+                    pk_max3_f16(pk_max3_f16(l9[9], l9[10], l9[11]), pk_max3_f16(l9[12], l9[13], l9[14]), l9[15]));
+                // brighter: (best arc minimum) - centre - 1; darker: centre - (best arc maximum) - 1; < t means "no corner at t"
+                const int slo = (int)(m & 255u) - (int)(ctr & 255u) - 1;
+                const int shi = (int)(ctr >> 16) - (int)((m >> 16) & 255u) - 1;
+                if (vlo && slo >= th) sc[__umul24(ylo + 1u, PITCH) + xlo + SC_COL0] = (uint8_t)slo;
+                if (vhi && shi >= th) sc[__umul24(yhi + 1u, PITCH) + xhi + SC_COL0] = (uint8_t)shi;
+                nB -= tb; nD -= td;
                 wave_sync_lds();
-                nlist = 0;
                 FD_STAMP(2);
             }
         }
-        // NMS straight off the score tile, 4 pixels per lane, zero dwords skipped
+        // NMS byte-parallel over the score tile, 4 pixels per lane: n >= s per byte  <=>  MSB of (n + ~s + 1) >> 1.
+        // A pixel below t holds 0 and is beaten by any neighbour; columns / rows around the scan area hold 0.
         nkp = 0;
         for (int i0 = 0; i0 < nitems; i0 += WAVE) {
             const int it = i0 + lane;
-            unsigned keep = 0;
-            int y = 0, x0 = 0;
+            unsigned keep = 0, e0 = 0;
             if (it < nitems) {
-                y = (int)(__umul24(it, inv_g) >> 20);
-                x0 = (it - y * ngrp) * 4;
-                const uint8_t* s = &sc[(y + 1) * PITCH + x0 + SC_COL0];
-                const unsigned cur = *reinterpret_cast<const uint32_t*>(s);
-                if (cur) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int v = (cur >> (8 * j)) & 0xFF;
-                        if (v) {
-                            const uint8_t* q = s + j;
-                            int nb = imax3(q[-PITCH - 1], q[-PITCH], q[-PITCH + 1]);
-                            nb = imax3(nb, q[-1], q[1]);
-                            nb = max(nb, imax3(q[PITCH - 1], q[PITCH], q[PITCH + 1]));
-                            if (v > nb) keep |= 1u << j;
-                        }
-                    }
-                }
+                const int y = (int)(__umul24(it, inv_g) >> 20);
+                const int x0 = (it - y * ngrp) * 4;
+                e0 = (unsigned)((y << 6) | x0);
+                const uint32_t* s1 = reinterpret_cast<const uint32_t*>(&sc[(y + 1) * PITCH + x0 + SC_COL0]);
+                const uint32_t* s0 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s1) - PITCH);
+                const uint32_t* s2 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s1) + PITCH);
+                const uint32_t cur = s1[0];
+                const uint32_t ns = ~cur, one = 0x01010101u;
+                const uint32_t uc = s0[0], dc = s2[0];
+                const uint32_t ul = __builtin_amdgcn_alignbyte(uc, s0[-1], 3), ur = __builtin_amdgcn_alignbyte(s0[1], uc, 1);
+                const uint32_t cl = __builtin_amdgcn_alignbyte(cur, s1[-1], 3), cr = __builtin_amdgcn_alignbyte(s1[1], cur, 1);
+                const uint32_t dl = __builtin_amdgcn_alignbyte(dc, s2[-1], 3), dr = __builtin_amdgcn_alignbyte(s2[1], dc, 1);
+                const uint32_t g1 = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_lerp(ul, ns, one), __builtin_amdgcn_lerp(uc, ns, one), __builtin_amdgcn_lerp(ur, ns, one), 0xFE);
+                const uint32_t g2 = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_lerp(dl, ns, one), __builtin_amdgcn_lerp(dc, ns, one), __builtin_amdgcn_lerp(dr, ns, one), 0xFE);
+                const uint32_t g3 = __builtin_amdgcn_lerp(cl, ns, one) | __builtin_amdgcn_lerp(cr, ns, one);
+                keep = ~(g1 | g2 | g3) & 0x80808080u;     // pixels beyond the scan row hold 0 and are never kept
             }
             // two strict maxima are never adjacent, so a group of 4 keeps at most 2 pixels: two ballots compact them
             const int cnt = __popc(keep);
-            const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2);
+            const unsigned long long b1 = __ballot(cnt >= 1);
             if (b1) {
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                const int pos = nkp + __popcll(b1 & lt) + __popcll(b2 & lt);
-                const int p0 = y * sw + x0;
-                if (cnt >= 1) s_kp[pos] = (unsigned short)(p0 + __ffs(keep) - 1);
-                if (cnt >= 2) s_kp[pos + 1] = (unsigned short)(p0 + 31 - __clz(keep));
+                const unsigned long long b2 = __ballot(cnt >= 2);
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, (unsigned)nkp)) +
+                                     __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u));
+                if (cnt >= 1) s_kp[pos] = (unsigned short)(e0 + ((__ffs(keep) - 1) >> 3));
+                if (cnt >= 2) s_kp[pos + 1] = (unsigned short)(e0 + ((31 - __clz(keep)) >> 3));
                 nkp += __popcll(b1) + __popcll(b2);
             }
         }
@@ -585,8 +648,7 @@ __device__ __forceinline__ void fast_cell_wave(
     unsigned long long* out = cand + L.cand_off + (size_t)frame * cand_frame_stride;
     for (int i = lane; i < nkp; i += WAVE) {
         const int p = s_kp[i];
-        const int y = (int)(__umul24(p, inv_sw) >> 20);
-        const int x = p - y * sw;
+        const int y = p >> 6, x = p & 63;
         const unsigned S = sc[(y + 1) * PITCH + x + SC_COL0];
         const unsigned order = ((unsigned)c << 12) | ((unsigned)(y + 3) << 6) | (unsigned)(x + 3);
         const int o = base + i;
