@@ -120,6 +120,11 @@ int slamit_orb_level(slamit_orb* h, int frame, int level, uint8_t* dst, size_t d
  *  in the reference's (cell row, cell col, y, x) order. */
 int slamit_orb_debug_candidates(slamit_orb* h, int frame, int level, int32_t* xys, int cap,
                                 int* n_out);
+/*  the blurred level the descriptors were sampled from: GaussianBlur(mvImagePyramid[level].clone(), 7x7, sigma 2,
+ *  BORDER_REFLECT_101) of src/ORBextractor.cc:1116-1117, *h_out rows of *w bytes (no border). dst may be NULL
+ *  to query the size. */
+int slamit_orb_debug_blurred(slamit_orb* h, int frame, int level, uint8_t* dst, size_t dst_bytes, int* w,
+                             int* h_out);
 
 /* ---- Hamming matcher -------------------------------------------------------------------- */
 

@@ -67,3 +67,31 @@ def sim3_close(got, ref, tol=1e-5, strict_its=True):
     assert abs(got["s12"] - ref["s12"]) <= tol * abs(ref["s12"])
     for a, b in zip(got["chi2"], ref["chi2"]):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b))
+
+
+ORB_GOLDEN = ("vga", "vga2000", "720p")
+
+
+def crc32(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def load_orb_golden(name):
+    """tests/golden/orb_<name>.npz (tools/gen_orb_golden.py): the restatement's outputs on a synthetic frame, a
+    NON-AUTHORITATIVE regression guard (the ORB half is parity-unpinned: no OpenCV 2.4.9, no reference fixtures).
+    Returns (golden dict, frame); fails loudly when the synthesized frame is not the one the vectors were made from."""
+    from weiner_slamit_v2_amd import synth
+    z = dict(np.load(os.path.join(ROOT, "tests", "golden", "orb_%s.npz" % name)))
+    w, h, nf, idx = (int(v) for v in z["params"][:4])
+    img = synth.synth_frame(w, h, idx)
+    assert crc32(img) == int(z["img_crc"]), "synth_frame(%d, %d, %d) changed: regenerate with tools/gen_orb_golden.py" % (w, h, idx)
+    return z, img
+
+
+def assert_matches_orb_golden(z, kps, desc, tag=""):
+    assert len(kps) == len(z["desc"]), "%s keypoint count %d vs golden %d" % (tag, len(kps), len(z["desc"]))
+    for f in ("x", "y", "size", "response", "octave"):
+        assert np.array_equal(kps[f], z["kp_" + f]), "%s field %s differs from the golden vector" % (tag, f)
+    assert np.array_equal(kps["angle"].view(np.uint32), z["angle_bits"]), "%s angle bits differ from the golden vector" % tag
+    assert np.array_equal(desc, z["desc"]), "%s descriptors differ from the golden vector" % tag

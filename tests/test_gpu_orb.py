@@ -26,6 +26,7 @@ def _check_frame(ext, orc, img, tag, stages=True):
     if stages:
         for l in range(orc.nlevels):
             assert np.array_equal(ext.level(0, l), orc.level(l)), "%s pyramid level %d differs" % (tag, l)
+            assert np.array_equal(ext.blurred(0, l), orc.blurred(l)), "%s blurred level %d differs" % (tag, l)
             cg, co = ext.debug_candidates(0, l), orc.candidates(l)
             assert np.array_equal(cg, co), "%s FAST candidates level %d differ (%d vs %d)" % (tag, l, len(cg), len(co))
     _assert_same(kg, dg, ko, do, tag)
@@ -282,12 +283,21 @@ def test_guided_search_kat_and_limits():
     big = synth.synth_search(8192, 4, 9)
     with pytest.raises(api.SlamitError):
         api.ORBmatcher.guided_search(big[0], big[1])
-    # every keypoint in one window: more candidates than SLAMIT_SEARCH_MAX_CAND -> loud capacity error
+    # Every keypoint in every window: 1500 candidates, more than the SLAMIT_SEARCH_MAX_CAND (1024) entries a query's stored
+    # list holds.  The (best, second) pair is reduced over ALL hits, so the result is exact -- and must equal the oracle,
+    # which like the reference has no such limit -- unless an earlier query of the call took one of the two and the
+    # truncated list has to be re-scanned: only then the call fails, loudly.
     f, qq = synth.synth_search(1500, 4, 10, crowd=True)
     qq["uvr"][:, 2] = 500.0
     qq["level_min"][:] = 0
     qq["level_max"][:] = -1
     qq["valid"][:] = 1
+    qq["takes"][:] = 1
+    free = np.flatnonzero(f["kp_taken"] == 0)[:4]
+    qq["desc"][:] = f["desc"][free]                       # four different keypoints, each query an exact copy of "its" one
+    gm, gn = _search_same(f, qq, 100, False)
+    assert gm.tolist()[1:] == free.tolist()[1:] and gn >= 3   # (query 0's window lies outside the grid by construction)
+    qq["desc"][2] = qq["desc"][1]                         # the third query now wants the keypoint the second one just took
     with pytest.raises(api.SlamitError):
         api.ORBmatcher.guided_search(f, qq)
 
@@ -379,3 +389,54 @@ def test_search_for_initialization_mode(n, seed, window):
     gm, gn, gacc = api.ORBmatcher.search_for_initialization(f1, prev, f2, window, 0.9, 50)
     om, on, oacc = ob.search_for_initialization(f1, prev, f2, window, 0.9, 50)
     assert np.array_equal(gm, om) and gn == on and np.array_equal(gacc, oacc)
+
+
+@pytest.mark.parametrize("name", ["vga", "vga2000", "720p"])
+def test_hip_reproduces_orb_golden(name):
+    """The HIP path against the committed vectors of tests/golden/orb_*.npz (the restatement's outputs, frozen;
+    non-authoritative regression guards)."""
+    from tests.helpers import assert_matches_orb_golden, crc32, load_orb_golden
+    z, img = load_orb_golden(name)
+    ext = api.ORBextractor(int(z["params"][2]), 1.2, 8, 20, 7)
+    kps, desc = ext(img)
+    assert_matches_orb_golden(z, kps, desc, name)
+    for l in range(8):
+        c = ext.debug_candidates(0, l)
+        assert len(c) == int(z["cand_n"][l]) and crc32(c) == int(z["cand_crc"][l]), "level %d candidates" % l
+        assert crc32(ext.level(0, l)) == int(z["level_crc"][l]), "level %d pyramid plane" % l
+        assert crc32(ext.blurred(0, l)) == int(z["blur_crc"][l]), "level %d blurred plane" % l
+
+
+def test_720p_batch64_and_2000x2000_match():
+    """BASELINE config 3 at its full shape: 64 frames of 1280x720 with the 2000-feature extractor in ONE batch call
+    (Tracking.cc:162 really runs 2000 features), then every frame matched against its predecessor (2000 x 2000
+    best / second).  Every frame of the batch must equal the same frame extracted alone; three distinct frames (first,
+    middle, last slot) and the matches of two pairs must equal the oracle."""
+    B = 64
+    uniq = [synth.synth_frame(1280, 720, 40 + i) for i in range(6)] + [synth.warp_frame(synth.synth_frame(1280, 720, 40), 0)]
+    order = [(i * 5 + 3) % len(uniq) for i in range(B)]
+    order[0], order[1], order[31], order[63] = 0, 6, 3, 5   # (0, 6) is a real frame pair: B = warp(A)
+    frames = np.stack([uniq[k] for k in order])
+    ext = api.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=B)
+    ks, ds = ext.extract_batch(frames)
+    single = api.ORBextractor(2000, 1.2, 8, 20, 7)
+    alone = {}
+    for k in sorted(set(order)):
+        alone[k] = single(uniq[k])
+    for i, k in enumerate(order):
+        _assert_same(ks[i], ds[i], alone[k][0], alone[k][1], "batch slot %d (frame %d)" % (i, k))
+        assert len(ks[i]) >= 2000
+    orc = ob.OrbOracle(2000)
+    oracle_out = {}
+    for slot in (0, 1, 31, 63):
+        ko, do = orc.extract(frames[slot])
+        oracle_out[slot] = do
+        _assert_same(ks[slot], ds[slot], ko, do, "batch slot %d vs oracle" % slot)
+    for q, t in ((1, 0), (63, 31)):   # a warped pair (many accepted matches) and an unrelated pair
+        gi, gb, gs = api.ORBmatcher.best2(ds[q], ds[t])
+        oi, obest, osec = ob.best2(oracle_out[q], oracle_out[t])
+        assert len(gi) >= 2000 and len(ds[t]) >= 2000
+        assert np.array_equal(gi, oi) and np.array_equal(gb, obest) and np.array_equal(gs, osec), "2000x2000 best2 pair (%d, %d)" % (q, t)
+    acc = (gb <= 50) & (gb < 0.9 * gs)
+    gi, gb, gs = api.ORBmatcher.best2(ds[1], ds[0])
+    assert int(((gb <= 50) & (gb < 0.9 * gs)).sum()) > 200, "the warped pair must produce accepted matches"

@@ -647,3 +647,21 @@ def test_bow_oracle_mode1_gates_and_last_wins():
     assert ob.bow_search(s1, s2c, g, mode=1, th=50, epi=epi)[0].tolist() == [1]
     # degenerate line (F = 0): den == 0 -> no match
     assert ob.bow_search(s1, s2, g, mode=1, th=50, epi=dict(epi, F12=np.zeros(9, np.float32)))[2] == 0
+
+
+@pytest.mark.parametrize("name", ["vga", "vga2000", "720p"])
+def test_oracle_reproduces_orb_golden(name):
+    """The restatement still produces the frozen vectors of tests/golden/orb_*.npz (regression guard, non-authoritative:
+    SURVEY 8c; the reference's end-to-end path is ORBextractor.cc:1064-1136)."""
+    from tests.helpers import assert_matches_orb_golden, crc32, load_orb_golden
+    z, img = load_orb_golden(name)
+    nf = int(z["params"][2])
+    orc = ob.OrbOracle(nf, 1.2, 8, 20, 7)
+    kps, desc = orc.extract(img)
+    assert_matches_orb_golden(z, kps, desc, name)
+    for l in range(8):
+        c = orc.candidates(l)
+        assert len(c) == int(z["cand_n"][l]) and crc32(c) == int(z["cand_crc"][l]), "level %d candidates" % l
+        assert crc32(orc.level(l)) == int(z["level_crc"][l]), "level %d pyramid plane" % l
+        assert crc32(orc.blurred(l)) == int(z["blur_crc"][l]), "level %d blurred plane" % l
+        assert int((kps["octave"] == l).sum()) == int(z["level_kps"][l])

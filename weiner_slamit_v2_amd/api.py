@@ -128,7 +128,7 @@ _lib = None
 EXPORTS = [
     "slamit_orb_create", "slamit_orb_destroy", "slamit_orb_tables", "slamit_orb_max_keypoints",
     "slamit_orb_extract", "slamit_orb_extract_batch", "slamit_orb_extract_batch_dev", "slamit_orb_level",
-    "slamit_orb_debug_candidates", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
+    "slamit_orb_debug_candidates", "slamit_orb_debug_blurred", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
     "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_guided_search_workspace", "slamit_guided_search_batch_dev", "slamit_bow_search", "slamit_undistort_points", "slamit_frame_finish",
     "slamit_frame_finish_batch_dev", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
     "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_sim3_optimize", "slamit_sim3_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
@@ -162,6 +162,7 @@ def lib():
         L.slamit_orb_extract_batch.argtypes = [vp, vp, sz, sz, i32, vp, vp, i32, vp]
         L.slamit_orb_extract_batch_dev.argtypes = [vp, vp, sz, sz, i32, vp, vp, i32, vp, vp]
         L.slamit_orb_level.argtypes = [vp, i32, i32, vp, sz, vp, vp]
+        L.slamit_orb_debug_blurred.argtypes = [vp, i32, i32, vp, sz, vp, vp]
         L.slamit_orb_profile.argtypes = [vp, i32, vp, vp, i32]
         L.slamit_orb_debug_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
         L.slamit_hamming_best2.argtypes = [vp, i32, vp, i32, vp, vp, vp]
@@ -325,6 +326,15 @@ class ORBextractor:
         out = np.zeros((h.value + 38, w.value + 38), np.uint8)
         _check(lib().slamit_orb_level(self._h, frame, level, _np_ptr(out), out.size, C.byref(w), C.byref(h)),
                "slamit_orb_level")
+        return out
+
+    def blurred(self, frame, level):
+        """The blurred level (h, w) the descriptors of `frame` of the last call were sampled from."""
+        w, h = C.c_int(), C.c_int()
+        _check(lib().slamit_orb_debug_blurred(self._h, frame, level, None, 0, C.byref(w), C.byref(h)), "slamit_orb_debug_blurred")
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(lib().slamit_orb_debug_blurred(self._h, frame, level, _np_ptr(out), out.size, C.byref(w), C.byref(h)),
+               "slamit_orb_debug_blurred")
         return out
 
     def debug_candidates(self, frame, level):

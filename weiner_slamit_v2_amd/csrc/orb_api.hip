@@ -652,6 +652,22 @@ int slamit_orb_level(slamit_orb* h, int frame, int level, uint8_t* dst, size_t d
     return SLAMIT_OK;
 }
 
+int slamit_orb_debug_blurred(slamit_orb* h, int frame, int level, uint8_t* dst, size_t dst_bytes, int* w, int* h_out) {
+    if (!h || level < 0 || level >= h->nlevels) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_debug_blurred: bad level");
+    if (h->p.width == 0 || h->p.height == 0) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_debug_blurred: empty image");
+    const OrbLevel& L = h->levels[level];
+    if (w) *w = L.w;
+    if (h_out) *h_out = L.h;
+    if (!dst) return SLAMIT_OK;
+    if (frame < 0 || frame >= h->last_nframes) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_debug_blurred: no such frame in the last extract call");
+    if (dst_bytes < (size_t)L.w * L.h) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_debug_blurred: dst too small");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)L.w, h->d_blur + L.blur_off + (size_t)frame * h->blur_frame_total, (size_t)L.stride, (size_t)L.w,
+                             (size_t)L.h, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAMIT_OK;
+}
+
 int slamit_orb_debug_candidates(slamit_orb* h, int frame, int level, int32_t* xys, int cap, int* n_out) {
     if (!h || level < 0 || level >= h->nlevels || !n_out) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_debug_candidates: bad argument");
     if (frame < 0 || frame >= h->last_nframes) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_debug_candidates: no such frame");

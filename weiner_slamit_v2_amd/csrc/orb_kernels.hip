@@ -1458,7 +1458,11 @@ void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const Pyr
                        tabs, img0, img0_stride, img0_frame, pyr, bufA_bytes, l_first, l_last);
 }
 
-static int fast_pitch(int max_wcell) { return max_wcell + 11 <= 48 ? 48 : 72; }  // LDS columns 0 .. sw + 10 are touched
+#ifndef FAST_PS
+#define FAST_PS 48   // tile pitch for cells of <= 37 pixels
+#define FAST_PL 72   // ... up to 59
+#endif
+static int fast_pitch(int max_wcell) { return max_wcell + 11 <= 48 ? FAST_PS : FAST_PL; }  // LDS columns 0 .. sw + 10 are touched
 
 size_t orbk_fast_smem(int max_wcell, int max_hcell) {
     const int P = fast_pitch(max_wcell);
@@ -1471,12 +1475,12 @@ size_t orbk_fast_smem(int max_wcell, int max_hcell) {
 hipError_t orbk_fast_prepare(int max_wcell, int max_hcell) {
     const int smem = (int)orbk_fast_smem(max_wcell, max_hcell);
     hipError_t e;
-    if (fast_pitch(max_wcell) == 48) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_listed_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (fast_pitch(max_wcell) == FAST_PS) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<FAST_PS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_listed_kernel<FAST_PS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<72>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_listed_kernel<72>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<FAST_PL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_listed_kernel<FAST_PL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     }
     return e;
 }
@@ -1524,12 +1528,12 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
         D.maxBorderX = S.maxBorderX; D.maxBorderY = S.maxBorderY; D.stride = S.stride; D.cand_cap = S.cand_cap;
         D.plane_off = S.plane_off; D.plane_bytes = S.plane_bytes; D.cand_off = S.cand_off;
     }
-    if (fast_pitch(max_wcell) == 48)
-        hipLaunchKernelGGL(fast_cells_kernel<48>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
+    if (fast_pitch(max_wcell) == FAST_PS)
+        hipLaunchKernelGGL(fast_cells_kernel<FAST_PS>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
                            (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
                            sc_rows, kp_cap);
     else
-        hipLaunchKernelGGL(fast_cells_kernel<72>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
+        hipLaunchKernelGGL(fast_cells_kernel<FAST_PL>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
                            (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
                            sc_rows, kp_cap);
 }
@@ -1549,11 +1553,11 @@ void orbk_fast_listed(hipStream_t st, const OrbLevel* host_levels, int nlevels, 
         D.plane_off = S.plane_off; D.plane_bytes = S.plane_bytes; D.cand_off = S.cand_off;
     }
     const dim3 grid(512);   // 2048 waves walk the list
-    if (fast_pitch(max_wcell) == 48)
-        hipLaunchKernelGGL(fast_cells_listed_kernel<48>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, d_list,
+    if (fast_pitch(max_wcell) == FAST_PS)
+        hipLaunchKernelGGL(fast_cells_listed_kernel<FAST_PS>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, d_list,
                            d_list_count, img0, (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, th, tile_rows, sc_rows, kp_cap);
     else
-        hipLaunchKernelGGL(fast_cells_listed_kernel<72>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, d_list,
+        hipLaunchKernelGGL(fast_cells_listed_kernel<FAST_PL>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, d_list,
                            d_list_count, img0, (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, th, tile_rows, sc_rows, kp_cap);
 }
 

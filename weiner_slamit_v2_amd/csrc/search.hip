@@ -178,7 +178,6 @@ __global__ __launch_bounds__(64) void search_resolve_kernel(SearchDev D) {
         unsigned long long tb = NONE, ts = NONE;
         int ncq = 0, tkq = 0;
         if (live) { tb = D.tent[2 * (q0 + qj)]; ts = D.tent[2 * (q0 + qj) + 1]; ncq = D.cand_n[q0 + qj]; tkq = D.takes[q0 + qj]; }
-        overflow |= __ballot(ncq > D.cand_cap) != 0ull;
         int res = -1, bd = 256, bl = -1, sd = 256, sl = -1;     // lane j collects query qb + j
         const int jn = min(64, m - qb);
         for (int j = 0; j < jn; ++j) {
@@ -189,7 +188,11 @@ __global__ __launch_bounds__(64) void search_resolve_kernel(SearchDev D) {
                 const bool stale = (((taken[bi0 >> 5] >> (bi0 & 31)) | (taken[si0 >> 5] >> (si0 & 31))) & 1u) != 0;
                 if (stale) {   // an earlier query of this call took one of the two: re-scan this query's candidates
                     const size_t qo = q0 + qb + j;
-                    const int nc = min(__builtin_amdgcn_readlane(ncq, j), D.cand_cap);
+                    const int nc_all = __builtin_amdgcn_readlane(ncq, j), nc = min(nc_all, D.cand_cap);
+                    // The stored list is only read HERE.  The tentative pair was reduced over every hit, so a window that holds
+                    // more than cand_cap keypoints is still exact as long as no re-scan of it is needed; only a re-scan of
+                    // a truncated list voids the frame (the reference has no such limit, ORBmatcher.cc:85-117).
+                    if (nc_all > D.cand_cap) overflow = 1;
                     const unsigned long long* C = D.cand + qo * D.cand_cap;
                     unsigned long long k1 = NONE, k2 = NONE;
                     for (int c = lane; c < nc; c += 64) {
@@ -253,7 +256,6 @@ __global__ __launch_bounds__(64) void search_resolve_init_kernel(SearchDev D) {
         unsigned long long tb = NONE, ts = NONE;
         int ncq = 0;
         if (live) { tb = D.tent[2 * (q0 + qj)]; ts = D.tent[2 * (q0 + qj) + 1]; ncq = D.cand_n[q0 + qj]; }
-        overflow |= __ballot(ncq > D.cand_cap) != 0ull;
         int res = -1, bd = 256, bl = -1, sd = 256, sl = -1;
         const int jn = min(64, m - qb);
         for (int j = 0; j < jn; ++j) {
@@ -263,7 +265,8 @@ __global__ __launch_bounds__(64) void search_resolve_init_kernel(SearchDev D) {
                 const bool xs = second != NONE && md[KEY_KP(second)] <= (int)(second >> 32);
                 if (xb || xs) {
                     const size_t qo = q0 + qb + j;
-                    const int nc = min(__builtin_amdgcn_readlane(ncq, j), D.cand_cap);
+                    const int nc_all = __builtin_amdgcn_readlane(ncq, j), nc = min(nc_all, D.cand_cap);
+                    if (nc_all > D.cand_cap) overflow = 1;   // a truncated list is being consumed (see search_resolve_kernel)
                     const unsigned long long* C = D.cand + qo * D.cand_cap;
                     unsigned long long k1 = NONE, k2 = NONE;
                     for (int c = lane; c < nc; c += 64) {
