@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <limits.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -17,13 +19,13 @@
 
 size_t bak_ldlt_smem(int Npad);
 hipError_t bak_prepare(int Npad);
-void bak_import(hipStream_t st, BaWin* wins, const double* const* in_pose, int max_kf, int nwin);
+void bak_import(hipStream_t st, BaWin* wins, const BaIo* io, int max_kf, int max_pt, int max_edge, int Npad, int nwin);
 void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int stage, int max_it, int robust, bool gate);
 void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad);
-void bak_final(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_edge, double* const* out_pose,
-               uint8_t* const* out_flag);
+void bak_final(hipStream_t st, BaWin* wins, const BaIo* io, int nwin, int max_kf, int max_pt, int max_edge);
 
 static_assert(BA_MAX_ITS == SLAMIT_BA_MAX_ITS, "stats capacity");
+static_assert(sizeof(BaState) % 8 == 0, "BaState is copied as 64-bit words");
 
 namespace {
 inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -32,21 +34,22 @@ inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct slamit_ba {
     int device;
     hipStream_t stream;
+    hipEvent_t ev[2];          // state read-backs of the LM chunks in flight
     int max_kf, max_pt, max_edge, max_batch;
     int Npad_max, Kpad_max, n_part;
-    size_t win_bytes;          // device bytes of one window slab
+    size_t win_bytes;          // device bytes of one window slab: io section (inputs | outputs) then the workspace
+    size_t io_cap;             // bytes of the io section
     uint8_t* d_slab;           // max_batch * win_bytes
     BaWin* d_wins;             // max_batch
     BaState* d_states;         // max_batch
-    double** d_out_pose;       // max_batch pointers (into the slabs)
-    uint8_t** d_out_flag;
-    const double** d_in_pose;
-    std::vector<uint8_t> h_stage;   // pinned-like staging (plain host memory)
+    BaIo* d_io;                // max_batch
+    uint8_t* h_pin;            // pinned: every window's packed inputs, then outputs, then 2 x max_batch LM states
+    size_t pin_bytes;
 };
 
 namespace {
 
-// carve one window's arrays out of its slab; returns bytes used. `base` may be null (size query)
+// carve arrays out of a block; `base` may be null (size query)
 struct Carver {
     uint8_t* base;
     size_t off;
@@ -59,28 +62,45 @@ struct Carver {
     }
 };
 
-struct WinLayout {
-    BaWin w;
-    double* in_pose;     // 12 * n_kf staging of the caller's R|t
-    double* out_pose;    // 12 * n_kf
-    uint8_t* out_flag;   // n_edge
+// The io section of a window: the arrays the host writes (packed for the ACTUAL sizes of the problem, so one copy moves
+// exactly what is needed) followed by the arrays it reads back.
+struct IoLayout {
+    // inputs
+    double* in_pose; double* intr; int32_t* pose_col; double* in_pt; int32_t* e_kf; int32_t* e_pt; double* e_uv; double* e_w;
+    int32_t* pt_edges; int32_t* kf_edges; int32_t* pt_ptr; int32_t* kf_ptr;
+    size_t in_bytes;
+    // outputs
+    size_t out_off;
+    double* out_pose; double* out_pt; double* out_chi2; uint8_t* out_flag; uint8_t* out_out1; BaState* out_state;
     size_t bytes;
 };
 
-WinLayout carve(uint8_t* base, int max_kf, int max_pt, int max_edge, int Npad, int Kpad, int n_part) {
+IoLayout carve_io(uint8_t* base, int n_kf, int n_pt, int n_edge) {
     Carver c{base, 0};
-    WinLayout L;
-    memset(&L.w, 0, sizeof(L.w));
-    BaWin& w = L.w;
+    IoLayout L;
+    L.in_pose = c.take<double>(12 * (size_t)n_kf); L.intr = c.take<double>(4 * (size_t)n_kf); L.pose_col = c.take<int32_t>(n_kf);
+    L.in_pt = c.take<double>(3 * (size_t)std::max(n_pt, 1));
+    L.e_kf = c.take<int32_t>(std::max(n_edge, 1)); L.e_pt = c.take<int32_t>(std::max(n_edge, 1));
+    L.e_uv = c.take<double>(2 * (size_t)std::max(n_edge, 1)); L.e_w = c.take<double>(std::max(n_edge, 1));
+    L.pt_edges = c.take<int32_t>(std::max(n_edge, 1)); L.kf_edges = c.take<int32_t>(std::max(n_edge, 1));
+    L.pt_ptr = c.take<int32_t>((size_t)n_pt + 1); L.kf_ptr = c.take<int32_t>((size_t)n_kf + 1);
+    L.in_bytes = rup(c.off, 256);
+    c.off = L.in_bytes;
+    L.out_off = c.off;
+    L.out_pose = c.take<double>(12 * (size_t)n_kf); L.out_pt = c.take<double>(3 * (size_t)std::max(n_pt, 1));
+    L.out_chi2 = c.take<double>(std::max(n_edge, 1)); L.out_flag = c.take<uint8_t>(std::max(n_edge, 1));
+    L.out_out1 = c.take<uint8_t>(std::max(n_edge, 1)); L.out_state = c.take<BaState>(1);
+    L.bytes = rup(c.off, 4096);
+    return L;
+}
+
+// the workspace of a window (sized for the handle's maxima); returns bytes used
+size_t carve_work(uint8_t* base, BaWin& w, int max_kf, int max_pt, int max_edge, int Npad, int Kpad, int n_part) {
+    Carver c{base, 0};
     w.pose = c.take<double>(7 * (size_t)max_kf); w.pose_bak = c.take<double>(7 * (size_t)max_kf);
-    w.intr = c.take<double>(4 * (size_t)max_kf); w.pose_col = c.take<int32_t>(max_kf);
     w.pt = c.take<double>(3 * (size_t)max_pt); w.pt_bak = c.take<double>(3 * (size_t)max_pt);
-    w.e_kf = c.take<int32_t>(max_edge); w.e_pt = c.take<int32_t>(max_edge);
-    w.e_uv = c.take<double>(2 * (size_t)max_edge); w.e_w = c.take<double>(max_edge);
     w.e_active = c.take<uint8_t>(max_edge); w.e_out1 = c.take<uint8_t>(max_edge);
     w.e_chi2 = c.take<double>(max_edge); w.e_jac = c.take<double>(21 * (size_t)max_edge);
-    w.pt_ptr = c.take<int32_t>((size_t)max_pt + 1); w.pt_edges = c.take<int32_t>(max_edge);
-    w.kf_ptr = c.take<int32_t>((size_t)max_kf + 1); w.kf_edges = c.take<int32_t>(max_edge);
     w.Hll = c.take<double>(6 * (size_t)max_pt); w.bl = c.take<double>(3 * (size_t)max_pt);
     w.Dinv = c.take<double>(6 * (size_t)max_pt);
     w.Hpp = c.take<double>(36 * (size_t)max_kf); w.bp = c.take<double>(6 * (size_t)max_kf + 8);
@@ -89,11 +109,7 @@ WinLayout carve(uint8_t* base, int max_kf, int max_pt, int max_edge, int Npad, i
     w.S = c.take<double>((size_t)Npad * Npad); w.rhs = c.take<double>(Npad);
     w.x_l = c.take<double>(3 * (size_t)max_pt);
     w.chi_part = c.take<double>(n_part); w.scale_part = c.take<double>(n_part);
-    L.in_pose = c.take<double>(12 * (size_t)max_kf);
-    L.out_pose = c.take<double>(12 * (size_t)max_kf);
-    L.out_flag = c.take<uint8_t>(max_edge);
-    L.bytes = rup(c.off, 4096);
-    return L;
+    return rup(c.off, 4096);
 }
 
 }  // namespace
@@ -111,31 +127,22 @@ int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int de
     h->Npad_max = (int)rup((size_t)6 * max_kf + 1, BA_TILE);
     h->Kpad_max = (int)rup((size_t)3 * max_pt, (size_t)BA_KC * BA_SPLITS);
     h->n_part = std::max((max_edge + 255) / 256, (std::max(8 * max_pt, max_kf) + 255) / 256) + 1;   // 8 = BA_PG lanes per point
-    if (bak_ldlt_smem(h->Npad_max) > 160 * 1024 - 2048) {
+    if (bak_ldlt_smem(h->Npad_max) > 160 * 1024 - 2048 || h->Npad_max > BA_TILE * BA_MAX_TILES || h->Npad_max > 32 * BA_MAX_PANELS) {
         delete h;
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_create: max_kf too large for the LDS-resident LDLt panel");
     }
-    WinLayout probe = carve(nullptr, max_kf, max_pt, max_edge, h->Npad_max, h->Kpad_max, h->n_part);
-    h->win_bytes = probe.bytes;
+    {
+        BaWin probe;
+        h->io_cap = carve_io(nullptr, max_kf, max_pt, max_edge).bytes;
+        h->win_bytes = h->io_cap + carve_work(nullptr, probe, max_kf, max_pt, max_edge, h->Npad_max, h->Kpad_max, h->n_part);
+    }
     hipError_t e = hipMalloc((void**)&h->d_slab, h->win_bytes * (size_t)max_batch);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_wins, sizeof(BaWin) * max_batch);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_states, sizeof(BaState) * max_batch);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_out_pose, sizeof(double*) * max_batch);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_out_flag, sizeof(uint8_t*) * max_batch);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_in_pose, sizeof(double*) * max_batch);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_io, sizeof(BaIo) * max_batch);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = bak_prepare(h->Npad_max);
-    if (e == hipSuccess) {
-        std::vector<double*> op(max_batch), ip(max_batch);
-        std::vector<uint8_t*> of(max_batch);
-        for (int b = 0; b < max_batch; ++b) {
-            WinLayout L = carve(h->d_slab + (size_t)b * h->win_bytes, max_kf, max_pt, max_edge, h->Npad_max, h->Kpad_max, h->n_part);
-            op[b] = L.out_pose; of[b] = L.out_flag; ip[b] = L.in_pose;
-        }
-        e = hipMemcpy(h->d_out_pose, op.data(), sizeof(double*) * max_batch, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(h->d_out_flag, of.data(), sizeof(uint8_t*) * max_batch, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(h->d_in_pose, ip.data(), sizeof(double*) * max_batch, hipMemcpyHostToDevice);
-    }
     if (e != hipSuccess) {
         slamit_ba_destroy(h);
         return slamit_fail_hip(e, "slamit_ba_create");
@@ -147,8 +154,9 @@ int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int de
 void slamit_ba_destroy(slamit_ba* h) {
     if (!h) return;
     hipSetDevice(h->device);
-    hipFree(h->d_slab); hipFree(h->d_wins); hipFree(h->d_states); hipFree(h->d_out_pose); hipFree(h->d_out_flag);
-    hipFree((void*)h->d_in_pose);
+    hipFree(h->d_slab); hipFree(h->d_wins); hipFree(h->d_states); hipFree(h->d_io);
+    if (h->h_pin) hipHostFree(h->h_pin);
+    for (int i = 0; i < 2; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -160,9 +168,7 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
     if (nwin == 0) return SLAMIT_OK;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    // ---- validate, build CSR lists, upload ----
-    std::vector<BaWin> wins(nwin);
-    std::vector<WinLayout> lay(nwin);
+    // ---- validate ----
     int mk = 1, mp = 1, me = 1, Npad = BA_TILE;
     for (int b = 0; b < nwin; ++b) {
         const slamit_ba_problem& P = probs[b];
@@ -178,13 +184,41 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
                 return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: edge index out of range");
         mk = std::max(mk, P.n_kf); mp = std::max(mp, P.n_pt); me = std::max(me, P.n_edge);
     }
+    // ---- one pinned block: [inputs of window 0 | inputs of window 1 | ...][outputs ...][2 x nwin LM states] ----
+    std::vector<size_t> in_off(nwin), out_off(nwin);
+    std::vector<IoLayout> dio(nwin);   // device addresses inside the slabs
+    size_t pin_need = 0;
+    for (int b = 0; b < nwin; ++b) {
+        dio[b] = carve_io(h->d_slab + (size_t)b * h->win_bytes, probs[b].n_kf, probs[b].n_pt, probs[b].n_edge);
+        in_off[b] = pin_need; pin_need += dio[b].in_bytes;
+    }
+    for (int b = 0; b < nwin; ++b) { out_off[b] = pin_need; pin_need += dio[b].bytes - dio[b].out_off; }
+    const size_t st_off = rup(pin_need, 256);
+    pin_need = st_off + 2 * sizeof(BaState) * (size_t)nwin;
+    if (pin_need > h->pin_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h->h_pin) hipHostFree(h->h_pin);
+        h->h_pin = nullptr; h->pin_bytes = 0;
+        HIP_TRY(hipHostMalloc((void**)&h->h_pin, pin_need + pin_need / 4, hipHostMallocDefault));
+        h->pin_bytes = pin_need + pin_need / 4;
+    }
+    std::vector<BaWin> wins(nwin);
+    std::vector<BaIo> io(nwin);
+    std::vector<std::vector<int32_t> > perm(nwin);   // device point index -> caller's point index
     for (int b = 0; b < nwin; ++b) {
         const slamit_ba_problem& P = probs[b];
-        uint8_t* base = h->d_slab + (size_t)b * h->win_bytes;
-        lay[b] = carve(base, h->max_kf, h->max_pt, h->max_edge, h->Npad_max, h->Kpad_max, h->n_part);
-        BaWin& w = lay[b].w;
+        uint8_t* slab = h->d_slab + (size_t)b * h->win_bytes;
+        BaWin& w = wins[b];
+        memset(&w, 0, sizeof(w));
+        carve_work(slab + h->io_cap, w, h->max_kf, h->max_pt, h->max_edge, h->Npad_max, h->Kpad_max, h->n_part);
+        const IoLayout& D = dio[b];
+        const IoLayout H = carve_io(h->h_pin + in_off[b], P.n_kf, P.n_pt, P.n_edge);   // the same packing in the pinned block
+        w.intr = D.intr; w.pose_col = D.pose_col; w.e_kf = D.e_kf; w.e_pt = D.e_pt; w.e_uv = D.e_uv; w.e_w = D.e_w;
+        w.pt_edges = D.pt_edges; w.kf_edges = D.kf_edges; w.pt_ptr = D.pt_ptr; w.kf_ptr = D.kf_ptr;
+        io[b].in_pose = D.in_pose; io[b].in_pt = D.in_pt; io[b].out_pose = D.out_pose; io[b].out_pt = D.out_pt;
+        io[b].out_chi2 = D.out_chi2; io[b].out_flag = D.out_flag; io[b].out_out1 = D.out_out1; io[b].out_state = D.out_state;
         w.n_kf = P.n_kf; w.n_pt = P.n_pt; w.n_edge = P.n_edge;
-        std::vector<int32_t> col(P.n_kf);
+        int32_t* col = H.pose_col;
         int nfree = 0;
         for (int k = 0; k < P.n_kf; ++k) col[k] = P.kf_fixed[k] ? -1 : nfree++;
         w.n_free = nfree; w.nS = 6 * nfree;
@@ -194,95 +228,151 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
         w.huber_delta = opts->huber_delta; w.chi2_gate = opts->chi2_gate;
         w.st = h->d_states + b;
         Npad = std::max(Npad, w.Npad);
-        // CSR by point / by keyframe (counting sort, caller order preserved inside each list)
-        std::vector<int32_t> pptr(P.n_pt + 1, 0), kptr(P.n_kf + 1, 0), pe(P.n_edge), ke(P.n_edge);
-        for (int e = 0; e < P.n_edge; ++e) { ++pptr[P.edge_pt[e] + 1]; ++kptr[P.edge_kf[e] + 1]; }
-        for (int p = 0; p < P.n_pt; ++p) pptr[p + 1] += pptr[p];
+        // ---- structure of the window (g2o's BlockSolver / SimplicialLDLT exploit the same sparsity on the CPU,
+        // block_solver.hpp:381-432, linear_solver_eigen.h:94-124) ----
+        // Points are stored on the device sorted by the first free keyframe that observes them: the rows of GA / GB that
+        // belong to a 64-row tile then have their non-zeros in one k range, and the Schur product skips the rest.
+        std::vector<int32_t> minc(P.n_pt, INT32_MAX), maxc(P.n_pt, -1);
+        for (int e = 0; e < P.n_edge; ++e) {
+            const int c = col[P.edge_kf[e]], p2 = P.edge_pt[e];
+            if (c >= 0) { minc[p2] = std::min(minc[p2], c); maxc[p2] = std::max(maxc[p2], c); }
+        }
+        std::vector<int32_t>& new2old = perm[b];
+        new2old.resize(P.n_pt);
+        std::vector<int32_t> old2new(P.n_pt);
+        for (int p2 = 0; p2 < P.n_pt; ++p2) new2old[p2] = p2;
+        std::stable_sort(new2old.begin(), new2old.end(), [&](int a, int b2) { return minc[a] != minc[b2] ? minc[a] < minc[b2] : maxc[a] < maxc[b2]; });
+        for (int p2 = 0; p2 < P.n_pt; ++p2) old2new[new2old[p2]] = p2;
+        {
+            // per pose column: range of (sorted) points it observes, and the first column it is coupled with
+            std::vector<int32_t> plo(std::max(nfree, 1), INT32_MAX), phi(std::max(nfree, 1), -1), fcol(std::max(nfree, 1));
+            for (int c = 0; c < nfree; ++c) fcol[c] = c;
+            for (int e = 0; e < P.n_edge; ++e) {
+                const int c = col[P.edge_kf[e]], po = P.edge_pt[e];
+                if (c < 0) continue;
+                const int pn = old2new[po];
+                plo[c] = std::min(plo[c], pn); phi[c] = std::max(phi[c], pn);
+                fcol[c] = std::min(fcol[c], minc[po]);
+            }
+            const int T = w.Npad / BA_TILE, kmax = w.Kpad;
+            for (int t = 0; t < T; ++t) {
+                int lo = INT32_MAX, hi = -1;
+                for (int c = 0; c < nfree; ++c) {
+                    if (6 * c + 5 < BA_TILE * t || 6 * c >= BA_TILE * (t + 1) || phi[c] < 0) continue;   // pose rows outside the tile / no points
+                    lo = std::min(lo, 3 * plo[c]); hi = std::max(hi, 3 * phi[c] + 3);
+                }
+                if (hi < 0) { lo = 0; hi = 0; }
+                lo = lo / BA_KC * BA_KC; hi = std::min((hi + BA_KC - 1) / BA_KC * BA_KC, kmax);
+                w.tile_alo[t] = lo; w.tile_ahi[t] = hi; w.tile_blo[t] = lo; w.tile_bhi[t] = hi;
+                if (w.nS >= BA_TILE * t && w.nS < BA_TILE * (t + 1)) { w.tile_blo[t] = 0; w.tile_bhi[t] = kmax; }   // row nS of GB = bl of every point
+            }
+            // LDLt: row envelope.  first[r] = 6 * fcol[r / 6]; panel i (columns 32 i ..) only touches rows r with first[r] < 32 i + 32
+            const int n = w.nS;
+            for (int i = 0; i < BA_MAX_PANELS; ++i) { w.panel_hi[i] = (int16_t)std::max(n - 1, 0); w.back_lo[i] = 0; }
+            for (int i = 0; 32 * i < n; ++i) {
+                const int jb = 32 * i, pend = std::min(jb + 32, n);
+                int hi = pend - 1, lo = jb;
+                for (int c = 0; c < nfree; ++c) {
+                    if (6 * fcol[c] < pend) hi = std::max(hi, 6 * c + 5);                               // row block c reaches into the panel's columns
+                    if (6 * c + 5 >= jb && 6 * c < pend) lo = std::min(lo, 6 * fcol[c]);               // rows of the panel: leftmost column
+                }
+                w.panel_hi[i] = (int16_t)std::min(hi, n - 1);
+                w.back_lo[i] = (int16_t)lo;
+            }
+        }
+        // ---- inputs, straight into the pinned block: CSR by point / by keyframe (counting sort, caller order kept
+        // inside each list), points in device order ----
+        memcpy(H.in_pose, P.kf_pose, sizeof(double) * 12 * (size_t)P.n_kf);
+        memcpy(H.intr, P.kf_intr, sizeof(double) * 4 * (size_t)P.n_kf);
+        for (int p2 = 0; p2 < P.n_pt; ++p2) for (int j = 0; j < 3; ++j) H.in_pt[3 * (size_t)p2 + j] = P.pt_xyz[3 * (size_t)new2old[p2] + j];
+        if (P.n_edge) {
+            memcpy(H.e_kf, P.edge_kf, sizeof(int32_t) * (size_t)P.n_edge);
+            memcpy(H.e_uv, P.edge_uv, sizeof(double) * 2 * (size_t)P.n_edge);
+            memcpy(H.e_w, P.edge_inv_sigma2, sizeof(double) * (size_t)P.n_edge);
+        }
+        int32_t* pptr = H.pt_ptr; int32_t* kptr = H.kf_ptr;
+        for (int p2 = 0; p2 <= P.n_pt; ++p2) pptr[p2] = 0;
+        for (int k = 0; k <= P.n_kf; ++k) kptr[k] = 0;
+        for (int e = 0; e < P.n_edge; ++e) { H.e_pt[e] = old2new[P.edge_pt[e]]; ++pptr[H.e_pt[e] + 1]; ++kptr[P.edge_kf[e] + 1]; }
+        for (int p2 = 0; p2 < P.n_pt; ++p2) pptr[p2 + 1] += pptr[p2];
         for (int k = 0; k < P.n_kf; ++k) kptr[k + 1] += kptr[k];
         {
-            std::vector<int32_t> pc(pptr.begin(), pptr.end() - 1), kc(kptr.begin(), kptr.end() - 1);
-            for (int e = 0; e < P.n_edge; ++e) { pe[pc[P.edge_pt[e]]++] = e; ke[kc[P.edge_kf[e]]++] = e; }
+            std::vector<int32_t> pc(pptr, pptr + P.n_pt), kc(kptr, kptr + P.n_kf);
+            for (int e = 0; e < P.n_edge; ++e) { H.pt_edges[pc[H.e_pt[e]]++] = e; H.kf_edges[kc[P.edge_kf[e]]++] = e; }
         }
-#define UP(dst, src, n) HIP_TRY(hipMemcpyAsync((void*)(dst), (src), sizeof(*(src)) * (size_t)(n), hipMemcpyHostToDevice, st))
-        UP(lay[b].in_pose, P.kf_pose, 12 * P.n_kf);
-        UP(w.intr, P.kf_intr, 4 * P.n_kf);
-        UP(w.pose_col, col.data(), P.n_kf);
-        if (P.n_pt) UP(w.pt, P.pt_xyz, 3 * P.n_pt);
-        if (P.n_edge) {
-            UP(w.e_kf, P.edge_kf, P.n_edge); UP(w.e_pt, P.edge_pt, P.n_edge);
-            UP(w.e_uv, P.edge_uv, 2 * P.n_edge); UP(w.e_w, P.edge_inv_sigma2, P.n_edge);
-            UP(w.pt_edges, pe.data(), P.n_edge); UP(w.kf_edges, ke.data(), P.n_edge);
-        }
-        UP(w.pt_ptr, pptr.data(), P.n_pt + 1); UP(w.kf_ptr, kptr.data(), P.n_kf + 1);
-#undef UP
-        HIP_TRY(hipMemsetAsync(w.e_active, 1, std::max(P.n_edge, 1), st));
-        HIP_TRY(hipMemsetAsync(w.e_out1, 0, std::max(P.n_edge, 1), st));
-        HIP_TRY(hipMemsetAsync(w.e_chi2, 0, sizeof(double) * std::max(P.n_edge, 1), st));
-        HIP_TRY(hipMemsetAsync(w.st, 0, sizeof(BaState), st));
-        HIP_TRY(hipStreamSynchronize(st));  // the staging vectors above go out of scope
-        wins[b] = w;
+        HIP_TRY(hipMemcpyAsync(slab, h->h_pin + in_off[b], D.in_bytes, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipMemcpyAsync(h->d_wins, wins.data(), sizeof(BaWin) * nwin, hipMemcpyHostToDevice, st));
-    bak_import(st, h->d_wins, h->d_in_pose, mk, nwin);
+    HIP_TRY(hipMemcpyAsync(h->d_io, io.data(), sizeof(BaIo) * nwin, hipMemcpyHostToDevice, st));
+    bak_import(st, h->d_wins, h->d_io, mk, mp, me, Npad, nwin);   // also zeroes the Schur operands' ranges and the LM states
 
     // ---- two-stage schedule (Optimizer.cc:659-707) ----
-    std::vector<BaState> hs(nwin);
+    // LM trial slots are enqueued two at a time; the windows' states come back through the pinned block one chunk LATE
+    // (the next chunk is already queued when the host looks at the previous one: no bubble between chunks), and *stop is
+    // polled before every chunk like SparseOptimizer::terminate() (sparse_optimizer.cpp:376) is before every iteration.
+    // Slots of a finished stage return at once, so a chunk queued in vain costs a few launches.
+    BaState* hs[2] = {reinterpret_cast<BaState*>(h->h_pin + st_off), reinterpret_cast<BaState*>(h->h_pin + st_off) + nwin};
     bool stopped = opts->stop && *opts->stop;  // :655-657
     for (int stage = 0; stage < 2 && !stopped; ++stage) {
         const int its = stage == 0 ? opts->its_robust : opts->its_final;
-        for (int b = 0; b < nwin; ++b) {  // the sparsity pattern of the operands shrinks after the gate
-            HIP_TRY(hipMemsetAsync(wins[b].GA, 0, sizeof(double) * (size_t)wins[b].Npad * wins[b].Kpad, st));
-            HIP_TRY(hipMemsetAsync(wins[b].GB, 0, sizeof(double) * (size_t)wins[b].Npad * wins[b].Kpad, st));
-        }
         bak_stage_begin(st, h->d_wins, nwin, me, stage, its, stage == 0 ? 1 : 0, stage == 1);
         int budget = its * 10 + 1;  // at most 10 LM trials per iteration
-        int chunk = std::max(its, 1);
+        int cur = 0, pending = -1;
         bool all_done = false;
-        while (!all_done && budget > 0) {
-            if (opts->stop && *opts->stop) { stopped = true; break; }  // SparseOptimizer::terminate()
-            const int nslots = std::min(chunk, budget);
-            for (int s = 0; s < nslots; ++s) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad);
-            budget -= nslots;
-            HIP_TRY(hipMemcpyAsync(hs.data(), h->d_states, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            all_done = true;
-            for (int b = 0; b < nwin; ++b) all_done = all_done && hs[b].done;
-            chunk = 2;
+        while (!all_done) {
+            if (opts->stop && *opts->stop) { stopped = true; break; }
+            if (budget > 0) {
+                const int nslots = std::min(2, budget);
+                for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad);
+                budget -= nslots;
+                HIP_TRY(hipMemcpyAsync(hs[cur], h->d_states, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(h->ev[cur], st));
+            }
+            if (pending >= 0) {
+                HIP_TRY(hipEventSynchronize(h->ev[pending]));
+                all_done = true;
+                for (int b = 0; b < nwin; ++b) all_done = all_done && hs[pending][b].done;
+            }
+            if (budget <= 0 && pending == cur) break;   // nothing new was queued: the last read-back has been looked at
+            pending = cur;
+            if (budget > 0) cur ^= 1;
         }
         HIP_TRY(hipGetLastError());
     }
-    // ---- results ----
-    bak_final(st, h->d_wins, nwin, mk, me, h->d_out_pose, h->d_out_flag);
-    HIP_TRY(hipMemcpyAsync(hs.data(), h->d_states, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));
+    // ---- results: one copy per window out of its output section ----
+    bak_final(st, h->d_wins, h->d_io, nwin, mk, mp, me);
+    for (int b = 0; b < nwin; ++b)
+        HIP_TRY(hipMemcpyAsync(h->h_pin + out_off[b], h->d_slab + (size_t)b * h->win_bytes + dio[b].out_off, dio[b].bytes - dio[b].out_off,
+                               hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     for (int b = 0; b < nwin; ++b) {
         const slamit_ba_problem& P = probs[b];
         slamit_ba_result& R = results[b];
-        HIP_TRY(hipMemcpyAsync(R.kf_pose, lay[b].out_pose, sizeof(double) * 12 * P.n_kf, hipMemcpyDeviceToHost, st));
-        if (P.n_pt) HIP_TRY(hipMemcpyAsync(R.pt_xyz, wins[b].pt, sizeof(double) * 3 * P.n_pt, hipMemcpyDeviceToHost, st));
+        // the output section as the host sees it: same carve, shifted so that its output part starts at out_off[b]
+        const IoLayout H = carve_io(h->h_pin + out_off[b] - dio[b].out_off, P.n_kf, P.n_pt, P.n_edge);
+        memcpy(R.kf_pose, H.out_pose, sizeof(double) * 12 * (size_t)P.n_kf);
+        for (int p2 = 0; p2 < P.n_pt; ++p2)   // points back in the caller's order
+            for (int j = 0; j < 3; ++j) R.pt_xyz[3 * (size_t)perm[b][p2] + j] = H.out_pt[3 * (size_t)p2 + j];
         if (P.n_edge) {
-            if (R.edge_chi2) HIP_TRY(hipMemcpyAsync(R.edge_chi2, wins[b].e_chi2, sizeof(double) * P.n_edge, hipMemcpyDeviceToHost, st));
-            if (R.edge_outlier) HIP_TRY(hipMemcpyAsync(R.edge_outlier, lay[b].out_flag, P.n_edge, hipMemcpyDeviceToHost, st));
-            if (R.edge_stage1_outlier) HIP_TRY(hipMemcpyAsync(R.edge_stage1_outlier, wins[b].e_out1, P.n_edge, hipMemcpyDeviceToHost, st));
+            if (R.edge_chi2) memcpy(R.edge_chi2, H.out_chi2, sizeof(double) * (size_t)P.n_edge);
+            if (R.edge_outlier) memcpy(R.edge_outlier, H.out_flag, (size_t)P.n_edge);
+            if (R.edge_stage1_outlier) memcpy(R.edge_stage1_outlier, H.out_out1, (size_t)P.n_edge);
         }
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (getenv("SLAMIT_BA_DIAG"))  // diagnostic builds only: in-kernel clock of the last LDLt launch
-        fprintf(stderr, "[ba diag] ldlt shader cycles %llu, realtime ticks (100 MHz) %llu -> %.0f MHz, %.1f us\n",
-                hs[0].dbg[2] - hs[0].dbg[0], hs[0].dbg[3] - hs[0].dbg[1],
-                100.0 * (double)(hs[0].dbg[2] - hs[0].dbg[0]) / (double)(hs[0].dbg[3] - hs[0].dbg[1] + 1),
-                (double)(hs[0].dbg[3] - hs[0].dbg[1]) / 100.0);
-    if (getenv("SLAMIT_BA_DIAG"))
-        fprintf(stderr, "[ba diag] ldlt phase cycles: load %llu factor %llu rows %llu writeback %llu trailing %llu backsub %llu\n",
-                hs[0].dbg[4] >> 32, hs[0].dbg[4] & 0xffffffffull, hs[0].dbg[5] >> 32, hs[0].dbg[5] & 0xffffffffull,
-                hs[0].dbg[6] >> 32, hs[0].dbg[6] & 0xffffffffull);
-    for (int b = 0; b < nwin; ++b) {
-        slamit_ba_stats* S = results[b].stats;
+        const BaState& S0 = *H.out_state;
+        if (b == 0 && getenv("SLAMIT_BA_DIAG")) {  // diagnostic builds only: in-kernel clock and phases of the last LDLt launch
+            fprintf(stderr, "[ba diag] ldlt shader cycles %llu, realtime ticks (100 MHz) %llu -> %.0f MHz, %.1f us\n",
+                    S0.dbg[2] - S0.dbg[0], S0.dbg[3] - S0.dbg[1],
+                    100.0 * (double)(S0.dbg[2] - S0.dbg[0]) / (double)(S0.dbg[3] - S0.dbg[1] + 1), (double)(S0.dbg[3] - S0.dbg[1]) / 100.0);
+            fprintf(stderr, "[ba diag] ldlt phase cycles: load %llu factor %llu rows %llu writeback %llu trailing %llu backsub %llu\n",
+                    S0.dbg[4] >> 32, S0.dbg[4] & 0xffffffffull, S0.dbg[5] >> 32, S0.dbg[5] & 0xffffffffull, S0.dbg[6] >> 32, S0.dbg[6] & 0xffffffffull);
+        }
+        slamit_ba_stats* S = R.stats;
         if (!S) continue;
         memset(S, 0, sizeof(*S));
-        for (int s = 0; s < 2; ++s) {
-            S->n_its[s] = hs[b].n_its[s];
-            S->chi2_init[s] = hs[b].chi2_init[s];
-            for (int i = 0; i < SLAMIT_BA_MAX_ITS; ++i) { S->chi2[s][i] = hs[b].chi2[s][i]; S->lambda[s][i] = hs[b].lam[s][i]; S->trials[s][i] = hs[b].trials[s][i]; }
+        for (int sg = 0; sg < 2; ++sg) {
+            S->n_its[sg] = S0.n_its[sg];
+            S->chi2_init[sg] = S0.chi2_init[sg];
+            for (int i = 0; i < SLAMIT_BA_MAX_ITS; ++i) { S->chi2[sg][i] = S0.chi2[sg][i]; S->lambda[sg][i] = S0.lam[sg][i]; S->trials[sg][i] = S0.trials[sg][i]; }
         }
     }
     return SLAMIT_OK;

@@ -20,6 +20,8 @@
 // an LM trial is a fixed sequence of launches ("slot") with no host round trip; kernels of a
 // finished window exit at once.  blockIdx.y is the window of a batch.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <float.h>
 #include <stdint.h>
 
@@ -289,8 +291,11 @@ __global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
     const int J = I + rem;
     if (I >= T) return;
     const int s = blockIdx.y;
-    const int kchunk = W.Kpad / BA_SPLITS;
-    const int k0 = s * kchunk;
+    // Only the k range in which BOTH row tiles have non-zeros is multiplied (points are sorted by their first observing
+    // keyframe, ba_api.hip): its slabs of BA_KC are dealt to the BA_SPLITS splits; a split without a slab stores zeros.
+    const int klo = max(W.tile_alo[I], W.tile_blo[J]), khi = min(W.tile_ahi[I], W.tile_bhi[J]);
+    const int nslab = khi > klo ? (khi - klo) / BA_KC : 0;
+    const int k0 = klo + (int)((long)nslab * s / BA_SPLITS) * BA_KC, kend = klo + (int)((long)nslab * (s + 1) / BA_SPLITS) * BA_KC;
     __shared__ double As[BA_TILE * LDS_PITCH];
     __shared__ double Bs[BA_TILE * LDS_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -302,13 +307,15 @@ __global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
     for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0, 0, 0, 0};
     // software pipeline: the next slab is fetched into registers while the current one feeds the MFMAs
     double pa[8], pb[8];
+    if (kend > k0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = tid + 256 * u, r = i >> 5, c = i & 31;
-        pa[u] = A[(size_t)r * K + k0 + c];
-        pb[u] = B[(size_t)r * K + k0 + c];
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u, r = i >> 5, c = i & 31;
+            pa[u] = A[(size_t)r * K + k0 + c];
+            pb[u] = B[(size_t)r * K + k0 + c];
+        }
     }
-    for (int kk = k0; kk < k0 + kchunk; kk += BA_KC) {
+    for (int kk = k0; kk < kend; kk += BA_KC) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
             Bs[r * LDS_PITCH + c] = pb[u];
         }
         __syncthreads();
-        if (kk + BA_KC < k0 + kchunk) {
+        if (kk + BA_KC < kend) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = tid + 256 * u, r = i >> 5, c = i & 31;
@@ -401,31 +408,55 @@ __device__ __forceinline__ double fast_recip(double d) {
 }
 
 __device__ __forceinline__ void ldlt_factor_diag(double* Dg, double* s_invd, double* s_corr, double* s_dval,
-                                                 const unsigned char* s_pr, const unsigned char* s_pc, const short* s_off,
                                                  int nb, int tid, int* s_fail) {
     // TWO columns per step (16 barriers per block instead of 32): with d0 = a[k][k], f = a[k+1][k] / d0 and
     // d1 = a[k+1][k+1] - a[k+1][k] f, every pair (r, c), c >= k+2, takes the rank-2 update
     //     a[r][c] -= a[r][k] a[c][k] / d0 + a'[r] a'[c] / d1,   a'[x] = a[x][k+1] - a[x][k] f
-    // Columns k and k+1 themselves are never written inside the loop (their final L*d values are a[.][k] and a'[.]),
-    // so one barrier per step is enough; the unit-L entries are produced at the end from the untouched columns.
+    // Columns k and k+1 themselves are never written inside the loop (their final L*d values are a[.][k] and a'[.]);
+    // the unit-L entries are produced at the end from the untouched columns.
+    // Every thread OWNS one entry of the lower triangle (528 entries: threads 0..15 own a second one) and keeps it in a
+    // register through all the steps; it only stores it to LDS when its column is about to become a pivot column.  A
+    // step is then ONE round of LDS reads (three pivot entries + four column entries, all issued right after the
+    // barrier), the pivot arithmetic, six FMAs and at most one store -- no pair table, no read-modify-write.
+    int r0, c0, r1 = 0, c1 = 0;
+    {
+        int q = tid;
+        r0 = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+        while ((r0 + 1) * (r0 + 2) / 2 <= q) ++r0;
+        while (r0 * (r0 + 1) / 2 > q) --r0;
+        c0 = q - r0 * (r0 + 1) / 2;
+        if (tid < LD_NB * (LD_NB + 1) / 2 - LD_THREADS) {   // 16 leftover entries: the tail of row 31
+            q = LD_THREADS + tid;
+            r1 = LD_NB - 1; c1 = q - r1 * (r1 + 1) / 2;
+        }
+    }
+    const bool two_entries = tid < LD_NB * (LD_NB + 1) / 2 - LD_THREADS;
+    double v0 = Dg[r0 * LD_P + c0], v1 = two_entries ? Dg[r1 * LD_P + c1] : 0.0;
     for (int k = 0; k < nb; k += 2) {
         const bool two = k + 1 < nb;
         const double d0 = Dg[k * LD_P + k];
+        const double l10 = two ? Dg[(k + 1) * LD_P + k] : 0.0;
+        const double d11 = two ? Dg[(k + 1) * LD_P + k + 1] : 1.0;
+        const bool act0 = c0 >= k + 2 && r0 < nb, act1 = two_entries && c1 >= k + 2 && r1 < nb;
+        const double ark0 = act0 ? Dg[r0 * LD_P + k] : 0.0, ack0 = act0 ? Dg[c0 * LD_P + k] : 0.0;
+        const double ar10 = act0 ? Dg[r0 * LD_P + k + 1] : 0.0, ac10 = act0 ? Dg[c0 * LD_P + k + 1] : 0.0;
+        const double ark1 = act1 ? Dg[r1 * LD_P + k] : 0.0, ack1 = act1 ? Dg[c1 * LD_P + k] : 0.0;
+        const double ar11 = act1 ? Dg[r1 * LD_P + k + 1] : 0.0, ac11 = act1 ? Dg[c1 * LD_P + k + 1] : 0.0;
         const bool bad0 = (d0 == 0.0 || !(fabs(d0) <= DBL_MAX));
         const double inv0 = bad0 ? 0.0 : fast_recip(d0);
-        const double l10 = two ? Dg[(k + 1) * LD_P + k] : 0.0;
         const double f = l10 * inv0;
-        const double d1 = two ? Dg[(k + 1) * LD_P + k + 1] - l10 * f : 1.0;
+        const double d1 = two ? d11 - l10 * f : 1.0;
         const bool bad1 = two && (d1 == 0.0 || !(fabs(d1) <= DBL_MAX));
         const double inv1 = (two && !bad1) ? fast_recip(d1) : 0.0;
-        const int p = s_off[k + 2] + tid;
-        if (p < LD_PAIRS) {
-            const int r = s_pr[p], c = s_pc[p];
-            if (r < nb) {
-                const double ark = Dg[r * LD_P + k], ack = Dg[c * LD_P + k];
-                const double ar1 = Dg[r * LD_P + k + 1] - ark * f, ac1 = Dg[c * LD_P + k + 1] - ack * f;
-                Dg[r * LD_P + c] -= ark * ack * inv0 + ar1 * ac1 * inv1;
-            }
+        if (act0) {
+            const double ar1 = ar10 - ark0 * f, ac1 = ac10 - ack0 * f;
+            v0 -= ark0 * ack0 * inv0 + ar1 * ac1 * inv1;
+            if (c0 <= k + 3) Dg[r0 * LD_P + c0] = v0;   // column c0 is a pivot column of the next step
+        }
+        if (act1) {
+            const double ar1 = ar11 - ark1 * f, ac1 = ac11 - ack1 * f;
+            v1 -= ark1 * ack1 * inv0 + ar1 * ac1 * inv1;
+            if (c1 <= k + 3) Dg[r1 * LD_P + c1] = v1;
         }
         if (tid == 0) {
             s_invd[k] = inv0;
@@ -504,17 +535,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     double* Wd = Dg + LD_NB * LD_P;       // (rows below + rhs row, padded to 16) x LD_P: L21 * D
     __shared__ int s_fail;
     __shared__ double s_invd[LD_NB], s_corr[LD_NB], s_dval[LD_NB];
-    __shared__ unsigned char s_pr[LD_PAIRS], s_pc[LD_PAIRS];
-    __shared__ short s_off[LD_NB + 2];
-    if (tid == 0) {
-        s_fail = 0;
-        int p = 0;
-        for (int c = 1; c < LD_NB; ++c) {   // pairs (r, c), 1 <= c <= r < 32, ordered by c
-            s_off[c] = (short)p;
-            for (int r = c; r < LD_NB; ++r) { s_pr[p] = (unsigned char)r; s_pc[p] = (unsigned char)c; ++p; }
-        }
-        s_off[LD_NB] = (short)p; s_off[LD_NB + 1] = (short)p;
-    }
+    if (tid == 0) s_fail = 0;
     if (n == 0) { if (tid == 0) st->ok2 = 1; return; }
 #ifdef BA_DIAG_STAMPS
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
@@ -529,8 +550,11 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     for (int jb = 0; jb < n; jb += LD_NB) {
         const int nb = min(LD_NB, n - jb);
         const int base = jb + nb;
-        const int below = n - base;          // matrix rows under the panel
-        const int rows = below + 1;          // + the rhs row
+        // rows under the panel that can hold an entry in its columns (row envelope, ba_api.hip); LDLt without pivoting
+        // never fills outside the envelope, so the rows beyond keep exact zeros there and are not touched
+        const int below = max((int)W.panel_hi[jb / LD_NB] + 1 - base, 0);
+        const int rows = below + 1;          // + the rhs row, which is matrix row n
+#define GROW(r) ((r) < below ? base + (r) : n)
         const int rows16 = (rows + 15) & ~15;
         for (int i = tid; i < nb * LD_NB; i += LD_THREADS) {
             const int r = i >> 5, c = i & 31;
@@ -546,7 +570,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {   // issue all loads first: the L2 round trip is paid once per batch
                 const int i = i0 + u * LD_THREADS, r = i >> 5, c = i & 31;
-                v[u] = (i < rows16 * LD_NB && r < rows && c < nb) ? S[(size_t)(base + r) * N + jb + c] : 0.0;
+                v[u] = (i < rows16 * LD_NB && r < rows && c < nb) ? S[(size_t)GROW(r) * N + jb + c] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -556,7 +580,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
         }
         __syncthreads();
         STAMP(0);
-        ldlt_factor_diag(Dg, s_invd, s_corr, s_dval, s_pr, s_pc, s_off, nb, tid, &s_fail);
+        ldlt_factor_diag(Dg, s_invd, s_corr, s_dval, nb, tid, &s_fail);
         STAMP(1);
         __syncthreads();
         if (s_fail) break;
@@ -570,7 +594,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
         }
         for (int i = tid; i < rows * LD_NB; i += LD_THREADS) {
             const int r = i >> 5, c = i & 31;
-            if (c < nb) S[(size_t)(base + r) * N + jb + c] = Wd[r * LD_P + c] * s_invd[c];
+            if (c < nb) S[(size_t)GROW(r) * N + jb + c] = Wd[r * LD_P + c] * s_invd[c];
         }
         // trailing update on MFMA: C[r][c] -= sum_k (w[r][k] invd[k]) w[c][k],  c <= r
         STAMP(3);
@@ -603,7 +627,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r = 16 * frt + lk + 4 * g, c = 16 * fct + l15;
-                    C[g] = (r < rows && c < below && c <= r) ? S[(size_t)(base + r) * N + base + c] : 0.0;
+                    C[g] = (r < rows && c < below && c <= r) ? S[(size_t)GROW(r) * N + base + c] : 0.0;
                 }
             };
             auto advance = [&](int& art_, int& act_) { if (++act_ >= min(art_ + 1, CT)) { ++art_; act_ = 0; } };
@@ -628,7 +652,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int r = 16 * rt + lk + 4 * g, c = 16 * ct + l15;
-                            if (r < rows && c < below && c <= r) S[(size_t)(base + r) * N + base + c] = acc[g];
+                            if (r < rows && c < below && c <= r) S[(size_t)GROW(r) * N + base + c] = acc[g];
                         }
                         if (t + d + LD_CDEPTH < tend) { load_c(lrt, lct, cq[d]); advance(lrt, lct); }
                         advance(rt, ct);
@@ -639,6 +663,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
 #endif
         __syncthreads();
         STAMP(4);
+#undef GROW
     }
     if (s_fail) {
         if (tid == 0) st->ok2 = 0;
@@ -853,7 +878,39 @@ __global__ __launch_bounds__(256) void k_gate(BaWin* wins) {
     const EdgeGeom g = edge_eval(W, e);
     const bool out = W.e_chi2[e] > W.chi2_gate || !(g.z > 0.0);
     W.e_out1[e] = out;
-    if (out) W.e_active[e] = 0;
+    if (out && W.e_active[e]) {
+        W.e_active[e] = 0;
+        // the edge leaves the Schur operands: k_prepare only (re)writes the blocks of active edges
+        const int col = W.pose_col[W.e_kf[e]];
+        if (col >= 0) {
+            const size_t K = (size_t)W.Kpad;
+            for (int r = 0; r < 6; ++r) {
+                const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)W.e_pt[e];
+                W.GA[o] = 0.0; W.GA[o + 1] = 0.0; W.GA[o + 2] = 0.0;
+                W.GB[o] = 0.0; W.GB[o + 1] = 0.0; W.GB[o + 2] = 0.0;
+            }
+        }
+    }
+}
+
+// Zeroes the k ranges of GA / GB the window's structure can touch (a solve starts from whatever the slab held before);
+// grid (x, row tile, window), one double2 per thread and step.
+__global__ __launch_bounds__(256) void k_zero_operands(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.z];
+    const int t = blockIdx.y;
+    if (t >= W.Npad / BA_TILE) return;
+    const size_t K = (size_t)W.Kpad;
+    for (int m = 0; m < 2; ++m) {
+        const int lo = m ? W.tile_blo[t] : W.tile_alo[t], hi = m ? W.tile_bhi[t] : W.tile_ahi[t];
+        gdouble* M = (gdouble*)(m ? W.GB : W.GA) + (size_t)(BA_TILE * t) * K;
+        const int wdt = (hi - lo) >> 1;   // double2 per row (ranges are multiples of BA_KC)
+        if (wdt <= 0) continue;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)BA_TILE * wdt; i += (long)gridDim.x * 256) {
+            const int r = (int)(i / wdt), c = (int)(i - (long)r * wdt);
+            gdouble* q = M + (size_t)r * K + lo + 2 * c;
+            q[0] = 0.0; q[1] = 0.0;
+        }
+    }
 }
 
 // stage entry: counts the active edges; the following k_errors + k_stage_begin2 set the start cost
@@ -885,29 +942,40 @@ __global__ __launch_bounds__(256) void k_stage_begin2(BaWin* wins) {
     if (threadIdx.x == 0) { st->currentChi = chi; st->chi2_init[st->stage] = chi; }
 }
 
-// final erasure test on every edge (Optimizer.cc:715-728) and pose export as R|t
-__global__ __launch_bounds__(256) void k_final(BaWin* wins, double* const* out_pose, uint8_t* const* out_flag) {
+// final erasure test on every edge (Optimizer.cc:715-728), pose export as R|t, and every other output of the window
+// copied into its contiguous output section (one device-to-host copy per window)
+__global__ __launch_bounds__(256) void k_final(BaWin* wins, const BaIo* io) {
     const BaWin& W = wins[blockIdx.y];
+    const BaIo& O = io[blockIdx.y];
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < W.n_edge) {
         const EdgeGeom g = edge_eval(W, e);
-        out_flag[blockIdx.y][e] = W.e_chi2[e] > W.chi2_gate || !(g.z > 0.0);
+        O.out_flag[e] = W.e_chi2[e] > W.chi2_gate || !(g.z > 0.0);
+        O.out_chi2[e] = W.e_chi2[e];
+        O.out_out1[e] = W.e_out1[e];
     }
+    if (e < 3 * W.n_pt) O.out_pt[e] = W.pt[e];
     if (e < W.n_kf) {
         double R[9];
         quat_to_R(W.pose + 7 * (size_t)e, R);
-        double* o = out_pose[blockIdx.y] + 12 * (size_t)e;
+        double* o = O.out_pose + 12 * (size_t)e;
         for (int i = 0; i < 9; ++i) o[i] = R[i];
         for (int i = 0; i < 3; ++i) o[9 + i] = W.pose[7 * (size_t)e + 4 + i];
     }
+    if (e < (int)(sizeof(BaState) / 8)) reinterpret_cast<unsigned long long*>(O.out_state)[e] = reinterpret_cast<const unsigned long long*>(W.st)[e];
 }
 
-// input poses R|t -> normalised quaternion (Converter::toSE3Quat -> SE3Quat(R,t))
-__global__ void k_import_poses(BaWin* wins, const double* const* in_pose) {
+// window set-up on the device: input poses R|t -> normalised quaternion (Converter::toSE3Quat -> SE3Quat(R,t)), points into
+// their working array, every edge active, LM state cleared
+__global__ __launch_bounds__(256) void k_import(BaWin* wins, const BaIo* io) {
     const BaWin& W = wins[blockIdx.y];
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const BaIo& I = io[blockIdx.y];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < W.n_edge) { W.e_active[k] = 1; W.e_out1[k] = 0; W.e_chi2[k] = 0.0; }
+    if (k < 3 * W.n_pt) W.pt[k] = I.in_pt[k];
+    if (k < (int)(sizeof(BaState) / 8)) reinterpret_cast<unsigned long long*>(W.st)[k] = 0ull;
     if (k >= W.n_kf) return;
-    const double* p = in_pose[blockIdx.y] + 12 * (size_t)k;
+    const double* p = I.in_pose + 12 * (size_t)k;
     double R[9], q[4];
     for (int i = 0; i < 9; ++i) R[i] = p[i];
     R_to_quat(R, q);
@@ -924,8 +992,10 @@ hipError_t bak_prepare(int Npad) {
                                (int)bak_ldlt_smem(Npad));
 }
 
-void bak_import(hipStream_t st, BaWin* wins, const double* const* in_pose, int max_kf, int nwin) {
-    hipLaunchKernelGGL(k_import_poses, dim3((max_kf + 63) / 64, nwin), dim3(64), 0, st, wins, in_pose);
+void bak_import(hipStream_t st, BaWin* wins, const BaIo* io, int max_kf, int max_pt, int max_edge, int Npad, int nwin) {
+    const int nb = std::max(std::max(max_edge, 3 * max_pt), std::max(max_kf, (int)(sizeof(BaState) / 8)));
+    hipLaunchKernelGGL(k_import, dim3((nb + 255) / 256, nwin), dim3(256), 0, st, wins, io);
+    hipLaunchKernelGGL(k_zero_operands, dim3(64, Npad / BA_TILE, nwin), dim3(256), 0, st, wins);
 }
 
 void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int stage, int max_it, int robust, bool gate) {
@@ -954,8 +1024,7 @@ void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int
     hipLaunchKernelGGL(k_decide, dim3(1, nwin), dim3(256), 0, st, wins);
 }
 
-void bak_final(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_edge, double* const* out_pose,
-               uint8_t* const* out_flag) {
-    const int nb = max_edge > max_kf ? max_edge : max_kf;
-    hipLaunchKernelGGL(k_final, dim3((nb + 255) / 256, nwin), dim3(256), 0, st, wins, out_pose, out_flag);
+void bak_final(hipStream_t st, BaWin* wins, const BaIo* io, int nwin, int max_kf, int max_pt, int max_edge) {
+    const int nb = std::max(std::max(max_edge, 3 * max_pt), std::max(max_kf, (int)(sizeof(BaState) / 8)));
+    hipLaunchKernelGGL(k_final, dim3((nb + 255) / 256, nwin), dim3(256), 0, st, wins, io);
 }

@@ -8,6 +8,8 @@
 #define BA_TILE 64          // Schur macro tile (rows/cols of S per workgroup)
 #define BA_KC 32            // k-depth of one staged slab
 #define BA_SPLITS 16        // split-K factor of the Schur GEMM
+#define BA_MAX_TILES 10     // 64-row tiles of the reduced system (slamit_ba_create refuses larger handles)
+#define BA_MAX_PANELS 20    // 32-column LDLt panels
 
 // LM control block of one window (device resident; the host only reads it back between chunks
 // of enqueued trial slots).  Mirrors the locals of OptimizationAlgorithmLevenberg::solve
@@ -43,6 +45,7 @@ struct BaState {
 #define BA_G __attribute__((address_space(1)))
 #else
 #define BA_G
+
 #endif
 struct BaWin {
     int32_t n_kf, n_pt, n_edge, n_free;
@@ -51,6 +54,13 @@ struct BaWin {
     int32_t Kpad;      // padded k extent (3 * n_pt rounded up to BA_KC * BA_SPLITS)
     int32_t n_part;    // partial-sum slots of the chi2 reduction
     double huber_delta, chi2_gate;
+    // Structure of the window (host, ba_api.hip), conservative for both stages.  Points are stored sorted by the first
+    // free keyframe that observes them, so the non-zeros of a 64-row tile of GA / GB sit in ONE k range, and the reduced
+    // system has a row envelope (first coupled column per pose) that LDLt without pivoting never leaves.
+    int32_t tile_alo[BA_MAX_TILES], tile_ahi[BA_MAX_TILES];   // k range (multiples of BA_KC) of GA's rows 64 t .. 64 t + 63
+    int32_t tile_blo[BA_MAX_TILES], tile_bhi[BA_MAX_TILES];   // ... of GB's (the tile that holds row nS = bl spans every point)
+    int16_t panel_hi[BA_MAX_PANELS];   // last matrix row with an entry in the 32 columns of LDLt panel i (>= the panel's last row)
+    int16_t back_lo[BA_MAX_PANELS];    // first column any row of panel i's 32 rows reaches (back-substitution)
     // vertices
     BA_G double* pose;      // n_kf x 7: q(x,y,z,w), t
     BA_G double* pose_bak;
@@ -84,5 +94,18 @@ struct BaWin {
     BA_G double* scale_part;// n_part partial sums of x(lambda x + b) over landmarks
     BA_G BaState* st;
 };
+
+// Where one window's inputs and outputs sit in its slab (device addresses): the host fills / reads them with ONE copy each.
+struct BaIo {
+    const double* in_pose;   // n_kf x 12 (R|t)
+    const double* in_pt;     // n_pt x 3, device point order
+    double* out_pose;        // n_kf x 12
+    double* out_pt;          // n_pt x 3, device point order
+    double* out_chi2;        // n_edge
+    uint8_t* out_flag;       // n_edge
+    uint8_t* out_out1;       // n_edge
+    BaState* out_state;
+};
+
 
 #endif

@@ -102,6 +102,9 @@ struct slamit_orb {
     slamit_orb_params p;
     int device;
     hipStream_t stream;
+    hipStream_t stream_b;     // side stream: the blur of a call runs beside its FAST / octree / orientation launches
+    hipEvent_t ev_pyr, ev_blur;
+    int overlap;              // 0: everything on one stream (SLAMIT_ORB_SERIAL=1)
     int nlevels;
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
     std::vector<int> per_level;
@@ -164,6 +167,9 @@ static void orb_free(slamit_orb* h) {
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
     for (int l = 0; l < ORB_MAX_LEVELS; ++l) { hipFree(h->d_rs_col[l]); hipFree(h->d_rs_row[l]); }
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
+    if (h->ev_pyr) hipEventDestroy(h->ev_pyr);
+    if (h->ev_blur) hipEventDestroy(h->ev_blur);
+    if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -296,6 +302,10 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
                                         (sizeof(unsigned long long) + 3 * sizeof(int)) * (h->cand_frame_stride + 64));
     ALLOC(h->d_scratch, h->scratch_bytes);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming);
+    h->overlap = getenv("SLAMIT_ORB_SERIAL") ? 0 : 1;
     if (e == hipSuccess && !empty) e = hipMemcpy(h->d_levels, h->levels.data(), sizeof(OrbLevel) * nl, hipMemcpyHostToDevice);
     {
         std::vector<uint32_t> cells;
@@ -529,6 +539,12 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
         }
     }
     prof_mark(h, st, ST_RESIZE, false);
+    if (h->overlap && h->prof_on != 1 && getenv("SLAMIT_ORB_FORK_EARLY")) {
+        HIP_TRY(hipEventRecord(h->ev_pyr, st));
+        HIP_TRY(hipStreamWaitEvent(h->stream_b, h->ev_pyr, 0));
+        orbk_blur(h->stream_b, h->d_levels, h->d_blur_tiles, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
+        HIP_TRY(hipEventRecord(h->ev_blur, h->stream_b));
+    }
     // K2: FAST + NMS + per-cell threshold fallback -> candidate lists
     prof_mark(h, st, ST_FAST, true);
     const bool strip = h->fast_jobs > 0 && src0_aligned;
@@ -544,6 +560,18 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
                   h->cand_frame_stride, cand_count, h->p.ini_th_fast, h->p.min_th_fast, h->max_wcell, h->max_hcell, nframes);
     }
     prof_mark(h, st, ST_FAST, false);
+    // K6: blur every level.  Only the descriptor pass reads it, and it only needs the pyramid: it runs on the side stream
+    // beside the octree / orientation launches (latency bound: a few hundred workgroups on 256 CUs) and joins before the
+    // descriptors.  FAST (issue bound, the kernel the roofline is quoted on) keeps the chip to itself.  While every stage
+    // is being timed (slamit_orb_profile(h, 1)) everything stays on one stream.
+    const bool side = h->overlap && h->prof_on != 1;
+    static const int fork_early = getenv("SLAMIT_ORB_FORK_EARLY") ? 1 : 0;
+    if (side && !fork_early) {
+        HIP_TRY(hipEventRecord(h->ev_pyr, st));
+        HIP_TRY(hipStreamWaitEvent(h->stream_b, h->ev_pyr, 0));
+        orbk_blur(h->stream_b, h->d_levels, h->d_blur_tiles, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
+        HIP_TRY(hipEventRecord(h->ev_blur, h->stream_b));
+    }
     // K4: octree
     prof_mark(h, st, ST_OCTREE, true);
     orbk_octree(st, h->d_levels, nl, h->d_cand, h->cand_frame_stride, cand_count, h->d_ws_xy, h->d_ws_node, h->d_lkp,
@@ -554,10 +582,13 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     orbk_ic_angle(st, h->d_levels, nl, d_gray, stride, frame_stride, h->d_pyr, h->d_lkp, h->kp_frame_stride, kp_count,
                   h->max_kp_level, nframes);
     prof_mark(h, st, ST_ANGLE, false);
-    // K6: blur every level
-    prof_mark(h, st, ST_BLUR, true);
-    orbk_blur(st, h->d_levels, h->d_blur_tiles, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
-    prof_mark(h, st, ST_BLUR, false);
+    if (side) {
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_blur, 0));
+    } else {
+        prof_mark(h, st, ST_BLUR, true);
+        orbk_blur(st, h->d_levels, h->d_blur_tiles, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
+        prof_mark(h, st, ST_BLUR, false);
+    }
     // K7: descriptors + output records
     prof_mark(h, st, ST_DESCRIBE, true);
     orbk_describe(st, h->d_levels, nl, h->d_blur, h->d_lkp, h->kp_frame_stride, kp_count, d_kps, d_desc, cap, d_n_out,

@@ -1563,7 +1563,8 @@ void orbk_fast_listed(hipStream_t st, const OrbLevel* host_levels, int nlevels, 
 
 // candidates kept in LDS: as many as fit beside the node arrays in half a CU's LDS (lists above that use the HBM workspace)
 int orbk_octree_key_cap(int node_cap) {
-    const long room = (long)OCT_LDS_BUDGET - (long)orbk_octree_node_bytes(node_cap);
+    static const long budget = getenv("SLAMIT_OCT_LDS_KB") ? 1024L * atol(getenv("SLAMIT_OCT_LDS_KB")) : (long)OCT_LDS_BUDGET;
+    const long room = budget - (long)orbk_octree_node_bytes(node_cap);
     return (int)std::min<long>(OCT_LDS_KEYS_MAX, std::max<long>(OCT_LDS_KEYS_MIN, room / 6)) & ~7;
 }
 size_t orbk_octree_smem(int node_cap) { return orbk_octree_node_bytes(node_cap) + (size_t)orbk_octree_key_cap(node_cap) * 6; }
