@@ -102,3 +102,42 @@ def test_degenerate_windows(opt):
     allfixed = dict(prob)
     allfixed["kf_fixed"] = np.ones(4, np.uint8)
     _close(opt.LocalBundleAdjustment(allfixed), ob.ba_solve(allfixed), "allfixed")
+
+
+def test_stop_flag_aborts_a_running_solve_within_a_millisecond_scale(opt):
+    """LocalMapping::InterruptBA (src/LocalMapping.cc:681-684) raises *pbStopFlag from the tracking thread while the
+    optimiser runs; g2o polls it before every iteration (core/sparse_optimizer.cpp:376).  Here LM slots are queued two
+    at a time and the flag is read before every chunk, with at most two chunks in flight: a raised flag must end the
+    call after a few slots (a few hundred microseconds each), not after the whole 5 + 10 iteration schedule."""
+    import threading
+    import time
+
+    prob = synth.synth_ba(50, 2000, 8)
+    big = api.Optimizer(64, 2048, len(prob["edge_kf"]) + 64, 1, 0)
+    t0 = time.perf_counter()
+    full = big.LocalBundleAdjustment(prob)
+    full_s = time.perf_counter() - t0          # includes the first-call warm-up: an upper bound
+    t0 = time.perf_counter()
+    full = big.LocalBundleAdjustment(prob)
+    full_s = time.perf_counter() - t0
+    assert sum(full["stats"]["n_its"]) >= 10
+    stop = np.zeros(1, np.uint8)
+    out = {}
+
+    def run():
+        out["r"] = big.LocalBundleAdjustment(prob, stop=stop)
+        out["t_end"] = time.perf_counter()
+
+    th = threading.Thread(target=run)
+    th.start()
+    time.sleep(0.35 * full_s)                  # somewhere inside the robust stage
+    t_flag = time.perf_counter()
+    stop[0] = 1
+    th.join(10)
+    assert not th.is_alive()
+    latency = out["t_end"] - t_flag
+    its = sum(out["r"]["stats"]["n_its"])
+    assert its < sum(full["stats"]["n_its"]), "the stop flag did not shorten the schedule (%d its)" % its
+    # <= 4 queued slots + result download; 2.5 ms leaves room for a slow box (a full solve takes ~4 ms)
+    assert latency < min(2.5e-3, 0.8 * full_s), "stop latency %.2f ms (full solve %.2f ms)" % (1e3 * latency, 1e3 * full_s)
+    big.close()
