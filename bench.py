@@ -13,12 +13,18 @@ summary is all-gathered over RCCL.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config pipeline [--streams 8]      # BASELINE configs[4]: 8 x 720p streams + per-GPU local BA + slot gather
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import platform
+import re
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,48 +38,98 @@ FAST_BYTES_PER_FRAME = 950532        # 1 B per pyramid pixel, 
 CONFIGS = {  # name: (width, height, nfeatures, algorithmic FAST bytes per frame, BASELINE.json config)
     "vga": (640, 480, 1000, 950532, "configs[1]"),
     "720p": (1280, 720, 2000, 2853088, "configs[2]"),
+    "pipeline": (1280, 720, 2000, 2853088, "configs[4]"),
 }
+# algorithmic flops of the Schur complement per LM trial (50 KF x 2000 points, mono edges)
+SCHUR_ALGO_MFLOP = {"window8": 17.9, "dense": 565.0}
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
 
-def measured_traffic(batch):
-    """HBM bytes per launch of the FAST kernel from the committed rocprofv3 PMC summary
-    (profiles/r01_hbm_traffic.json, produced by tools/collect_profiles.sh on the same kernel);
-    FETCH_SIZE + WRITE_SIZE, scaled to this run's frames per launch.  None if absent."""
+def _sha16(path):
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-        k = [v for n, v in doc["kernels"].items() if n.startswith("fast_cells_kernel")][0]
-        kb = k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]
-        return int(kb * 1024 * batch / doc["frames_per_launch"])
-    except Exception:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
         return None
 
 
-def cpu_baseline(frames_a, frames_b, nfeat=1000, budget_s=12.0, min_frames=16):
-    """The CPU oracle (port of the reference path) on one host core over a bounded sample of the
-    same workload: extract frame A_i, extract B_i, match B_i against A_i."""
+def measured_traffic(batch):
+    """HBM bytes per launch of the FAST kernel from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_hbm_traffic.json, tools/collect_profiles.sh + tools/summarize_profiles.py): FETCH_SIZE + WRITE_SIZE,
+    scaled to this run's frames per launch.  (None, reason) when there is no summary or when it was taken on a different
+    version of the kernel source (the summary records the source's hash): a stale number is worse than none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None, "no profiles/r*_hbm_traffic.json"
+    path = files[-1]
+    try:
+        doc = json.load(open(path))
+        k = [v for n, v in doc["kernels"].items() if n.startswith("fast_cells_kernel")][0]
+        kb = k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]
+        rel = os.path.relpath(path, ROOT)
+        sha = _sha16(os.path.join(ROOT, "weiner_slamit_v2_amd", "csrc", "orb_kernels.hip"))
+        if doc.get("kernel_src_sha16") != sha:
+            return None, "%s was taken on another version of csrc/orb_kernels.hip (%s, now %s)" % (rel, doc.get("kernel_src_sha16"), sha)
+        return int(kb * 1024 * batch / doc["frames_per_launch"]), "%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch; kernel source %s)" % (rel, sha)
+    except Exception as e:
+        return None, "unreadable %s: %r" % (path, e)
+
+
+def cpu_info():
+    """What the CPU comparators ran on and how they were built (SURVEY 8d asks for both)."""
+    model = platform.processor() or ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    flags = ""
+    try:
+        mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+        flags = re.search(r"^NATIVE_CXXFLAGS \?= (.*)$", mk, re.M).group(1)
+    except Exception:
+        pass
+    try:
+        cxx = subprocess.check_output(["g++", "--version"], text=True).splitlines()[0]
+    except Exception:
+        cxx = "g++ (unknown)"
+    return {"model": model, "logical_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "compiler": cxx, "flags": flags}
+
+
+def cpu_baseline(frames_a, frames_b, nfeat=1000, budget_s=12.0, min_frames=24):
+    """The CPU port of the reference path on ONE host core over a bounded sample of the same workload: extract frame
+    A_i, extract B_i, match B_i against A_i.  Timed on the comparator build of the oracle (-O3 -march=native, compiled on
+    the machine it runs on; the strict -O2 build stays the parity checker) after 3 warm-up frames; `value` is frames per
+    second over the median per-frame time of >= 20 timed frames."""
     from oracle import bindings as ob
 
+    native = ob.use_native_comparator()
     orc = ob.OrbOracle(nfeat, 1.2, NLEVELS, 20, 7)
-    t0 = time.perf_counter()
-    n = 0
-    prev = None
-    i = 0
+    times, prev, i = [], None, 0
+    t_start = time.perf_counter()
     while True:
         src = frames_a if (i // len(frames_a)) % 2 == 0 else frames_b
+        t0 = time.perf_counter()
         _, d = orc.extract(src[i % len(frames_a)])
         if prev is not None:
             ob.best2(d, prev)
+        dt = time.perf_counter() - t0
         prev = d
-        n += 1
+        if i >= 3:
+            times.append(dt)
         i += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s and n >= min_frames:
+        if time.perf_counter() - t_start >= budget_s and len(times) >= min_frames:
             break
-    return {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic %dx%d frames, oracle extract (%d feat, 8 lvl) + all-pairs best2 vs previous frame, %.1f s" % (
-                n, frames_a[0].shape[1], frames_a[0].shape[0], nfeat, el)}
+    med = statistics.median(times)
+    return {"value": round(1.0 / med, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "build": "oracle/liborb_oracle_native.so" if native else "oracle/liborb_oracle.so (-O2: the native comparator did not build)",
+            "median_ms_per_frame": round(1e3 * med, 3), "mean_ms_per_frame": round(1e3 * sum(times) / len(times), 3),
+            "sample": "%d synthetic %dx%d frames after 3 warm-ups, oracle extract (%d feat, 8 lvl) + all-pairs best2 vs previous frame, %.1f s" % (
+                len(times), frames_a[0].shape[1], frames_a[0].shape[0], nfeat, time.perf_counter() - t_start)}
 
 
 def cpu_baseline_all_cores(frames_a, frames_b, nfeat=1000, budget_s=8.0):
@@ -192,10 +248,14 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real runs; gloo only to rehearse the multi-rank flow with ranks sharing one GPU")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="vga",
-                    help="vga = the headline metric's configuration; 720p = BASELINE configs[2] (profiling run)")
+                    help="vga = the headline metric's configuration; 720p = BASELINE configs[2] (profiling run); "
+                         "pipeline = BASELINE configs[4]: --streams 720p streams dealt over the ranks (stream s on rank s %% N), "
+                         "each rank also solving its streams' local-BA windows, results gathered in fixed-capacity slots")
+    ap.add_argument("--streams", type=int, default=8, help="pipeline config: total camera streams over all ranks")
     args = ap.parse_args()
     global W, H, NFEAT, FAST_BYTES_PER_FRAME
     W, H, NFEAT, FAST_BYTES_PER_FRAME, cfg_name = CONFIGS[args.config]
+    pipeline = args.config == "pipeline"
 
     import torch
     import torch.distributed as dist
@@ -219,11 +279,22 @@ def main():
 
     from weiner_slamit_v2_amd import api, shard, synth
 
-    B = args.batch
-    # each rank owns its own B streams (different seeds per rank); two consecutive frames per stream
-    uniq = min(B, 16)
-    fa = [synth.synth_frame(W, H, 1000 * rank + i) for i in range(uniq)]
-    fb = [synth.warp_frame(fa[i], 1000 * rank + i) for i in range(uniq)]
+    if pipeline:
+        # strong scaling: a fixed set of streams, stream s on rank s % world; every stream has its own frames
+        if args.streams % world:
+            raise SystemExit("--streams must be a multiple of the number of ranks")
+        mine = shard.stream_assignment(args.streams, world, rank)
+        B = len(mine)
+        uniq = B
+        fa = [synth.synth_frame(W, H, 5000 + sid) for sid in mine]
+        fb = [synth.warp_frame(fa[i], 5000 + sid) for i, sid in enumerate(mine)]
+    else:
+        B = args.batch
+        # each rank owns its own B streams (different seeds per rank); two consecutive frames per stream; 16 distinct
+        # frame pairs per rank, each used by B / 16 streams (the kernels are issue bound: content repeats do not help them)
+        uniq = min(B, 16)
+        fa = [synth.synth_frame(W, H, 1000 * rank + i) for i in range(uniq)]
+        fb = [synth.warp_frame(fa[i], 1000 * rank + i) for i in range(uniq)]
     frames = [np.stack([f[i % uniq] for i in range(B)]) for f in (fa, fb)]
     d_frames = [torch.from_numpy(f).to(dev) for f in frames]
 
@@ -237,6 +308,16 @@ def main():
     d_best = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_second = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     gather = shard.SummaryGather(B, 2, cdev, world)  # per-frame (keypoints, matches) to every rank
+    slots = ba_opt = ba_probs = None
+    ba_its = [0]
+    if pipeline:
+        # every stream also owns a local-BA window (BASELINE configs[3] geometry, window-8 visibility); the rank's windows are
+        # solved as one batch on the BA handle's own HIP stream, from a host thread, beside the extract + match launches
+        import threading
+        slots = shard.SlotGather(B, cdev, world)
+        ba_probs = [synth.synth_ba(50, 2000, 8, seed=12345 + sid) for sid in mine]
+        ba_opt = api.Optimizer(64, 2048, max(len(p["edge_kf"]) for p in ba_probs) + 64, B, dev.index)
+        ba_opt.LocalBundleAdjustmentBatch(ba_probs)   # warm-up: pinned block, kernels
     # ONE non-default stream carries the whole step: extract(k) -> match(k) are ordered by the stream.  (A NULL
     # stream handle would mean "the extractor's own stream" to the C-ABI and un-order the two calls.)
     tstream = torch.cuda.Stream(dev)
@@ -249,13 +330,34 @@ def main():
         ext.extract_batch_dev(d_frames[cur], d_kps[cur], d_desc[cur], d_n[cur], stream=stream)
         api.ORBmatcher.best2_batch_dev(d_desc[cur], d_n[cur], d_desc[prv], d_n[prv], d_idx, d_best, d_second,
                                        cap, device=dev.index, stream=stream)
-        if world > 1:  # result summary to every rank (the only cross-GPU traffic of the path)
+        if pipeline:
+            ba_out = {}
+            th = threading.Thread(target=lambda: ba_out.setdefault("r", ba_opt.LocalBundleAdjustmentBatch(ba_probs)))
+            th.start()                                  # ctypes releases the GIL inside the solve
+        if world > 1 and not pipeline:  # result summary to every rank (the only cross-GPU traffic of the path)
             gather.local[:, 0] = d_n[cur]
             gather.step()
+        if pipeline:
+            # fixed-capacity result slots: header, first 2000 keypoints + descriptors, the window's 50 poses
+            th.join()
+            n_kp = torch.clamp(d_n[cur], max=shard.SLOT_KP_CAP)
+            acc = ((d_best <= 50) & (d_best.float() < 0.9 * d_second.float()) & (torch.arange(cap, device=dev)[None, :] < d_n[cur][:, None])).sum(1).to(torch.int32)
+            hdr = torch.stack([n_kp, acc, torch.tensor([sum(r["stats"]["n_its"]) for r in ba_out["r"]], dtype=torch.int32, device=dev),
+                               torch.tensor(mine, dtype=torch.int32, device=dev)], 1)
+            poses = torch.from_numpy(np.stack([shard.rt_to_quat_t(r["kf_pose"]) for r in ba_out["r"]])).to(dev)
+            ba_its[0] += sum(sum(r["stats"]["n_its"]) for r in ba_out["r"])
+            if cdev.type == "cpu":   # gloo rehearsal: the slots live on the host
+                slots.header().copy_(hdr.cpu()); slots.keypoints().copy_(d_kps[cur][:, :shard.SLOT_KP_CAP].cpu())
+                slots.descriptors().copy_(d_desc[cur][:, :shard.SLOT_KP_CAP].cpu()); slots.ba_poses().copy_(poses.cpu())
+            else:
+                slots.header().copy_(hdr); slots.keypoints().copy_(d_kps[cur][:, :shard.SLOT_KP_CAP])
+                slots.descriptors().copy_(d_desc[cur][:, :shard.SLOT_KP_CAP]); slots.ba_poses().copy_(poses)
+            slots.step()
 
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize(dev)
+    ba_its[0] = 0
     ext.profile(5)   # timed region: events around the dominant kernel (FAST) only, on every 4th step
     m0 = torch.cuda.Event(enable_timing=True)
     m1 = torch.cuda.Event(enable_timing=True)
@@ -266,19 +368,25 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         step(k)
-    if world > 1:
+    last_slots = None
+    if world > 1 and not pipeline:
         gather.flush()   # the last step's summary is part of the timed work
+    if pipeline:
+        last_slots = slots.flush()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    ba_its_timed = ba_its[0]
     stages = ext.profile(1)
     # per-stage breakdown: a separate, untimed pass with events around every stage
-    for k in range(args.warmup + args.steps, args.warmup + args.steps + 5):
+    for k in range(args.warmup + args.steps, args.warmup + args.steps + (1 if pipeline else 5)):
         step(k)
-    if world > 1:
+    if world > 1 and not pipeline:
         gather.flush()
+    if pipeline:
+        slots.flush()
     torch.cuda.synchronize(dev)
     all_stages = ext.profile(0)
 
@@ -296,13 +404,20 @@ def main():
     # sanity of the timed work: every frame produced its keypoints and matches
     n_last = d_n[(args.warmup + args.steps - 1) & 1].cpu().numpy()
     assert (n_last >= NFEAT).all(), "extractor returned too few keypoints: %s" % n_last[:8]
+    if pipeline:   # every stream's slot arrived on this rank, with its keypoints, descriptors and BA poses
+        hdr = slots.header(last_slots).cpu().numpy()
+        assert sorted(hdr[:, 3].tolist()) == list(range(args.streams)), hdr[:, 3]
+        assert (hdr[:, 0] == shard.SLOT_KP_CAP).all() and (hdr[:, 2] > 0).all(), hdr[:, :3]
+        q = slots.ba_poses(last_slots)[:, :, :4].cpu().numpy()
+        assert np.allclose((q * q).sum(2), 1.0, atol=1e-9), "BA slot poses are not unit quaternions"
 
     if rank == 0:
         fast_ms, fast_calls = stages["fast"]
         fast_avg_ms = fast_ms / max(fast_calls, 1)
         achieved = FAST_BYTES_PER_FRAME * B / (fast_avg_ms * 1e-3) / 1e9 if fast_avg_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(B) if args.config == "vga" else (None, "only collected for the vga configuration")
         out = {
-            "metric": "frames/sec ORB extract+match @%dx%dx8lvl" % (W, H),
+            "metric": ("frames/sec ORB extract+match @%dx%dx8lvl" % (W, H)) + (" + per-stream local BA, %d streams" % args.streams if pipeline else ""),
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "frames/s",
             "n_gpus": world,
@@ -310,28 +425,36 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if pipeline else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "BASELINE %s: %dx%d 8-level ORB extract (%d features, FAST 20/7) + "
                                    "brute-force 256-bit Hamming best/second match vs the stream's previous frame; "
-                                   "%d independent streams per GPU per step" % (cfg_name, W, H, NFEAT, B),
-                       "frames_per_step_per_gpu": B, "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world},
+                                   "%d independent streams per GPU per step" % (cfg_name, W, H, NFEAT, B) +
+                                   ("; every stream also solves one local-BA window (50 KF, 2000 points, window-8) per step on the BA "
+                                    "handle's own HIP stream; every stream's result slot (count + 2000 keypoints + 2000 descriptors + "
+                                    "50 poses, %d B) is all_gathered to every rank, one step late" % shard.SLOT_BYTES if pipeline else ""),
+                       "frames_per_step_per_gpu": B, "distinct_frame_pairs_per_gpu": uniq,
+                       "parallelism": ("stream s on rank s %% %d, results gathered over RCCL" % world) if pipeline else
+                                      "streams sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"kernel": "fast_cells_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(B) if args.config == "vga" else None,
-                         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)",
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(fast_avg_ms, 5), "launches": fast_calls,
                          "timing": "HIP events on the launch stream around every 4th launch of the timed region (an event pair drains the pipeline for ~20 us)",
                          "algorithmic_bytes_per_launch": FAST_BYTES_PER_FRAME * B},
             "stage_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in all_stages.items()},
             "match_ms_per_step": round(match_ms, 4),
         }
+        if pipeline:
+            out["secondary"] = {"metric": "local-BA LM iterations/sec inside the pipeline (one window-8 window per stream and step)",
+                                "unit": "iters/s", "value": round(world * ba_its_timed / elapsed, 1), "note": "this rank's count x ranks"}
         if not args.no_cpu and world == 1:   # CPU comparators: rank 0 at N = 1 only
+            out["cpu"] = cpu_info()
             out["cpu_baseline"] = cpu_baseline(fa, fb, NFEAT)
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(fa, fb, NFEAT)
-        if not args.no_ba and world == 1:
+        if not args.no_ba and world == 1 and not pipeline:
             out["secondary"] = ba_secondary(dev.index, args.steps, with_cpu=not args.no_cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -36,13 +36,30 @@ def _ptr(a, t=_u8p):
 
 
 _orb = None
+_orb_name = "liborb_oracle.so"
+
+
+def use_native_comparator():
+    """bench.py's cpu_baseline only: (re)builds liborb_oracle_native.so (-O3 -march=native) ON THIS HOST and makes the
+    ORB oracle load it from now on.  Timing comparator, never the parity checker (tests keep the strict -O2 build).
+    Returns False (and keeps the strict build) when it cannot be built."""
+    global _orb, _orb_name
+    try:
+        path = os.path.join(HERE, "liborb_oracle_native.so")
+        if os.path.exists(path):
+            os.remove(path)        # a copy built on another host may use instructions this one lacks
+        subprocess.check_call(["make", "-s", "-C", HERE, "-f", os.path.join(HERE, "Makefile"), "native"])
+        _orb, _orb_name = None, "liborb_oracle_native.so"
+        return True
+    except Exception:
+        return False
 
 
 def orb_lib():
     global _orb
     if _orb is None:
         build()
-        L = C.CDLL(os.path.join(HERE, "liborb_oracle.so"))
+        L = C.CDLL(os.path.join(HERE, _orb_name))
         L.orb_oracle_create.restype = C.c_void_p
         L.orb_oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.orb_oracle_destroy.argtypes = [C.c_void_p]

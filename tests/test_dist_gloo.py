@@ -44,6 +44,36 @@ def _worker(rank, world, port, q):
         assert t == float(world)
         strong = shard.stream_assignment(8, world, rank)
         assert strong == list(range(rank, 8, world))
+        # fixed-capacity result slots of the 8-stream pipeline: layout + one-step-late gather
+        assert shard.SLOT_BYTES % 256 == 0 and shard.SLOT_BYTES >= 16 + 2000 * (28 + 32) + 50 * 7 * 8
+        sg = shard.SlotGather(len(strong), torch.device("cpu"), world)
+        def fill(step):
+            h = sg.header()
+            for i, sid in enumerate(strong):
+                h[i, 0], h[i, 1], h[i, 2], h[i, 3] = 1900 + sid, 100 * step + sid, step, sid
+                sg.keypoints()[i, :, 0] = float(sid) + 0.5
+                sg.keypoints()[i, :, 5].view(torch.int32)[:] = step
+                sg.descriptors()[i, :, :] = (7 * sid + step) % 256
+                sg.ba_poses()[i, :, :] = sid + step / 16.0
+        def check_slots(allb, step):
+            assert allb.shape == (8, shard.SLOT_BYTES)
+            h = sg.header(allb)
+            for row in range(8):
+                sid = int(h[row, 3])
+                assert sid == (row // len(strong)) + world * (row % len(strong))   # rank-major rows, stream s on rank s % world
+                assert h[row].tolist() == [1900 + sid, 100 * step + sid, step, sid]
+                assert float(sg.keypoints(allb)[row, 1999, 0]) == sid + 0.5
+                assert int(sg.keypoints(allb)[row, 0, 5].view(torch.int32)) == step
+                assert int(sg.descriptors(allb)[row, 1999, 31]) == (7 * sid + step) % 256
+                assert float(sg.ba_poses(allb)[row, 49, 6]) == sid + step / 16.0
+        for step in range(3):
+            fill(step)
+            prev = sg.step()
+            if step:
+                check_slots(prev, step - 1)
+            else:
+                assert prev is None
+        check_slots(sg.flush(), 2)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

@@ -41,3 +41,21 @@ def test_bench_two_rank_rehearsal():
     d = _line(out)
     assert d["n_gpus"] == 2 and d["steps"] == 3
     assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # whole-job aggregate over both ranks
+
+
+def test_bench_pipeline_config_single_gpu_and_two_rank_rehearsal():
+    """BASELINE configs[4] as bench.py runs it: 8 x 720p streams dealt over the ranks (stream s on rank s % N), every rank
+    also solving its streams' local-BA windows beside the extractor, every stream's fixed-capacity result slot gathered
+    to every rank.  bench.py itself asserts that all 8 slots arrived with 2000 keypoints and unit-quaternion BA poses."""
+    out = subprocess.check_output([sys.executable, "bench.py", "--config", "pipeline", "--steps", "2", "--warmup", "1", "--no-cpu"], cwd=ROOT,
+                                  stderr=subprocess.STDOUT, timeout=600)
+    d = _line(out)
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["frames_per_step_per_gpu"] == 8
+    assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01 and d["secondary"]["value"] > 0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29717", "bench.py", "--gpus", "2", "--config", "pipeline", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu"]
+    out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=900, env=env)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step_per_gpu"] == 4
+    assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01   # 8 streams in all, whatever the rank count

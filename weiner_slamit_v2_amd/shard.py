@@ -63,6 +63,92 @@ class SummaryGather:
         return out
 
 
+# ---- fixed-capacity result slots: what a rank publishes per stream and step ----------------------
+SLOT_KP_CAP = 2000                      # keypoints kept per frame (the extractor may return up to nfeatures + 3 per level)
+SLOT_KP_BYTES = 28                      # slamit_kp == cv::KeyPoint
+SLOT_DESC_BYTES = 32
+SLOT_BA_KF = 50                         # keyframes of a local-BA window
+SLOT_BA_DOUBLES = 7                     # pose as unit quaternion (x, y, z, w) + translation
+SLOT_OFF_COUNT = 0                      # int32 keypoints, int32 matches, int32 BA iterations, int32 stream id
+SLOT_OFF_KP = 16
+SLOT_OFF_DESC = SLOT_OFF_KP + SLOT_KP_CAP * SLOT_KP_BYTES
+SLOT_OFF_BA = SLOT_OFF_DESC + SLOT_KP_CAP * SLOT_DESC_BYTES
+SLOT_BYTES = (SLOT_OFF_BA + SLOT_BA_KF * SLOT_BA_DOUBLES * 8 + 255) // 256 * 256
+
+
+class SlotGather:
+    """Every rank's per-stream result slots to every rank, one `all_gather_into_tensor` per step, issued asynchronously and
+    consumed one step late (like SummaryGather).  A slot is SLOT_BYTES of uint8:
+        [0:16)   int32 x 4: keypoint count (clamped to SLOT_KP_CAP), accepted matches, BA iterations, global stream id
+        [16: )   SLOT_KP_CAP keypoints of 28 bytes (x, y, size, angle, response: float32; octave, class_id: int32)
+        then     SLOT_KP_CAP descriptors of 32 bytes
+        then     SLOT_BA_KF x 7 float64: the window's optimised keyframe poses (quaternion x y z w, translation)
+    No reduction is needed for correctness: streams are independent, the gather only makes every result visible everywhere."""
+
+    def __init__(self, rows, device, world):
+        self.world, self.rows = world, rows
+        self._loc = [torch.zeros((rows, SLOT_BYTES), dtype=torch.uint8, device=device) for _ in range(2)]
+        self._all = [torch.zeros((world * rows, SLOT_BYTES), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else self._loc
+        self._k = 0
+        self._pending = None
+
+    @property
+    def local(self):
+        return self._loc[self._k & 1]
+
+    def header(self, buf=None):
+        """int32 view [rows, 4] of the slots' headers (of `buf`, default the local slots being filled)."""
+        b = self.local if buf is None else buf
+        return b[:, SLOT_OFF_COUNT:SLOT_OFF_KP].view(torch.int32)
+
+    def keypoints(self, buf=None):
+        b = self.local if buf is None else buf
+        return b[:, SLOT_OFF_KP:SLOT_OFF_DESC].view(torch.float32).view(b.shape[0], SLOT_KP_CAP, 7)
+
+    def descriptors(self, buf=None):
+        b = self.local if buf is None else buf
+        return b[:, SLOT_OFF_DESC:SLOT_OFF_BA].view(b.shape[0], SLOT_KP_CAP, SLOT_DESC_BYTES)
+
+    def ba_poses(self, buf=None):
+        b = self.local if buf is None else buf
+        return b[:, SLOT_OFF_BA:SLOT_OFF_BA + SLOT_BA_KF * SLOT_BA_DOUBLES * 8].view(torch.float64).view(b.shape[0], SLOT_BA_KF, SLOT_BA_DOUBLES)
+
+    def step(self):
+        """Publishes the local slots; returns every rank's slots of the PREVIOUS step (None on the first call)."""
+        prev = self.flush()
+        cur = self._k & 1
+        if self.world > 1:
+            self._pending = (dist.all_gather_into_tensor(self._all[cur], self._loc[cur], async_op=True), self._all[cur])
+        else:
+            self._pending = (None, self._loc[cur])
+        self._k += 1
+        return prev
+
+    def flush(self):
+        if self._pending is None:
+            return None
+        work, out = self._pending
+        if work is not None:
+            work.wait()
+        self._pending = None
+        return out
+
+
+def rt_to_quat_t(rt):
+    """n x 12 (R row-major | t) -> n x 7 (quaternion x y z w | t), numpy; the BA slot's pose format."""
+    import numpy as np
+
+    rt = np.asarray(rt, np.float64).reshape(-1, 12)
+    R = rt[:, :9].reshape(-1, 3, 3)
+    q = np.zeros((len(rt), 4))
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    q[:, 3] = np.sqrt(np.maximum(1.0 + tr, 0.0)) / 2
+    q[:, 0] = np.copysign(np.sqrt(np.maximum(1.0 + R[:, 0, 0] - R[:, 1, 1] - R[:, 2, 2], 0.0)) / 2, R[:, 2, 1] - R[:, 1, 2])
+    q[:, 1] = np.copysign(np.sqrt(np.maximum(1.0 - R[:, 0, 0] + R[:, 1, 1] - R[:, 2, 2], 0.0)) / 2, R[:, 0, 2] - R[:, 2, 0])
+    q[:, 2] = np.copysign(np.sqrt(np.maximum(1.0 - R[:, 0, 0] - R[:, 1, 1] + R[:, 2, 2], 0.0)) / 2, R[:, 1, 0] - R[:, 0, 1])
+    return np.concatenate([q, rt[:, 9:12]], 1)
+
+
 def max_over_ranks(value, device, world):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     if world > 1:
