@@ -11,6 +11,8 @@
 #include <limits.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/slamit.h"
@@ -205,9 +207,12 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
     std::vector<BaWin> wins(nwin);
     std::vector<BaIo> io(nwin);
     std::vector<std::vector<int32_t> > perm(nwin);   // device point index -> caller's point index
-    for (int b = 0; b < nwin; ++b) {
+    // per-window preparation (structure, CSR lists, packing into the pinned block) is host work of ~10 ns per edge: windows
+    // are independent, so a batch is prepared by a few host threads; the copies are queued afterwards, in order
+    auto prepare = [&](int b) {
         const slamit_ba_problem& P = probs[b];
         uint8_t* slab = h->d_slab + (size_t)b * h->win_bytes;
+        (void)slab;
         BaWin& w = wins[b];
         memset(&w, 0, sizeof(w));
         carve_work(slab + h->io_cap, w, h->max_kf, h->max_pt, h->max_edge, h->Npad_max, h->Kpad_max, h->n_part);
@@ -227,7 +232,6 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
         w.n_part = h->n_part;
         w.huber_delta = opts->huber_delta; w.chi2_gate = opts->chi2_gate;
         w.st = h->d_states + b;
-        Npad = std::max(Npad, w.Npad);
         // ---- structure of the window (g2o's BlockSolver / SimplicialLDLT exploit the same sparsity on the CPU,
         // block_solver.hpp:381-432, linear_solver_eigen.h:94-124) ----
         // Points are stored on the device sorted by the first free keyframe that observes them: the rows of GA / GB that
@@ -300,7 +304,22 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             std::vector<int32_t> pc(pptr, pptr + P.n_pt), kc(kptr, kptr + P.n_kf);
             for (int e = 0; e < P.n_edge; ++e) { H.pt_edges[pc[H.e_pt[e]]++] = e; H.kf_edges[kc[P.edge_kf[e]]++] = e; }
         }
-        HIP_TRY(hipMemcpyAsync(slab, h->h_pin + in_off[b], D.in_bytes, hipMemcpyHostToDevice, st));
+    };
+    {
+        const int nthreads = std::max(1, std::min(std::min(nwin, 16), (int)std::thread::hardware_concurrency()));
+        if (nthreads <= 1) {
+            for (int b = 0; b < nwin; ++b) prepare(b);
+        } else {
+            std::atomic<int> next(0);
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; ++t)
+                pool.emplace_back([&]() { for (int b = next.fetch_add(1); b < nwin; b = next.fetch_add(1)) prepare(b); });
+            for (std::thread& t : pool) t.join();
+        }
+    }
+    for (int b = 0; b < nwin; ++b) {
+        Npad = std::max(Npad, wins[b].Npad);
+        HIP_TRY(hipMemcpyAsync(h->d_slab + (size_t)b * h->win_bytes, h->h_pin + in_off[b], dio[b].in_bytes, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipMemcpyAsync(h->d_wins, wins.data(), sizeof(BaWin) * nwin, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(h->d_io, io.data(), sizeof(BaIo) * nwin, hipMemcpyHostToDevice, st));
