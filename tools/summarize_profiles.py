@@ -1,56 +1,126 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/prof_<tag>/ (written by tools/collect_profiles.sh on the MI355X box) into the committed
-summaries under profiles/:  <tag>_bench.json, <tag>_bench_kernel_stats.csv, <tag>_hbm_traffic.json.
+"""Turns gpurun_out/prof_<tag>/ (written by tools/collect_profiles.sh on the MI355X box) into the committed summaries
+under profiles/:
 
-    python tools/summarize_profiles.py r01 [frames_per_launch]
+    <tag>_bench.json, <tag>_bench_720p.json, <tag>_bench_pipeline.json      the bench lines
+    <tag>_bench_kernel_stats.csv, <tag>_bench_720p_kernel_stats.csv,
+    <tag>_ba_kernel_stats.csv                                               rocprofv3 --kernel-trace --stats
+    <tag>_hbm_traffic.json        FETCH_SIZE / WRITE_SIZE per launch and kernel (+ the hash of the kernel source)
+    <tag>_fast_issue.json         SQ instruction-issue counters of the shipped FAST kernel, VGA x 64 and 720p x 64
+    <tag>_ba_mfma.json            matrix-core counters of the local-BA kernels per grid shape (single window / batch)
+
+    python tools/summarize_profiles.py r02 [frames_per_launch]
 
 FETCH_SIZE / WRITE_SIZE come from separate --pmc passes (they do not fit one pass) and are averaged per launch and
 kernel.  Units: rocprofv3 reports KB (bytes = value * 1024).  gfx950 caveat (MI355X_MICROARCH.md, HBM section):
 FETCH_SIZE halves wide 16-B/lane streaming reads; the ORB kernels read 1-4 B per lane, an uncalibrated width, so the
 values are reported as measured and the comparison with the algorithmic byte count is indicative."""
+import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SKIP = ("__amd_rocclr", "at::native", "Cijk", "ncclDevKernel")
+
+
+def newest(path, pattern):
+    f = glob.glob(os.path.join(path, "**", pattern), recursive=True)
+    return max(f, key=os.path.getmtime) if f else None
+
+
+def kname(row):
+    return row["Kernel_Name"].split("(")[0].replace("void ", "")
 
 
 def per_kernel(path, counter):
-    f = glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
+    f = newest(path, "*counter_collection.csv")
     if not f:
         return {}
     acc = {}
-    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
+    for r in csv.DictReader(open(f)):
         if r.get("Counter_Name") != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        d = acc.setdefault(k, {})
+        d = acc.setdefault(kname(r), {})
         key = r.get("Dispatch_Id")
         d[key] = d.get(key, 0.0) + float(r["Counter_Value"])
     return {k: sum(v.values()) / len(v) for k, v in acc.items()}
 
 
+def counters_by_kernel_and_grid(path, want=None):
+    """{(kernel, grid): {counter: mean per launch, 'launches': n}}"""
+    f = newest(path, "*counter_collection.csv")
+    if not f:
+        return {}
+    acc = collections.defaultdict(lambda: collections.defaultdict(dict))
+    dur = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        k = kname(r)
+        if k.startswith(SKIP) or (want and not any(w in k for w in want)):
+            continue
+        key = (k, int(r["Grid_Size"]))
+        d = acc[key][r["Counter_Name"]]
+        d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+        dur[key][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    out = {}
+    for key, cs in acc.items():
+        out[key] = {c: sum(v.values()) / len(v) for c, v in cs.items()}
+        out[key]["launches"] = max(len(v) for v in cs.values())
+        out[key]["avg_us_in_counter_pass"] = sum(dur[key].values()) / len(dur[key])
+    return out
+
+
+def kernel_avg_us(path, name):
+    f = newest(path, "*kernel_stats.csv")
+    if not f:
+        return None
+    for r in csv.DictReader(open(f)):
+        if r["Name"].startswith(name) or r["Name"].replace("void ", "").startswith(name):
+            return float(r["AverageNs"]) / 1e3
+    return None
+
+
+def sha16(path):
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def copy_bench(src, name, dst):
+    p = os.path.join(src, name)
+    if not os.path.exists(p):
+        return False
+    lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+    if not lines:
+        return False
+    json.dump(json.loads(lines[-1]), open(dst, "w"), indent=1)
+    return True
+
+
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
-    if stats:
-        shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
-    bench = os.path.join(src, "bench.json")
-    if os.path.exists(bench):
-        line = [l for l in open(bench).read().splitlines() if l.startswith("{")][-1]
-        json.dump(json.loads(line), open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
+    done = []
+    for sub, out in (("trace", "_bench_kernel_stats.csv"), ("trace720", "_bench_720p_kernel_stats.csv"), ("ba_trace", "_ba_kernel_stats.csv")):
+        f = newest(os.path.join(src, sub), "*kernel_stats.csv")
+        if f:
+            shutil.copy(f, os.path.join(dst, tag + out)); done.append(out)
+    for name, out in (("bench.json", "_bench.json"), ("bench_720p.json", "_bench_720p.json"), ("bench_pipeline.json", "_bench_pipeline.json")):
+        if copy_bench(src, name, os.path.join(dst, tag + out)):
+            done.append(out)
+    # ---- HBM traffic ----
     fetch = per_kernel(os.path.join(src, "fetch"), "FETCH_SIZE")
     write = per_kernel(os.path.join(src, "write"), "WRITE_SIZE")
-    skip = ("__amd_rocclr", "at::native", "Cijk", "ncclDevKernel")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
-        if k.startswith(skip):
+        if k.startswith(SKIP):
             continue
         kernels[k] = {"FETCH_SIZE_KB_per_launch": round(fetch.get(k, 0.0), 1), "WRITE_SIZE_KB_per_launch": round(write.get(k, 0.0), 1)}
     if kernels:
@@ -59,9 +129,65 @@ def main():
                          "(bytes = value*1024). gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide 16-B/lane "
                          "streaming reads by 2x; these kernels read 1-4 B per lane, an uncalibrated width, so the values are reported "
                          "as measured." % frames,
-               "frames_per_launch": frames, "kernels": kernels}
-        json.dump(doc, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
-    print("profiles/%s_* written: %d kernels with counters, stats %s, bench %s" % (tag, len(kernels), bool(stats), os.path.exists(bench)))
+               "frames_per_launch": frames,
+               "kernel_src_sha16": sha16(os.path.join(ROOT, "weiner_slamit_v2_amd", "csrc", "orb_kernels.hip")),
+               "kernels": kernels}
+        json.dump(doc, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1); done.append("_hbm_traffic.json")
+    # ---- FAST issue counters ----
+    geo = {"vga": (640 * 480, 950532, "trace"), "720p": (1280 * 720, 2853088, "trace720")}
+    fast = {}
+    for cfg, (_, pyr_px, tr) in geo.items():
+        c = {}
+        for part in ("sq_a_", "sq_b_"):
+            for (k, grid), v in counters_by_kernel_and_grid(os.path.join(src, part + cfg), want=("fast_cells_kernel",)).items():
+                c.update({kk: vv for kk, vv in v.items() if kk not in ("launches", "avg_us_in_counter_pass")})
+        if not c:
+            continue
+        us = kernel_avg_us(os.path.join(src, tr), "fast_cells_kernel")
+        px = pyr_px * frames
+        e = {"pyramid_pixels_per_launch": px, "counters_per_launch": {k: round(v) for k, v in sorted(c.items())},
+             "avg_launch_us_rocprof": round(us, 2) if us else None}
+        if "SQ_INSTS_VALU" in c:
+            total = c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_SALU", 0) + c.get("SQ_INSTS_LDS", 0) + c.get("SQ_INSTS_VMEM_RD", 0)
+            e["valu_wave_instructions_per_pixel"] = round(c["SQ_INSTS_VALU"] / px, 4)
+            e["valu_lane_ops_per_pixel"] = round(64 * c["SQ_INSTS_VALU"] / px, 2)
+            e["all_wave_instructions_per_pixel"] = round(total / px, 4)
+            if us:
+                e["valu_instructions_per_simd_per_us"] = round(c["SQ_INSTS_VALU"] / 1024 / us, 1)
+                e["ns_per_valu_instruction_per_simd"] = round(1e3 * us * 1024 / c["SQ_INSTS_VALU"], 3)
+                e["achieved_GBps_algorithmic"] = round(px / us / 1e3, 1)
+                e["frac_of_8TBps"] = round(px / us / 1e3 / 8000.0, 4)
+        fast[cfg] = e
+    if fast:
+        doc = {"_about": "SQ counters of the shipped fast_cells_kernel (rocprofv3 --kernel-trace --pmc, two passes of 8 counters, `python3 "
+                         "bench.py --no-ba --no-cpu --config <cfg> --steps 3 --warmup 1`), means per launch of %d frames, with the launch duration of "
+                         "the --kernel-trace --stats run of the same build.  1024 SIMDs.  Measured issue cost on this chip "
+                         "(tools/diag/ubench, wall clock at 4 waves per SIMD): 2.29 ns per half-rate VALU wave-instruction per SIMD "
+                         "(v_lerp_u8, v_perm, v_pk_*, 3-operand integer ops), 1.53 ns per full-rate one (v_and/or/xor/add, v_bitop3)." % frames,
+               "kernel_src_sha16": sha16(os.path.join(ROOT, "weiner_slamit_v2_amd", "csrc", "orb_kernels.hip")), "geometries": fast}
+        json.dump(doc, open(os.path.join(dst, tag + "_fast_issue.json"), "w"), indent=1); done.append("_fast_issue.json")
+    # ---- BA matrix-core counters per kernel and grid shape ----
+    ba = counters_by_kernel_and_grid(os.path.join(src, "ba_mfma"), want=("k_schur", "k_ldlt_solve"))
+    if ba:
+        rows = []
+        for (k, grid), v in sorted(ba.items()):
+            us = v.pop("avg_us_in_counter_pass")
+            r = {"kernel": k, "grid_threads": grid, "launches": v.pop("launches"), "avg_us_in_counter_pass": round(us, 2)}
+            r.update({kk: round(vv) for kk, vv in sorted(v.items())})
+            # matrix-pipe busy cycles summed over the SIMDs / (1024 SIMDs x launch duration at the 2.4 GHz nominal clock)
+            r["mfma_busy_frac_of_chip"] = round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * us * 2400.0), 5)
+            r["executed_TFLOPs"] = round(v.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) * 512 / us / 1e6, 3)
+            rows.append(r)
+        doc = {"_about": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_WAVE_CYCLES "
+                         "SQ_WAVES -- python3 tools/bench_ba.py 2 (window-8 and dense 50 KF x 2000 pts, single windows and batches of 8), means per "
+                         "launch, split by grid size (threads): the small grids are single windows.  SQ_INSTS_VALU_MFMA_MOPS_F64 counts in units of "
+                         "512 flop; one v_mfma_f64_16x16x4_f64 is 2048 flop.  mfma_busy_frac_of_chip = SQ_VALU_MFMA_BUSY_CYCLES (summed over SIMDs) / "
+                         "(1024 SIMDs x duration x 2.4 GHz); executed_TFLOPs = MOPS x 512 / duration (fp64 MFMA peak 78.6).  A launch mixes window-8 "
+                         "and dense windows (tools/bench_ba.py runs both); SURVEY 8(d)'s ALGORITHMIC Schur flops per LM trial are 17.9 MFLOP "
+                         "(window-8) and 565 MFLOP (dense) per window.",
+               "rows": rows}
+        json.dump(doc, open(os.path.join(dst, tag + "_ba_mfma.json"), "w"), indent=1); done.append("_ba_mfma.json")
+    print("profiles/%s: %s" % (tag, " ".join(done)))
 
 
 if __name__ == "__main__":
