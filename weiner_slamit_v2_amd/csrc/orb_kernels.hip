@@ -507,6 +507,8 @@ __device__ __forceinline__ void fast_cell_wave(
         const int Kv = (T + 1) >> 1;                       // 129..256
         const unsigned kc = (unsigned)(256 - Kv) * 0x01010101u;
         int nB = 0, nD = 0;   // survivor stacks: brighter-than-centre / darker-than-centre candidates, entry = y << 6 | x
+        int ncorner = 0;
+        bool corner_overflow = false;
         for (int i0 = 0; i0 < nitems; i0 += WAVE) {
             const int it = i0 + lane;
             unsigned pb = 0, pd = 0;
@@ -593,8 +595,22 @@ __device__ __forceinline__ void fast_cell_wave(
                 // brighter: (best arc minimum) - centre - 1; darker: centre - (best arc maximum) - 1; < t means "no corner at t"
                 const int slo = (int)(m & 255u) - (int)(ctr & 255u) - 1;
                 const int shi = (int)(ctr >> 16) - (int)((m >> 16) & 255u) - 1;
-                if (vlo && slo >= th) sc[__umul24(ylo + 1u, PITCH) + xlo + SC_COL0] = (uint8_t)slo;
-                if (vhi && shi >= th) sc[__umul24(yhi + 1u, PITCH) + xhi + SC_COL0] = (uint8_t)shi;
+                const bool clo = vlo && slo >= th, chi = vhi && shi >= th;
+                if (clo) sc[__umul24(ylo + 1u, PITCH) + xlo + SC_COL0] = (uint8_t)slo;
+                if (chi) sc[__umul24(yhi + 1u, PITCH) + xhi + SC_COL0] = (uint8_t)shi;
+                {   // the corners are also listed (in the keypoint array: NMS compacts it in place), so that NMS visits the
+                    // ~12 % of the pixels that are corners instead of all of them; a cell with more corners than the
+                    // array holds falls back to the pass over the whole score tile
+                    const unsigned long long m0 = __ballot(clo), m1 = __ballot(chi);
+                    const int add = __popcll(m0) + __popcll(m1);
+                    if (ncorner + add <= kp_cap) {
+                        const unsigned p0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, (unsigned)ncorner));
+                        const unsigned p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, (unsigned)(ncorner + __popcll(m0))));
+                        if (clo) s_kp[p0] = (unsigned short)elo;
+                        if (chi) s_kp[p1] = (unsigned short)ehi;
+                    } else corner_overflow = true;
+                    ncorner += add;
+                }
                 nB -= tb; nD -= td;
                 wave_sync_lds();
                 FD_STAMP(2);
@@ -603,6 +619,28 @@ __device__ __forceinline__ void fast_cell_wave(
         // NMS byte-parallel over the score tile, 4 pixels per lane: n >= s per byte  <=>  MSB of (n + ~s + 1) >> 1.
         // A pixel below t holds 0 and is beaten by any neighbour; columns / rows around the scan area hold 0.
         nkp = 0;
+        if (!corner_overflow) {
+            // NMS over the listed corners: strict > against the 8 neighbours' stored scores (0 below t / outside the scan
+            // area); kept entries are compacted in place (a pass reads its 64 entries before any of them is overwritten)
+            for (int i0 = 0; i0 < ncorner; i0 += WAVE) {
+                const int i = i0 + lane;
+                bool kept = false;
+                unsigned e = 0;
+                if (i < ncorner) {
+                    e = s_kp[i];
+                    const uint8_t* q = &sc[__umul24((e >> 6) + 1u, PITCH) + (e & 63u) + SC_COL0];
+                    const int v = q[0];
+                    int nb = imax3(q[-PITCH - 1], q[-PITCH], q[-PITCH + 1]);
+                    nb = imax3(nb, q[-1], q[1]);
+                    nb = max(nb, imax3(q[PITCH - 1], q[PITCH], q[PITCH + 1]));
+                    kept = v > nb;
+                }
+                wave_sync_lds();
+                const unsigned long long mk = __ballot(kept);
+                if (kept) s_kp[__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)nkp))] = (unsigned short)e;
+                nkp += __popcll(mk);
+            }
+        } else
         for (int i0 = 0; i0 < nitems; i0 += WAVE) {
             const int it = i0 + lane;
             unsigned keep = 0, e0 = 0;
