@@ -301,9 +301,11 @@ def main():
     ext = api.ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=dev.index, max_batch=B)
     ext._bind(W, H, B)
     cap = ext.max_keypoints
-    d_kps = [torch.zeros((B, cap, 7), dtype=torch.float32, device=dev) for _ in range(2)]
-    d_desc = [torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_n = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    # three result buffers in rotation: extract(k + 1) fills one while match(k) still reads the other two
+    NBUF = 3
+    d_kps = [torch.zeros((B, cap, 7), dtype=torch.float32, device=dev) for _ in range(NBUF)]
+    d_desc = [torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    d_n = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NBUF)]
     d_idx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_best = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_second = torch.zeros((B, cap), dtype=torch.int32, device=dev)
@@ -324,12 +326,26 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
+    # Opt-in experiment (SLAMIT_BENCH_TWO_STREAMS=1): the matcher of step k on a second stream, ordered after extract(k)
+    # by an event, so that it overlaps the pyramid chain of extract(k + 1).  Measured 5 % SLOWER than one stream (0.369 vs
+    # 0.352 ms per step): the two cross-stream events per step cost more than the overlap wins.  Default: one stream.
+    two_streams = not pipeline and bool(os.environ.get("SLAMIT_BENCH_TWO_STREAMS"))
+    mstream = torch.cuda.Stream(dev) if two_streams else tstream
+    ev_x = [torch.cuda.Event() for _ in range(NBUF)]   # extract into buffer i finished
+    ev_m = [torch.cuda.Event() for _ in range(NBUF)]   # the match that READ buffer i as "previous frame" finished
 
     def step(k):
-        cur, prv = k & 1, (k & 1) ^ 1
-        ext.extract_batch_dev(d_frames[cur], d_kps[cur], d_desc[cur], d_n[cur], stream=stream)
+        cur, prv = k % NBUF, (k - 1) % NBUF
+        if two_streams:
+            tstream.wait_event(ev_m[cur])     # buffer `cur` was the "previous frame" of match(k - 2): let it finish first
+        ext.extract_batch_dev(d_frames[k & 1], d_kps[cur], d_desc[cur], d_n[cur], stream=stream)
+        if two_streams:
+            ev_x[cur].record(tstream)
+            mstream.wait_event(ev_x[cur])
         api.ORBmatcher.best2_batch_dev(d_desc[cur], d_n[cur], d_desc[prv], d_n[prv], d_idx, d_best, d_second,
-                                       cap, device=dev.index, stream=stream)
+                                       cap, device=dev.index, stream=mstream.cuda_stream)
+        if two_streams:
+            ev_m[prv].record(mstream)
         if pipeline:
             ba_out = {}
             th = threading.Thread(target=lambda: ba_out.setdefault("r", ba_opt.LocalBundleAdjustmentBatch(ba_probs)))
@@ -402,7 +418,7 @@ def main():
     elapsed = shard.max_over_ranks(elapsed, cdev, world)
 
     # sanity of the timed work: every frame produced its keypoints and matches
-    n_last = d_n[(args.warmup + args.steps - 1) & 1].cpu().numpy()
+    n_last = d_n[(args.warmup + args.steps - 1) % NBUF].cpu().numpy()
     assert (n_last >= NFEAT).all(), "extractor returned too few keypoints: %s" % n_last[:8]
     if pipeline:   # every stream's slot arrived on this rank, with its keypoints, descriptors and BA poses
         hdr = slots.header(last_slots).cpu().numpy()

@@ -35,11 +35,12 @@ int orbk_fast_cells(const OrbLevel* host_levels, int nlevels, std::vector<uint32
 void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const uint32_t* d_cells, int cells_per_frame, const uint8_t* img0,
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, unsigned long long* cand,
                size_t cand_frame_stride, int* cand_count, int iniTh, int minTh, int max_wcell, int max_hcell, int nframes);
-size_t orbk_octree_smem(int node_cap);
-hipError_t orbk_octree_prepare(int node_cap);
+int orbk_octree_key_cap(int node_cap, int width, int height);
+size_t orbk_octree_smem(int node_cap, int key_cap);
+hipError_t orbk_octree_prepare(int node_cap, int key_cap);
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
                  size_t cand_frame_stride, int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
-                 OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int nframes,
+                 OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int key_cap, int nframes,
                  int level_override, int* fb_count);
 // FAST at iniThFAST as strip-walking waves (orb_fast_strip.hip) + the per-cell kernel over the cells it left empty
 int orbk_fast_strip_jobs(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out);
@@ -109,7 +110,7 @@ struct slamit_orb {
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
     std::vector<int> per_level;
     std::vector<OrbLevel> levels;
-    int cells_per_frame, blur_tiles, node_cap, max_kp_level, max_out, max_wcell, max_hcell;
+    int cells_per_frame, blur_tiles, node_cap, oct_key_cap, max_kp_level, max_out, max_wcell, max_hcell;
     size_t pyr_frame_total, blur_frame_total;
     size_t cand_frame_stride, kp_frame_stride;
     // device memory
@@ -275,7 +276,8 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         h->levels[l].plane_bytes = h->pyr_frame_total;   // stride between frames of the same level
         h->levels[l].blur_bytes = h->blur_frame_total;
     }
-    if (orbk_octree_smem(h->node_cap) > 160 * 1024 - 1024 || h->node_cap >= 4096) {   // labels carry the node in 12 bits
+    h->oct_key_cap = orbk_octree_key_cap(h->node_cap, p->width, p->height);
+    if (orbk_octree_smem(h->node_cap, h->oct_key_cap) > 160 * 1024 - 1024 || h->node_cap >= 4096) {   // labels carry the node in 12 bits
         orb_free(h);
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: nfeatures too large for the LDS octree");
     }
@@ -441,7 +443,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
     }
 #undef ALLOC
     if (e == hipSuccess) e = orbk_upload_pattern(h->stream);
-    if (e == hipSuccess) e = orbk_octree_prepare(h->node_cap);
+    if (e == hipSuccess) e = orbk_octree_prepare(h->node_cap, h->oct_key_cap);
     if (e == hipSuccess && !empty) e = orbk_fast_prepare(h->max_wcell, h->max_hcell);
     if (e == hipSuccess && h->d_counts) e = hipMemset(h->d_counts, 0, sizeof(int) * ((ORB_CC_PAD + 1) * B * nl + 2 * ORB_CC_PAD));
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -575,7 +577,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     // K4: octree
     prof_mark(h, st, ST_OCTREE, true);
     orbk_octree(st, h->d_levels, nl, h->d_cand, h->cand_frame_stride, cand_count, h->d_ws_xy, h->d_ws_node, h->d_lkp,
-                h->kp_frame_stride, kp_count, h->node_cap, nframes, -1, strip ? fb_count : nullptr);
+                h->kp_frame_stride, kp_count, h->node_cap, h->oct_key_cap, nframes, -1, strip ? fb_count : nullptr);
     prof_mark(h, st, ST_OCTREE, false);
     // K5: orientation
     prof_mark(h, st, ST_ANGLE, true);

@@ -540,7 +540,7 @@ __device__ __forceinline__ void fast_cell_wave(
             // compaction: one ballot per pixel slot and polarity; a pixel that passed both tests is on both stacks
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool pass = (pb & (0x80u << (8 * j))) != 0u;
+                const bool pass = ((pb >> (8 * j)) & 0xFFu) != 0u;   // byte select: one v_cmp_ne_u32_sdwa
                 const unsigned long long mk = __ballot(pass);
                 const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)nB));
                 if (pass) s_listB[pos] = (unsigned short)(e0 + j);
@@ -548,7 +548,7 @@ __device__ __forceinline__ void fast_cell_wave(
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool pass = (pd & (0x80u << (8 * j))) != 0u;
+                const bool pass = ((pd >> (8 * j)) & 0xFFu) != 0u;
                 const unsigned long long mk = __ballot(pass);
                 const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)nD));
                 if (pass) s_listD[pos] = (unsigned short)(e0 + j);
@@ -1600,26 +1600,33 @@ void orbk_fast_listed(hipStream_t st, const OrbLevel* host_levels, int nlevels, 
 }
 
 // candidates kept in LDS: as many as fit beside the node arrays in half a CU's LDS (lists above that use the HBM workspace)
-int orbk_octree_key_cap(int node_cap) {
-    static const long budget = getenv("SLAMIT_OCT_LDS_KB") ? 1024L * atol(getenv("SLAMIT_OCT_LDS_KB")) : (long)OCT_LDS_BUDGET;
+// LDS budget of one octree workgroup.  Two 78 KB workgroups fill a CU's LDS, which also keeps every other kernel off
+// the chip while the octree pass (a few hundred workgroups, latency bound) runs; images up to about VGA rarely have more
+// than 5,000 candidates on a level, so their handles take 48 KB and the blur runs beside the octree on the side stream.
+int orbk_octree_key_cap(int node_cap, int width, int height) {
+    long budget = (long)width * height <= 640L * 480L * 3 / 2 ? 48L * 1024 : (long)OCT_LDS_BUDGET;
+    if (getenv("SLAMIT_OCT_LDS_KB")) budget = 1024L * atol(getenv("SLAMIT_OCT_LDS_KB"));
     const long room = budget - (long)orbk_octree_node_bytes(node_cap);
     return (int)std::min<long>(OCT_LDS_KEYS_MAX, std::max<long>(OCT_LDS_KEYS_MIN, room / 6)) & ~7;
 }
-size_t orbk_octree_smem(int node_cap) { return orbk_octree_node_bytes(node_cap) + (size_t)orbk_octree_key_cap(node_cap) * 6; }
+size_t orbk_octree_smem(int node_cap, int key_cap) { return orbk_octree_node_bytes(node_cap) + (size_t)key_cap * 6; }
 
-hipError_t orbk_octree_prepare(int node_cap) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)orbk_octree_smem(node_cap));
+hipError_t orbk_octree_prepare(int node_cap, int key_cap) {
+    static int prepared = 0;   // the attribute is per function, not per handle: keep the largest request
+    const int want = (int)orbk_octree_smem(node_cap, key_cap);
+    if (want <= prepared) return hipSuccess;
+    prepared = want;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want);
 }
 
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
                  size_t cand_frame_stride, int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
-                 OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int nframes,
+                 OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int key_cap, int nframes,
                  int level_override, int* fb_count) {
     dim3 grid(level_override >= 0 ? 1 : nlevels, nframes);
-    hipLaunchKernelGGL(octree_kernel, grid, dim3(OCT_THREADS), orbk_octree_smem(node_cap), st, levels, nlevels, cand,
+    hipLaunchKernelGGL(octree_kernel, grid, dim3(OCT_THREADS), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
                        cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
-                       orbk_octree_key_cap(node_cap), level_override, fb_count);
+                       key_cap, level_override, fb_count);
 }
 
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0,
