@@ -451,6 +451,16 @@ const char* slamit_last_error(void);
 const char* slamit_version(void);
 int slamit_device_count(void);
 
+/* Devices and streams.  Every entry point runs on the device it is given (handles: the device of slamit_*_create) and
+ * restores the caller's current device before it returns.  The host-pointer entry points WITHOUT a device argument
+ * (slamit_hamming_best2, slamit_hamming_matrix, slamit_distinctive_batch) use the calling thread's slamit_set_device()
+ * (-1 = whatever device is current, the default).  `stream` arguments: NULL means the handle's own stream for entry points
+ * that take a handle, and the legacy default stream of `device` for the handle-less *_dev entry points; pass an explicit
+ * stream to order several calls.  Host-pointer entry points keep one pinned block, one device slab and one stream per
+ * calling thread and call site; they are released when the thread exits or by slamit_release_thread_scratch(). */
+int slamit_set_device(int device);
+void slamit_release_thread_scratch(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,6 +164,13 @@ def _apply_in_order(n, state, match):
 
 
 @pytest.mark.gpu
+def _gemm_row(Rrow, t, X, Y, Z):
+    """One row of cv::Mat x3Dc = Rcw * x3Dw + tcw on CV_32F operands: cv::gemm sums in double and rounds once
+    (the model the shim templates follow, ORBmatcher.cc:1363, 851, 1497)."""
+    f64 = np.float64
+    return (f64(Rrow[0]) * X.astype(f64) + f64(Rrow[1]) * Y.astype(f64) + f64(Rrow[2]) * Z.astype(f64) + f64(t)).astype(np.float32)
+
+
 def test_shim_search_by_projection_local_map(tmp_path):
     """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) through the template + mock types."""
     from oracle import bindings as ob
@@ -248,9 +255,9 @@ def test_shim_search_by_projection_last_frame(tmp_path):
     assert r[0] == 0
     # expected, float32 step by step as ORBmatcher.cc:1363-1386 computes it
     X, Y, Z = world[:, 0], world[:, 1], world[:, 2]
-    xc = ((Rc[0, 0] * X + Rc[0, 1] * Y) + Rc[0, 2] * Z) + tc[0]
-    yc = ((Rc[1, 0] * X + Rc[1, 1] * Y) + Rc[1, 2] * Z) + tc[1]
-    zc = ((Rc[2, 0] * X + Rc[2, 1] * Y) + Rc[2, 2] * Z) + tc[2]
+    xc = _gemm_row(Rc[0], tc[0], X, Y, Z)
+    yc = _gemm_row(Rc[1], tc[1], X, Y, Z)
+    zc = _gemm_row(Rc[2], tc[2], X, Y, Z)
     with np.errstate(divide="ignore"):
         invz = (1.0 / zc.astype(np.float64)).astype(np.float32)
     u = (fx * xc) * invz + cx
@@ -374,9 +381,9 @@ def test_shim_fuse(tmp_path):
     assert r[0] == 0
     # expected: the reference's float arithmetic step by step (ORBmatcher.cc:851-895)
     X, Y, Z = pos[:, 0], pos[:, 1], pos[:, 2]
-    xc = ((Rc[0, 0] * X + Rc[0, 1] * Y) + Rc[0, 2] * Z) + tc[0]
-    yc = ((Rc[1, 0] * X + Rc[1, 1] * Y) + Rc[1, 2] * Z) + tc[1]
-    zc = ((Rc[2, 0] * X + Rc[2, 1] * Y) + Rc[2, 2] * Z) + tc[2]
+    xc = _gemm_row(Rc[0], tc[0], X, Y, Z)
+    yc = _gemm_row(Rc[1], tc[1], X, Y, Z)
+    zc = _gemm_row(Rc[2], tc[2], X, Y, Z)
     with np.errstate(divide="ignore", invalid="ignore"):
         invz = f32(1) / zc
     u, v = fx * (xc * invz) + cx, fy * (yc * invz) + cy
@@ -496,7 +503,7 @@ def test_shim_search_by_projection_relocalization(tmp_path):
     fx, fy, cx, cy = f32(520.9), f32(521.0), f32(325.1), f32(249.7)
     Rc, tc = synth.se3_exp(np.array([-0.02, 0.015, 0.01, 0.05, 0.02, -0.03]))
     Rc, tc = Rc.astype(np.float32), tc.astype(np.float32)
-    Ow = np.array([-(Rc[0, r] * tc[0]) + -(Rc[1, r] * tc[1]) + -(Rc[2, r] * tc[2]) for r in range(3)], np.float32)
+    Ow = (-(Rc.astype(np.float64).T @ tc.astype(np.float64))).astype(np.float32)   # -Rcw.t() * tcw: double sum, one rounding
     src = rs.randint(0, n, m)
     depth = rs.uniform(2, 8, m)
     px = frame["kp_xy"][src].astype(np.float64) + rs.uniform(-5, 5, (m, 2))
@@ -527,9 +534,9 @@ def test_shim_search_by_projection_relocalization(tmp_path):
     subprocess.check_call([EXE, "search", str(pin), str(pout)])
     r = np.fromfile(pout, np.int32)
     assert r[0] == 0
-    xc = ((Rc[0, 0] * X + Rc[0, 1] * Y) + Rc[0, 2] * Z) + tc[0]
-    yc = ((Rc[1, 0] * X + Rc[1, 1] * Y) + Rc[1, 2] * Z) + tc[1]
-    zc = ((Rc[2, 0] * X + Rc[2, 1] * Y) + Rc[2, 2] * Z) + tc[2]
+    xc = _gemm_row(Rc[0], tc[0], X, Y, Z)
+    yc = _gemm_row(Rc[1], tc[1], X, Y, Z)
+    zc = _gemm_row(Rc[2], tc[2], X, Y, Z)
     invz = (1.0 / zc.astype(np.float64)).astype(np.float32)
     u, v = (fx * xc) * invz + cx, (fy * yc) * invz + cy
     ok = (has != 0) & (bad == 0) & (found == 0) & ~(u < f32(frame["min_x"])) & ~(u > f32(645.1)) & ~(v < f32(frame["min_y"])) & ~(v > f32(483.9))

@@ -131,7 +131,7 @@ EXPORTS = [
     "slamit_orb_debug_candidates", "slamit_orb_debug_blurred", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
     "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_guided_search_workspace", "slamit_guided_search_batch_dev", "slamit_bow_search", "slamit_undistort_points", "slamit_frame_finish",
     "slamit_frame_finish_batch_dev", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
-    "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_sim3_optimize", "slamit_sim3_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count",
+    "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_sim3_optimize", "slamit_sim3_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count", "slamit_set_device", "slamit_release_thread_scratch",
 ]
 
 

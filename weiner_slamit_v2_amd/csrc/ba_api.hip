@@ -122,7 +122,7 @@ int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int de
     if (!out || max_kf < 1 || max_pt < 1 || max_edge < 1 || max_batch < 1)
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_create: bad argument");
     *out = nullptr;
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     slamit_ba* h = new slamit_ba();
     h->device = device;
     h->max_kf = max_kf; h->max_pt = max_pt; h->max_edge = max_edge; h->max_batch = max_batch;
@@ -155,7 +155,7 @@ int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int de
 
 void slamit_ba_destroy(slamit_ba* h) {
     if (!h) return;
-    hipSetDevice(h->device);
+    SlamitDeviceGuard guard(h->device);
     hipFree(h->d_slab); hipFree(h->d_wins); hipFree(h->d_states); hipFree(h->d_io);
     if (h->h_pin) hipHostFree(h->h_pin);
     for (int i = 0; i < 2; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
@@ -168,7 +168,7 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
     if (!h || !probs || !opts || !results || nwin < 0) return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: bad argument");
     if (nwin > h->max_batch) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_ba_solve_batch: nwin > max_batch");
     if (nwin == 0) return SLAMIT_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    SLAMIT_USE_DEVICE(h->device);
     hipStream_t st = h->stream;
     // ---- validate ----
     int mk = 1, mp = 1, me = 1, Npad = BA_TILE;

@@ -159,7 +159,7 @@ extern "C" int slamit_bow_search(int device, const uint8_t* desc1, int32_t n1, c
         }
     }
     if (nq == 0 || ncand == 0) return SLAMIT_OK;
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     // one pinned staging block and one device slab per host thread, kept between calls (LocalMapping makes this call for
     // every neighbour keyframe of every new keyframe); inputs first, outputs last
     const bool m1 = rule->mode == 1;
@@ -171,19 +171,10 @@ extern "C" int slamit_bow_search(int device, const uint8_t* desc1, int32_t n1, c
     const size_t in_bytes = off;
     const size_t o_m = take(4 * (size_t)n1), o_d = take(4 * (size_t)n1), o_nm = take(4);
     const size_t io_bytes = off;
-    struct Scratch { int device; uint8_t* host; size_t host_bytes; uint8_t* dev; size_t dev_bytes; hipStream_t st; };
-    static thread_local Scratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
-    if (S.device != device || S.host_bytes < io_bytes || S.dev_bytes < io_bytes) {
-        if (S.st) hipStreamSynchronize(S.st);
-        if (S.host) hipHostFree(S.host);
-        if (S.dev) hipFree(S.dev);
-        if (S.st && S.device != device) { hipStreamDestroy(S.st); S.st = nullptr; }   // a stream belongs to the device it was created on
-        S.host = nullptr; S.dev = nullptr; S.host_bytes = S.dev_bytes = 0; S.device = device;
-        if (!S.st) HIP_TRY(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
-        HIP_TRY(hipHostMalloc((void**)&S.host, io_bytes + io_bytes / 2, hipHostMallocDefault));
-        S.host_bytes = io_bytes + io_bytes / 2;
-        HIP_TRY(hipMalloc((void**)&S.dev, io_bytes + io_bytes / 2));
-        S.dev_bytes = io_bytes + io_bytes / 2;
+    static thread_local SlamitScratch S;
+    {
+        const hipError_t es = slamit_scratch_reserve(S, device, io_bytes);
+        if (es != hipSuccess) return slamit_fail_hip(es, "slamit_bow_search: scratch");
     }
     uint8_t* hb = S.host;
     uint8_t* d = S.dev;

@@ -139,10 +139,10 @@ static CamD make_cam(const slamit_camera* c) {
 extern "C" int slamit_undistort_points(int device, const slamit_camera* cam, const float* xy_in, int n, float* xy_out) {
     if (!cam || n < 0 || (n && (!xy_in || !xy_out))) return slamit_fail(SLAMIT_ERR_ARG, "slamit_undistort_points: bad argument");
     if (n == 0) return SLAMIT_OK;
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     // one pinned staging block + one device slab per host thread (slamit_internal.h): [in | out], one copy each way
     const size_t half = (8 * (size_t)n + 255) & ~(size_t)255;
-    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    static thread_local SlamitScratch S;
     hipError_t e = slamit_scratch_reserve(S, device, 2 * half);
     if (e == hipSuccess) {
         memcpy(S.host, xy_in, 8 * (size_t)n);
@@ -168,7 +168,7 @@ extern "C" int slamit_frame_finish_batch_dev(int device, const slamit_camera* ca
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_frame_finish_batch_dev: bad argument");
     if (cap > SLAMIT_FRAME_MAX_KP) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_frame_finish_batch_dev: cap > SLAMIT_FRAME_MAX_KP");
     if (nframes == 0) return SLAMIT_OK;
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     hipLaunchKernelGGL(frame_finish_kernel, dim3(nframes), dim3(FF_THREADS), sizeof(short) * (size_t)std::max(cap, 1), (hipStream_t)stream,
                        make_cam(cam), d_kps, d_n, 0, cap, min_x, min_y, inv_w, inv_h, d_kps_un, d_cell_start, d_cell_items);
     HIP_TRY(hipGetLastError());
@@ -180,12 +180,12 @@ extern "C" int slamit_frame_finish(int device, const slamit_camera* cam, const s
     if (!cam || n < 0 || !cell_start || (n && (!kps || !kps_un || !cell_items)))
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_frame_finish: bad argument");
     if (n > SLAMIT_FRAME_MAX_KP) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_frame_finish: more than SLAMIT_FRAME_MAX_KP keypoints");
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     const int cap = std::max(n, 1);
     // one pinned staging block + one device slab per host thread: [keypoints in | keypoints out | cell_start | cell_items]
     const size_t kb = (sizeof(slamit_kp) * (size_t)cap + 255) & ~(size_t)255, cs = (sizeof(int) * (FG_CELLS + 1) + 255) & ~(size_t)255;
     const size_t o_un = kb, o_cs = 2 * kb, o_ci = o_cs + cs, bytes = o_ci + sizeof(int) * (size_t)cap;
-    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    static thread_local SlamitScratch S;
     hipError_t e = slamit_scratch_reserve(S, device, bytes);
     if (e == hipSuccess && n) {
         memcpy(S.host, kps, sizeof(slamit_kp) * (size_t)n);

@@ -190,9 +190,9 @@ int slamit_distinctive_batch(const uint8_t* desc, const int32_t* offsets, int np
     // one pinned staging block + one device slab per host thread (slamit_internal.h): [descriptors | offsets | out], one copy each way
     const size_t o_off = ((size_t)total * 32 + 255) & ~(size_t)255, o_out = o_off + ((sizeof(int) * ((size_t)npoints + 1) + 255) & ~(size_t)255);
     const size_t bytes = o_out + sizeof(int) * 2 * (size_t)npoints;
-    int cur_dev = 0;
-    hipGetDevice(&cur_dev);
-    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    const int cur_dev = slamit_default_device();   // slamit_set_device() of this thread, else the current device
+    SLAMIT_USE_DEVICE(cur_dev);
+    static thread_local SlamitScratch S;
     hipError_t e = slamit_scratch_reserve(S, cur_dev, bytes);
     if (e == hipSuccess) {
         if (total) memcpy(S.host, desc, (size_t)total * 32);
@@ -224,7 +224,7 @@ int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_best2_batch_dev: descriptors must be 16-byte aligned");
     if (npairs == 0 || max_n == 0) return SLAMIT_OK;
     if (max_n > SLAMIT_HAMMING_MAX_TRAIN) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_hamming_best2_batch_dev: more than SLAMIT_HAMMING_MAX_TRAIN descriptors per set");
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     dim3 grid((max_n + HM_QPB - 1) / HM_QPB, npairs);
     hipLaunchKernelGGL(hamming_best2_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_q, d_nq, 0, q_stride, d_t, d_nt,
                        0, t_stride, d_best_idx, d_best, d_second, out_stride);
@@ -241,9 +241,9 @@ int slamit_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int
     // one pinned staging block + one device slab per host thread: [query | train | out], one copy each way
     const size_t o_t = ((size_t)nq * 32 + 255) & ~(size_t)255, o_out = o_t + ((std::max<size_t>((size_t)nt * 32, 32) + 255) & ~(size_t)255);
     const size_t bytes = o_out + sizeof(int) * 3 * (size_t)nq;
-    int cur_dev = 0;
-    hipGetDevice(&cur_dev);
-    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    const int cur_dev = slamit_default_device();   // slamit_set_device() of this thread, else the current device
+    SLAMIT_USE_DEVICE(cur_dev);
+    static thread_local SlamitScratch S;
     hipError_t e = slamit_scratch_reserve(S, cur_dev, bytes);
     if (e == hipSuccess) {
         memcpy(S.host, q, (size_t)nq * 32);
@@ -269,19 +269,26 @@ int slamit_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int
 int slamit_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out) {
     if (nq < 0 || nt < 0 || ((nq && nt) && (!q || !t || !out))) return slamit_fail(SLAMIT_ERR_ARG, "slamit_hamming_matrix: bad argument");
     if (nq == 0 || nt == 0) return SLAMIT_OK;
-    uint8_t *dq = nullptr, *dt = nullptr;
-    uint16_t* dout = nullptr;
-    hipError_t e = hipMalloc((void**)&dq, (size_t)nq * 32);
-    if (e == hipSuccess) e = hipMalloc((void**)&dt, (size_t)nt * 32);
-    if (e == hipSuccess) e = hipMalloc((void**)&dout, sizeof(uint16_t) * (size_t)nq * nt);
-    if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice);
+    const int cur_dev = slamit_default_device();
+    SLAMIT_USE_DEVICE(cur_dev);
+    // one pinned staging block + one device slab per host thread: [query | train | matrix], one copy each way
+    const size_t o_t = ((size_t)nq * 32 + 255) & ~(size_t)255, o_out = o_t + (((size_t)nt * 32 + 255) & ~(size_t)255);
+    const size_t bytes = o_out + sizeof(uint16_t) * (size_t)nq * nt;
+    static thread_local SlamitScratch S;
+    hipError_t e = slamit_scratch_reserve(S, cur_dev, bytes);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(hamming_matrix_kernel, dim3((nt + 63) / 64, (nq + 63) / 64), dim3(256), 0, 0, dq, nq, dt, nt, dout);
+        memcpy(S.host, q, (size_t)nq * 32);
+        memcpy(S.host + o_t, t, (size_t)nt * 32);
+        e = hipMemcpyAsync(S.dev, S.host, o_out, hipMemcpyHostToDevice, S.st);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hamming_matrix_kernel, dim3((nt + 63) / 64, (nq + 63) / 64), dim3(256), 0, S.st, S.dev, nq, S.dev + o_t, nt,
+                           reinterpret_cast<uint16_t*>(S.dev + o_out));
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(uint16_t) * (size_t)nq * nt, hipMemcpyDeviceToHost);
-    hipFree(dq); hipFree(dt); hipFree(dout);
+    if (e == hipSuccess) e = hipMemcpyAsync(S.host + o_out, S.dev + o_out, bytes - o_out, hipMemcpyDeviceToHost, S.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(S.st);
+    if (e == hipSuccess) memcpy(out, S.host + o_out, bytes - o_out);
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_hamming_matrix");
     return SLAMIT_OK;
 }

@@ -160,7 +160,7 @@ struct slamit_orb {
 
 static void orb_free(slamit_orb* h) {
     if (!h) return;
-    hipSetDevice(h->device);
+    SlamitDeviceGuard guard(h->device);
     hipFree(h->d_levels); hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cand); hipFree(h->d_ws_xy);
     hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_jobs); hipFree(h->d_fb_list); hipFree(h->d_blur_tiles); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
     hipFree(h->d_out_desc); hipFree(h->d_out_n); if (h->h_out) hipHostFree(h->h_out); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
@@ -184,7 +184,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         p->ini_th_fast < 1 || p->ini_th_fast > 255 || p->min_th_fast < 1 || p->min_th_fast > 255 ||
         p->width < 0 || p->height < 0 || p->max_batch < 1)
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_create: parameter out of range");
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     slamit_orb* h = new slamit_orb();
     h->p = *p;
     h->device = device;
@@ -491,7 +491,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     if (!h || !d_n_out || nframes < 0) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: bad argument");
     if (nframes > h->p.max_batch) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_extract_batch_dev: nframes > max_batch");
     if (nframes == 0) return SLAMIT_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    SLAMIT_USE_DEVICE(h->device);
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const int nl = h->nlevels;
     if (h->p.width == 0 || h->p.height == 0) {  // ORBextractor.cc:1068: empty image -> nothing
@@ -614,7 +614,7 @@ int slamit_orb_extract_batch(slamit_orb* h, const uint8_t* gray, size_t stride, 
     }
     if (!gray || !kps || !desc) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch: null buffer");
     if (cap < h->max_out) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_extract_batch: cap < slamit_orb_max_keypoints()");
-    HIP_TRY(hipSetDevice(h->device));
+    SLAMIT_USE_DEVICE(h->device);
     const int W = h->p.width, H = h->p.height;
     for (int f = 0; f < nframes; ++f)
         HIP_TRY(hipMemcpy2DAsync(h->d_in + f * h->d_in_frame, h->d_in_stride, gray + (size_t)f * frame_stride, stride, W, H,
@@ -648,7 +648,7 @@ int slamit_orb_extract(slamit_orb* h, const uint8_t* gray, size_t stride, slamit
 
 int slamit_orb_profile(slamit_orb* h, int enable, float* stage_ms, int32_t* stage_calls, int nstages) {
     if (!h) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_profile: null handle");
-    HIP_TRY(hipSetDevice(h->device));
+    SLAMIT_USE_DEVICE(h->device);
     if (stage_ms || stage_calls) {
         for (int i = 0; i < nstages; ++i) { if (stage_ms) stage_ms[i] = 0.f; if (stage_calls) stage_calls[i] = 0; }
         for (size_t i = 0; i < h->prof_stage.size() && 2 * i + 1 < h->prof_ev.size(); ++i) {
@@ -676,7 +676,7 @@ int slamit_orb_level(slamit_orb* h, int frame, int level, uint8_t* dst, size_t d
     if (frame < 0 || frame >= h->last_nframes || !h->last_img0) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_level: no such frame in the last extract call");
     size_t need = (size_t)(L.w + 38) * (L.h + 38);
     if (dst_bytes < need) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_level: dst too small");
-    HIP_TRY(hipSetDevice(h->device));
+    SLAMIT_USE_DEVICE(h->device);
     const uint8_t* src = level == 0 ? h->last_img0 + (size_t)frame * h->last_frame
                                     : h->d_pyr + L.plane_off + (size_t)frame * h->pyr_frame_total;
     orbk_pad(h->stream, src, L.w, L.h, level == 0 ? h->last_stride : (size_t)L.stride, h->d_scratch);
@@ -694,7 +694,7 @@ int slamit_orb_debug_blurred(slamit_orb* h, int frame, int level, uint8_t* dst, 
     if (!dst) return SLAMIT_OK;
     if (frame < 0 || frame >= h->last_nframes) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_debug_blurred: no such frame in the last extract call");
     if (dst_bytes < (size_t)L.w * L.h) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_orb_debug_blurred: dst too small");
-    HIP_TRY(hipSetDevice(h->device));
+    SLAMIT_USE_DEVICE(h->device);
     HIP_TRY(hipMemcpy2DAsync(dst, (size_t)L.w, h->d_blur + L.blur_off + (size_t)frame * h->blur_frame_total, (size_t)L.stride, (size_t)L.w,
                              (size_t)L.h, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -704,7 +704,7 @@ int slamit_orb_debug_blurred(slamit_orb* h, int frame, int level, uint8_t* dst, 
 int slamit_orb_debug_candidates(slamit_orb* h, int frame, int level, int32_t* xys, int cap, int* n_out) {
     if (!h || level < 0 || level >= h->nlevels || !n_out) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_debug_candidates: bad argument");
     if (frame < 0 || frame >= h->last_nframes) return slamit_fail(SLAMIT_ERR_STATE, "slamit_orb_debug_candidates: no such frame");
-    HIP_TRY(hipSetDevice(h->device));
+    SLAMIT_USE_DEVICE(h->device);
     const OrbLevel& L = h->levels[level];
     int n = 0;
     HIP_TRY(hipMemcpy(&n, h->d_counts + (size_t)(frame * h->nlevels + level) * ORB_CC_PAD + 1, sizeof(int), hipMemcpyDeviceToHost));   // word 1: the count the octree pass consumed

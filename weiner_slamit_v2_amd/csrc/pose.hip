@@ -281,7 +281,7 @@ extern "C" {
 int slamit_pose_optimize_batch(int device, int nframes, const slamit_pose_problem* probs, slamit_pose_result* results) {
     if (nframes < 0 || (nframes && (!probs || !results))) return slamit_fail(SLAMIT_ERR_ARG, "slamit_pose_optimize_batch: bad argument");
     if (nframes == 0) return SLAMIT_OK;
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     // one slab per host thread (slamit_internal.h): [doubles of every frame | ints | PoseFrame records | flags], one copy each way
     size_t total = 0, flag_total = 0;
     int nmax = 1;
@@ -298,7 +298,7 @@ int slamit_pose_optimize_batch(int device, int nframes, const slamit_pose_proble
     }
     const size_t o_ints = sizeof(double) * total, o_frames = (o_ints + sizeof(int32_t) * 5 * nframes + 15) & ~(size_t)15;
     const size_t o_flags = o_frames + sizeof(PoseFrame) * nframes, bytes = o_flags + flag_total;
-    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    static thread_local SlamitScratch S;
     hipError_t e = slamit_scratch_reserve(S, device, bytes);
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_pose_optimize_batch");
     double* stage = reinterpret_cast<double*>(S.host);

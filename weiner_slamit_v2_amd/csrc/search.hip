@@ -333,7 +333,7 @@ extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, cons
         (F->n && (!F->kp_xy || !F->kp_octave || !F->desc || !F->kp_taken)))
         return slamit_fail(SLAMIT_ERR_ARG, "slamit_guided_search: null array");
     if (F->n > SLAMIT_SEARCH_MAX_KP) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_guided_search: more than SLAMIT_SEARCH_MAX_KP keypoints");
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     const int n = F->n, m = Q->m, cap = std::min(std::max(n, 1), SLAMIT_SEARCH_MAX_CAND);
     // One pinned staging block and one device slab per host thread, kept between calls (a Tracking thread makes this
     // call every frame: a fresh hipMalloc + nine pageable copies cost more than the search itself).  Layout of both:
@@ -347,19 +347,10 @@ extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, cons
     const size_t o_mk = take(4 * (size_t)m), o_o4 = take(16 * (size_t)m), o_nm = take(4);
     const size_t io_bytes = off;
     const size_t o_cand = take(8 * (size_t)m * cap), o_cn = take(4 * (size_t)m), o_te = take(16 * (size_t)m);
-    struct Scratch { int device; uint8_t* host; size_t host_bytes; uint8_t* dev; size_t dev_bytes; hipStream_t st; };
-    static thread_local Scratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
-    if (S.device != device || S.host_bytes < io_bytes || S.dev_bytes < off) {
-        if (S.st) hipStreamSynchronize(S.st);
-        if (S.host) hipHostFree(S.host);
-        if (S.dev) hipFree(S.dev);
-        if (S.st && S.device != device) { hipStreamDestroy(S.st); S.st = nullptr; }   // a stream belongs to the device it was created on
-        S.host = nullptr; S.dev = nullptr; S.host_bytes = S.dev_bytes = 0; S.device = device;
-        if (!S.st) HIP_TRY(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
-        HIP_TRY(hipHostMalloc((void**)&S.host, io_bytes + io_bytes / 2, hipHostMallocDefault));
-        S.host_bytes = io_bytes + io_bytes / 2;
-        HIP_TRY(hipMalloc((void**)&S.dev, off + off / 2));
-        S.dev_bytes = off + off / 2;
+    static thread_local SlamitScratch S;
+    {
+        const hipError_t es = slamit_scratch_reserve(S, device, io_bytes, off);   // pinned: inputs + outputs; device: + candidate lists
+        if (es != hipSuccess) return slamit_fail_hip(es, "slamit_guided_search: scratch");
     }
     uint8_t* hb = S.host;
     uint8_t* d = S.dev;
@@ -422,7 +413,7 @@ extern "C" int slamit_guided_search_batch_dev(int device, const slamit_search_ba
     if (B->kp_cap > SLAMIT_SEARCH_MAX_KP) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_guided_search_batch_dev: kp_cap > SLAMIT_SEARCH_MAX_KP");
     if (workspace_bytes < slamit_guided_search_workspace(B->nframes, B->q_cap))
         return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_guided_search_batch_dev: workspace smaller than slamit_guided_search_workspace()");
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     SearchDev D;
     D.nframes = B->nframes; D.kp_cap = B->kp_cap; D.q_cap = B->q_cap; D.cand_cap = SLAMIT_SEARCH_BATCH_CAND;
     D.n_arr = B->d_n; D.n_fixed = 0; D.m_arr = B->d_m; D.m_fixed = 0;

@@ -374,11 +374,11 @@ int slamit_sim3_optimize_batch(int device, int nprob, const slamit_sim3_problem*
         flag_total += ((size_t)P.n + 15) & ~(size_t)7;
         nmax = std::max(nmax, (int)P.n);
     }
-    HIP_TRY(hipSetDevice(device));
+    SLAMIT_USE_DEVICE(device);
     // one slab per host thread (slamit_internal.h): [doubles of every problem | ints | Sim3Prob records | flags], one copy each way
     const size_t o_ints = sizeof(double) * total, o_probs = (o_ints + sizeof(int32_t) * 4 * nprob + 15) & ~(size_t)15;
     const size_t o_flags = o_probs + sizeof(Sim3Prob) * nprob, bytes = o_flags + flag_total;
-    static thread_local SlamitScratch S = {-1, nullptr, 0, nullptr, 0, nullptr};
+    static thread_local SlamitScratch S;
     hipError_t e = slamit_scratch_reserve(S, device, bytes);
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_sim3_optimize_batch");
     double* stage = reinterpret_cast<double*>(S.host);

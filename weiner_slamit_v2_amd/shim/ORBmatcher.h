@@ -228,7 +228,8 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame
         tcw[r] = CurrentFrame.mTcw.template at<float>(r, 3); tlw[r] = LastFrame.mTcw.template at<float>(r, 3);
     }
     float twc[3];
-    for (int r = 0; r < 3; ++r) twc[r] = -Rcw[0][r] * tcw[0] + -Rcw[1][r] * tcw[1] + -Rcw[2][r] * tcw[2];
+    // cv::Mat products of CV_32F operands sum in double and round once (cv::gemm); so do these
+    for (int r = 0; r < 3; ++r) twc[r] = (float)((double)-Rcw[0][r] * tcw[0] + (double)-Rcw[1][r] * tcw[1] + (double)-Rcw[2][r] * tcw[2]);
     const float tlc2 = Rlw[2][0] * twc[0] + Rlw[2][1] * twc[1] + Rlw[2][2] * twc[2] + tlw[2];
     const bool bForward = tlc2 > CurrentFrame.mb && !bMono;
     const bool bBackward = -tlc2 > CurrentFrame.mb && !bMono;
@@ -240,9 +241,9 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame
         if (!pMP || LastFrame.mvbOutlier[i]) continue;
         const cv::Mat x3Dw = pMP->GetWorldPos();
         const float X = x3Dw.template at<float>(0, 0), Y = x3Dw.template at<float>(1, 0), Z = x3Dw.template at<float>(2, 0);
-        const float xc = Rcw[0][0] * X + Rcw[0][1] * Y + Rcw[0][2] * Z + tcw[0];
-        const float yc = Rcw[1][0] * X + Rcw[1][1] * Y + Rcw[1][2] * Z + tcw[1];
-        const float zc = Rcw[2][0] * X + Rcw[2][1] * Y + Rcw[2][2] * Z + tcw[2];
+        const float xc = (float)((double)Rcw[0][0] * X + (double)Rcw[0][1] * Y + (double)Rcw[0][2] * Z + (double)tcw[0]);
+        const float yc = (float)((double)Rcw[1][0] * X + (double)Rcw[1][1] * Y + (double)Rcw[1][2] * Z + (double)tcw[1]);
+        const float zc = (float)((double)Rcw[2][0] * X + (double)Rcw[2][1] * Y + (double)Rcw[2][2] * Z + (double)tcw[2]);
         const float invzc = 1.0 / zc;
         if (invzc < 0) continue;
         const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
@@ -301,7 +302,7 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const S
         for (int c = 0; c < 3; ++c) Rcw[r][c] = CurrentFrame.mTcw.template at<float>(r, c);
         tcw[r] = CurrentFrame.mTcw.template at<float>(r, 3);
     }
-    for (int r = 0; r < 3; ++r) Ow[r] = -Rcw[0][r] * tcw[0] + -Rcw[1][r] * tcw[1] + -Rcw[2][r] * tcw[2];
+    for (int r = 0; r < 3; ++r) Ow[r] = (float)((double)-Rcw[0][r] * tcw[0] + (double)-Rcw[1][r] * tcw[1] + (double)-Rcw[2][r] * tcw[2]);
     const auto vpMPs = pKF->GetMapPointMatches();
     GuidedQueries q;
     std::vector<int> who;   // index into vpMPs (= keypoint of pKF)
@@ -311,9 +312,9 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const S
         if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
         const cv::Mat x3Dw = pMP->GetWorldPos();
         const float X = x3Dw.template at<float>(0, 0), Y = x3Dw.template at<float>(1, 0), Z = x3Dw.template at<float>(2, 0);
-        const float xc = Rcw[0][0] * X + Rcw[0][1] * Y + Rcw[0][2] * Z + tcw[0];
-        const float yc = Rcw[1][0] * X + Rcw[1][1] * Y + Rcw[1][2] * Z + tcw[1];
-        const float zc = Rcw[2][0] * X + Rcw[2][1] * Y + Rcw[2][2] * Z + tcw[2];
+        const float xc = (float)((double)Rcw[0][0] * X + (double)Rcw[0][1] * Y + (double)Rcw[0][2] * Z + (double)tcw[0]);
+        const float yc = (float)((double)Rcw[1][0] * X + (double)Rcw[1][1] * Y + (double)Rcw[1][2] * Z + (double)tcw[1]);
+        const float zc = (float)((double)Rcw[2][0] * X + (double)Rcw[2][1] * Y + (double)Rcw[2][2] * Z + (double)tcw[2]);
         const float invzc = 1.0 / zc;
         const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
         const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
@@ -799,9 +800,9 @@ int ORBmatcher::Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints,
         if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
         const cv::Mat p3Dw = pMP->GetWorldPos();
         const float X = p3Dw.template at<float>(0, 0), Y = p3Dw.template at<float>(1, 0), Z = p3Dw.template at<float>(2, 0);
-        const float xc = R[0][0] * X + R[0][1] * Y + R[0][2] * Z + t[0];
-        const float yc = R[1][0] * X + R[1][1] * Y + R[1][2] * Z + t[1];
-        const float zc = R[2][0] * X + R[2][1] * Y + R[2][2] * Z + t[2];
+        const float xc = (float)((double)R[0][0] * X + (double)R[0][1] * Y + (double)R[0][2] * Z + (double)t[0]);   // cv::gemm: double sum, one rounding
+        const float yc = (float)((double)R[1][0] * X + (double)R[1][1] * Y + (double)R[1][2] * Z + (double)t[1]);   // cv::gemm: double sum, one rounding
+        const float zc = (float)((double)R[2][0] * X + (double)R[2][1] * Y + (double)R[2][2] * Z + (double)t[2]);   // cv::gemm: double sum, one rounding
         if (zc < 0.0f) continue;   // depth must be positive
         const float invz = 1 / zc;
         const float x = xc * invz, y = yc * invz;

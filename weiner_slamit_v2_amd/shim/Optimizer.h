@@ -84,7 +84,7 @@ public:
     static void SetDevice(int device) { deviceRef() = device; }
 
 private:
-    static int& lastStatus() { static int s = 0; return s; }
+    static int& lastStatus() { static thread_local int s = 0; return s; }   // per calling thread: Tracking, LocalMapping and LoopClosing run concurrently
     static int& deviceRef() { static int d = 0; return d; }
     static slamit_ba*& handleRef() { static slamit_ba* h = 0; return h; }
     static int* capRef() { static int c[3] = {0, 0, 0}; return c; }
