@@ -218,6 +218,32 @@ def test_hamming_ragged(nq, nt):
     assert np.array_equal(gi, oi) and np.array_equal(gb, obest) and np.array_equal(gs, osec)
 
 
+def test_hamming_every_bit_position_extremes_and_the_large_set_kernel():
+    """The matrix-core kernel permutes the 256 bit positions onto its K axis: every position must count exactly once
+    (one-hot rows), distances 0 and 256 must survive the key packing, and train sets above its 8192-row limit take
+    the xor / popcount kernel with the same answers."""
+    onehot = np.zeros((256, 32), np.uint8)
+    for b in range(256):
+        onehot[b, b >> 3] = 1 << (b & 7)
+    q = np.concatenate([np.zeros((1, 32), np.uint8), np.full((1, 32), 255, np.uint8), onehot[::7]])
+    t = np.concatenate([onehot, 255 - onehot, np.full((1, 32), 255, np.uint8)])
+    gi, gb, gs = api.ORBmatcher.best2(q, t)
+    oi, obest, osec = ob.best2(q, t)
+    assert np.array_equal(gi, oi) and np.array_equal(gb, obest) and np.array_equal(gs, osec)
+    assert gb[0] == 1 and gi[0] == 0 and gs[0] == 1 and gb[1] == 0 and gi[1] == 512
+    gi, gb, gs = api.ORBmatcher.best2(np.zeros((3, 32), np.uint8), np.full((40, 32), 255, np.uint8))
+    assert (gb == 256).all() and (gs == 256).all() and (gi == 0).all()       # 256 is a real distance here, not "none"
+    rs = np.random.RandomState(5)
+    q = rs.randint(0, 256, (70, 32)).astype(np.uint8)
+    t = rs.randint(0, 256, (8300, 32)).astype(np.uint8)
+    t[8250] = q[5]
+    for nt in (8192, 8193, 8300):
+        gi, gb, gs = api.ORBmatcher.best2(q, t[:nt])
+        oi, obest, osec = ob.best2(q, t[:nt])
+        assert np.array_equal(gi, oi) and np.array_equal(gb, obest) and np.array_equal(gs, osec), nt
+    assert gi[5] == 8250 and gb[5] == 0
+
+
 def test_extract_then_match_pair():
     """BASELINE config 2 end to end: frame A vs its warped copy B, all-pairs best/second +
     TH_LOW / ratio 0.9 acceptance, indices identical to the oracle's."""

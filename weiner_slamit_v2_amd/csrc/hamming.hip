@@ -11,6 +11,7 @@
 // tiles of 256 rows (8 KB), read as broadcast ds_read_b128; distance = 8 x (v_xor + v_bcnt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -110,6 +111,188 @@ __global__ __launch_bounds__(256) void hamming_best2_kernel(
     }
 }
 
+// ---- the same reduction on the matrix cores -------------------------------------------------------------------
+// 256-bit Hamming distance as an int8 dot product: a descriptor bit becomes the byte +-64 (query: 1 -> -64, train:
+// 1 -> +64), so a byte product is -4096 where the bits agree and +4096 where they differ and the sum over the 256
+// positions is 4096 * (2 d - 256) = 8192 d - 2^20 -- exact in i32.  The 13 low bits of that sum are zero, so the train
+// index j (< 8192) rides in the accumulator's initial value: v_mfma_i32_32x32x32_i8 leaves  8192 d - 2^20 + j  = the
+// (distance, first index) key itself, and the epilogue per distance is a min and a median (2 VALU ops instead of the
+// 19 of the xor / popcount kernel).  Unpacking costs one shift + one v_bitop3 per four positions:
+//     byte = ((w << (7 - s)) & 0x80) | 0x40            (query; train uses ~w)
+// Position order inside the K = 256 axis is whatever (lane half, shift class s, dword) gives -- the same for both operands.
+// A = train tile (32 rows), B = queries (32 columns): a lane's 16 accumulators are 16 train rows of ONE query, so the
+// running (best, second) keys are two registers per lane and query tile.  Workgroup = 4 wavefronts that share 64 queries
+// (two 32-column tiles kept unpacked in 64 VGPRs) and take every 4th train tile; they merge through LDS at the end.
+typedef int hm_v4i __attribute__((ext_vector_type(4)));
+typedef int hm_v16i __attribute__((ext_vector_type(16)));
+#define HMM_MAX_TRAIN 8192
+#define HMM_NONE 0x40000000          // accumulator start of a train row >= nt: its key stays above every real one
+#define HMM_EMPTY 0x7F000000         // "no key yet"
+
+__device__ __forceinline__ hm_v4i hm_unpack_q(const uint4 w, const int s) {   // bit 1 -> 0xC0 (-64), bit 0 -> 0x40 (+64)
+    const unsigned hi = 0x80808080u, mid = 0x40404040u;
+    hm_v4i r;
+    r.x = (int)__builtin_amdgcn_bitop3_b32(w.x << (7 - s), hi, mid, 0xEA);
+    r.y = (int)__builtin_amdgcn_bitop3_b32(w.y << (7 - s), hi, mid, 0xEA);
+    r.z = (int)__builtin_amdgcn_bitop3_b32(w.z << (7 - s), hi, mid, 0xEA);
+    r.w = (int)__builtin_amdgcn_bitop3_b32(w.w << (7 - s), hi, mid, 0xEA);
+    return r;
+}
+__device__ __forceinline__ hm_v4i hm_unpack_t(const uint4 w, const int s) {   // bit 1 -> 0x40 (+64), bit 0 -> 0xC0 (-64)
+    const unsigned hi = 0x80808080u, mid = 0x40404040u;
+    hm_v4i r;
+    r.x = (int)__builtin_amdgcn_bitop3_b32(w.x << (7 - s), hi, mid, 0xAE);
+    r.y = (int)__builtin_amdgcn_bitop3_b32(w.y << (7 - s), hi, mid, 0xAE);
+    r.z = (int)__builtin_amdgcn_bitop3_b32(w.z << (7 - s), hi, mid, 0xAE);
+    r.w = (int)__builtin_amdgcn_bitop3_b32(w.w << (7 - s), hi, mid, 0xAE);
+    return r;
+}
+// v_med3_i32 has no builtin.  The compiler pads the wait states between an MFMA and a VALU instruction that reads its
+// result only for instructions it knows, not inside asm: `after` is a value computed FROM the same MFMA result by an
+// ordinary instruction (the v_min of the same key), which orders this asm behind that instruction and its padding.
+__device__ __forceinline__ int imed3_after(int a, int b, int c, int after) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c), "v"(after));
+    return r;
+}
+
+// The kernel is bound by vector-instruction ISSUE, which the MFMAs share (8 of an MFMA's 32 cycles): per 64 queries x
+// 32 train rows that is 16 MFMAs (128 cycles of issue) + 64 epilogue instructions + the train tile's unpacking (60,
+// shared by all the query tiles of the wave) at ~4 cycles each.  A wave therefore carries FOUR query tiles (128
+// queries, 128 VGPRs of unpacked queries + 64 of accumulators -> 2 waves per SIMD): 30 + 64 instructions per 16 MFMAs.
+// Workgroup = 4 wavefronts = 4 train slices (a slice takes every 4th train tile) of the same 128 queries, one wave per
+// SIMD; they merge through LDS at the end.
+#define HMM_WAVES 4                   // train slices = wavefronts per workgroup
+#define HMM_NT 4                      // query tiles (32 queries each) per wavefront
+#ifndef HMM_DIAG_EPI
+#define HMM_DIAG_EPI 16
+#endif
+#ifndef HMM_DIAG_STEPS
+#define HMM_DIAG_STEPS 8
+#endif
+#ifndef HMM_STAGGER
+#define HMM_STAGGER 14                // x 64 cycles
+#endif
+
+__device__ __forceinline__ void hm_merge2(int& kb, int& ks, int ob, int os) {   // two smallest of the union of two (best, second) pairs
+    ks = min(min(ks, os), max(kb, ob));
+    kb = min(kb, ob);
+}
+
+__global__ __launch_bounds__(64 * HMM_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void hamming_best2_mfma_kernel(
+    const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed, size_t q_stride,
+    const uint8_t* __restrict__ t, const int* __restrict__ nt_arr, int nt_fixed, size_t t_stride,
+    int* __restrict__ best_idx, int* __restrict__ best, int* __restrict__ second, size_t out_stride) {
+    __shared__ int s_keys[HMM_WAVES - 1][64][2 * HMM_NT];       // slices 1..: (kb, ks) per query tile and lane
+    const int pair = blockIdx.y;
+    const int nq = __builtin_amdgcn_readfirstlane(nq_arr ? nq_arr[pair] : nq_fixed);
+    const int nt = __builtin_amdgcn_readfirstlane(min(nt_arr ? nt_arr[pair] : nt_fixed, HMM_MAX_TRAIN));
+    const int qbase = blockIdx.x * 32 * HMM_NT;
+    if (qbase >= nq) return;  // uniform over the workgroup
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, h = lane >> 5;
+    const uint4* Q = reinterpret_cast<const uint4*>(q + (size_t)pair * q_stride);
+    const uint4* T = reinterpret_cast<const uint4*>(t + (size_t)pair * t_stride);
+    // this lane's half (dwords 4h .. 4h+3) of its queries, unpacked once: 8 k-steps x 4 VGPRs per query tile
+    hm_v4i bq[HMM_NT][8];
+#pragma unroll
+    for (int u = 0; u < HMM_NT; ++u) {
+        const uint4 w = Q[2 * (size_t)min(qbase + 32 * u + col, nq - 1) + h];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bq[u][s] = hm_unpack_q(w, s);
+    }
+    // Accumulator start = row of (register r, lane half h) inside the tile: (r & 3) + 8 (r >> 2) + 4 h -- the same 16
+    // registers for every tile.  The running keys are kept RELATIVE to the current tile's first row (stepping to the next
+    // tile subtracts the stride from them) and the last tile's base is added back at the end.
+    hm_v16i cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 4 * h + (r & 3) + 8 * (r >> 2);
+    int kb[HMM_NT], ks[HMM_NT];
+#pragma unroll
+    for (int u = 0; u < HMM_NT; ++u) kb[u] = ks[u] = HMM_EMPTY;   // (room for the +- tile bases)
+    const int ntiles = (nt + 31) >> 5;
+    uint4 wt = make_uint4(0u, 0u, 0u, 0u);
+    if (wv < ntiles) wt = T[2 * (size_t)min(wv * 32 + col, nt - 1) + h];
+    // The two waves of a SIMD start together and would stay in step -- both in the MFMA phase (sharing the matrix pipe),
+    // then both in the min / median phase (sharing vector issue), neither phase overlapping the other.  The wave in the
+    // odd slot starts half a period late, so one wave's epilogue runs under the other's MFMAs.
+    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u) __builtin_amdgcn_s_sleep(HMM_STAGGER);
+    int tile = wv;
+    for (; tile < ntiles; tile += HMM_WAVES) {
+        const uint4 w = wt;
+#ifndef HMM_DIAG_NOLOAD
+        if (tile + HMM_WAVES < ntiles) wt = T[2 * (size_t)min((tile + HMM_WAVES) * 32 + col, nt - 1) + h];   // travels during this tile
+#else
+        wt.x += 0x01020304u * tile;
+#endif
+        hm_v16i c[HMM_NT];
+        {
+            const hm_v4i a = hm_unpack_t(w, 0);
+            hm_v16i cm = cinit;
+            if (tile * 32 + 32 > nt) {   // the set's last, partial tile: rows >= nt start above every real key
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cm[r] = tile * 32 + cinit[r] < nt ? cinit[r] : HMM_NONE;
+            }
+#pragma unroll
+            for (int u = 0; u < HMM_NT; ++u) c[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][0], cm, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 1; s < HMM_DIAG_STEPS; ++s) {
+            const hm_v4i a = hm_unpack_t(w, s);
+#pragma unroll
+            for (int u = 0; u < HMM_NT; ++u) c[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s], c[u], 0, 0, 0);
+        }
+        if (tile != wv) {
+#pragma unroll
+            for (int u = 0; u < HMM_NT; ++u) { kb[u] -= 32 * HMM_WAVES; ks[u] -= 32 * HMM_WAVES; }
+        }
+#pragma unroll
+        for (int u = 0; u < HMM_NT; ++u) {
+#pragma unroll
+            for (int r = 0; r < HMM_DIAG_EPI; ++r) {
+                const int n = min(kb[u], c[u][r]);
+#ifndef HMM_DIAG_NOASM
+                ks[u] = imed3_after(kb[u], ks[u], c[u][r], n);   // kb <= ks: the median of the three is the new second smallest
+#else
+                ks[u] = max(kb[u], min(ks[u], c[u][r]));
+#endif
+                kb[u] = n;
+            }
+        }
+    }
+    if (tile != wv) {   // this wave saw at least one tile: back to absolute train indices (base of its last tile)
+        const int base = (tile - HMM_WAVES) * 32;
+#pragma unroll
+        for (int u = 0; u < HMM_NT; ++u) { kb[u] += base; ks[u] += base; }
+    }
+    // the two lane halves hold different train rows of the same query
+#pragma unroll
+    for (int u = 0; u < HMM_NT; ++u) hm_merge2(kb[u], ks[u], __shfl_xor(kb[u], 32, 64), __shfl_xor(ks[u], 32, 64));
+    if (wv > 0) {
+#pragma unroll
+        for (int u = 0; u < HMM_NT; ++u) { s_keys[wv - 1][lane][2 * u] = kb[u]; s_keys[wv - 1][lane][2 * u + 1] = ks[u]; }
+    }
+    __syncthreads();
+    if (wv != 0 || h != 0) return;
+#pragma unroll
+    for (int o = 0; o < HMM_WAVES - 1; ++o) {
+#pragma unroll
+        for (int u = 0; u < HMM_NT; ++u) hm_merge2(kb[u], ks[u], s_keys[o][lane][2 * u], s_keys[o][lane][2 * u + 1]);
+    }
+    // key = 8192 d - 2^20 + j; anything from HMM_NONE / the empty start is far above 2^29
+#pragma unroll
+    for (int u = 0; u < HMM_NT; ++u) {
+        const int qi = qbase + 32 * u + col;
+        if (qi >= nq) continue;
+        const bool hb = kb[u] < 0x20000000, hs = ks[u] < 0x20000000;
+        const size_t o = (size_t)pair * out_stride + qi;
+        best_idx[o] = hb ? ((kb[u] + (1 << 20)) & 8191) : -1;
+        best[o] = hb ? ((kb[u] + (1 << 20)) >> 13) : 256;
+        second[o] = hs ? ((ks[u] + (1 << 20)) >> 13) : 256;
+    }
+}
+
 __global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t* __restrict__ q, int nq,
                                                              const uint8_t* __restrict__ t, int nt,
                                                              uint16_t* __restrict__ out) {
@@ -174,6 +357,13 @@ __global__ __launch_bounds__(64) void distinctive_kernel(const uint8_t* __restri
     if (lane == 0) { best_idx[p] = (int)(bestkey & 0xFFFF); best_median[p] = (int)(bestkey >> 16); }
 }
 
+// the matrix-core kernel carries the train index in 13 bits; larger train sets (and SLAMIT_HAMMING_VALU=1, for A/B
+// measurements) take the xor / popcount kernel.  Both give the same (index, best, second).
+static bool hm_use_mfma(int max_train) {
+    static const bool off = getenv("SLAMIT_HAMMING_VALU") != nullptr;
+    return !off && max_train <= HMM_MAX_TRAIN;
+}
+
 extern "C" {
 
 int slamit_distinctive_batch(const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx,
@@ -225,9 +415,14 @@ int slamit_hamming_best2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, size
     if (npairs == 0 || max_n == 0) return SLAMIT_OK;
     if (max_n > SLAMIT_HAMMING_MAX_TRAIN) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_hamming_best2_batch_dev: more than SLAMIT_HAMMING_MAX_TRAIN descriptors per set");
     SLAMIT_USE_DEVICE(device);
-    dim3 grid((max_n + HM_QPB - 1) / HM_QPB, npairs);
-    hipLaunchKernelGGL(hamming_best2_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_q, d_nq, 0, q_stride, d_t, d_nt,
-                       0, t_stride, d_best_idx, d_best, d_second, out_stride);
+    if (hm_use_mfma(max_n)) {
+        hipLaunchKernelGGL(hamming_best2_mfma_kernel, dim3((max_n + 32 * HMM_NT - 1) / (32 * HMM_NT), npairs), dim3(64 * HMM_WAVES), 0, (hipStream_t)stream, d_q, d_nq, 0, q_stride,
+                           d_t, d_nt, 0, t_stride, d_best_idx, d_best, d_second, out_stride);
+    } else {
+        dim3 grid((max_n + HM_QPB - 1) / HM_QPB, npairs);
+        hipLaunchKernelGGL(hamming_best2_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_q, d_nq, 0, q_stride, d_t, d_nt,
+                           0, t_stride, d_best_idx, d_best, d_second, out_stride);
+    }
     HIP_TRY(hipGetLastError());
     return SLAMIT_OK;
 }
@@ -252,8 +447,12 @@ int slamit_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int
     }
     if (e == hipSuccess) {
         int* dout = reinterpret_cast<int*>(S.dev + o_out);
-        hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + HM_QPB - 1) / HM_QPB, 1), dim3(256), 0, S.st, S.dev, (const int*)nullptr, nq,
-                           (size_t)0, S.dev + o_t, (const int*)nullptr, nt, (size_t)0, dout, dout + nq, dout + 2 * (size_t)nq, (size_t)0);
+        if (hm_use_mfma(nt))
+            hipLaunchKernelGGL(hamming_best2_mfma_kernel, dim3((nq + 32 * HMM_NT - 1) / (32 * HMM_NT), 1), dim3(64 * HMM_WAVES), 0, S.st, S.dev, (const int*)nullptr, nq,
+                               (size_t)0, S.dev + o_t, (const int*)nullptr, nt, (size_t)0, dout, dout + nq, dout + 2 * (size_t)nq, (size_t)0);
+        else
+            hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + HM_QPB - 1) / HM_QPB, 1), dim3(256), 0, S.st, S.dev, (const int*)nullptr, nq,
+                               (size_t)0, S.dev + o_t, (const int*)nullptr, nt, (size_t)0, dout, dout + nq, dout + 2 * (size_t)nq, (size_t)0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(S.host + o_out, S.dev + o_out, bytes - o_out, hipMemcpyDeviceToHost, S.st);

@@ -80,13 +80,10 @@ __device__ __forceinline__ uint32_t rs_dot2(uint32_t taps, uint32_t alpha) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(rs_us2, taps), __builtin_bit_cast(rs_us2, alpha), 0u, false);
 }
 
-template <int RP>   // RP row pairs (2 * RP dst rows) per lane
-__global__ __launch_bounds__(256) void resize_rows4_kernel(
-    const uint8_t* __restrict__ src, size_t sstride, size_t sframe,
-    uint8_t* __restrict__ dst, size_t dstride, size_t dframe,
-    const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, int ngroups, unsigned inv_groups, int nitems, int dh) {
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item >= nitems) return;
+template <int RP>   // RP row pairs (2 * RP dst rows) per lane; S / D: the frame's source and destination planes
+__device__ __forceinline__ void rs_item(const int item, const uint8_t* S, const unsigned ss, uint8_t* D, const unsigned dstride,
+                                        const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, const int ngroups,
+                                        const unsigned inv_groups, const int dh) {
     const int yq = (int)__umulhi((unsigned)item, inv_groups);
     const int g = item - yq * ngroups;
     // uniform 64-bit bases + 32-bit per-lane offsets (planes are far below 4 GB): global_load saddr + voffset
@@ -103,9 +100,6 @@ __global__ __launch_bounds__(256) void resize_rows4_kernel(
         rt[r] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(rowtab) + 8u * (unsigned)yrow[r]);
     }
     const unsigned b = c0.x & 0xFFFFu, sh = (c0.x >> 16) & 3u, off1 = (c0.x >> 20) & 15u, off2 = (c0.x >> 24) & 15u;
-    const uint8_t* S = src + (size_t)blockIdx.y * sframe;
-    uint8_t* D = dst + (size_t)blockIdx.y * dframe;
-    const unsigned ss = (unsigned)sstride;
     const uint32_t sel[4] = {c0.y, c0.z, c0.w, c1.x}, al[4] = {c1.y, c1.z, c1.w, c2x};
     uint32_t w[4 * RP][3];   // the 12-byte windows of the source rows (two per dst row)
 #pragma unroll
@@ -132,8 +126,19 @@ __global__ __launch_bounds__(256) void resize_rows4_kernel(
             const uint32_t v = ((__umul24(b0, h[0][j]) >> 16) + (__umul24(b1, h[1][j]) >> 16) + 2u) >> 2;
             out |= (v & 0xFFu) << (8 * j);
         }
-        *reinterpret_cast<uint32_t*>(D + (__umul24((unsigned)yrow[k], (unsigned)dstride) + 4u * (unsigned)g)) = out;
+        *reinterpret_cast<uint32_t*>(D + (__umul24((unsigned)yrow[k], dstride) + 4u * (unsigned)g)) = out;
     }
+}
+
+template <int RP>
+__global__ __launch_bounds__(256) void resize_rows4_kernel(
+    const uint8_t* __restrict__ src, size_t sstride, size_t sframe,
+    uint8_t* __restrict__ dst, size_t dstride, size_t dframe,
+    const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, int ngroups, unsigned inv_groups, int nitems, int dh) {
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= nitems) return;
+    rs_item<RP>(item, src + (size_t)blockIdx.y * sframe, (unsigned)sstride, dst + (size_t)blockIdx.y * dframe, (unsigned)dstride, coltab, rowtab,
+                ngroups, inv_groups, dh);
 }
 
 // Host: tables of resize_rows4_kernel for one level from the reference-shaped xofs/ialpha/yofs/ibeta tables.
@@ -487,6 +492,12 @@ __device__ __forceinline__ void fast_cell_wave(
 
     const int ngrp = (sw + 3) >> 2;          // groups of 4 scan pixels per row
     const int nitems = ngrp * sh;
+    // pre-test mapping: lane -> (row within a step, column group)
+    const int p_rsub = (int)(__umul24(lane, inv_g) >> 20), p_x0 = (lane - p_rsub * ngrp) * 4;
+    const int rps = (int)(__umul24(WAVE, inv_g) >> 20);      // WAVE / ngrp rows per step (ngrp <= 16: cells are <= 64 px wide)
+    const bool p_active = p_rsub < rps;
+    unsigned p_vmask = 0x80808080u;                          // pixels of the row's last group beyond the scan row (0 .. 3) are masked
+    if (p_x0 + 4 - sw > 0) p_vmask >>= 8 * (p_x0 + 4 - sw);
 
     // Two attempts like the reference: FAST at iniThFAST, and only if the cell stays empty, again at
     // minThFAST (ORBextractor.cc:827-833).  Per attempt:
@@ -509,14 +520,14 @@ __device__ __forceinline__ void fast_cell_wave(
         int nB = 0, nD = 0;   // survivor stacks: brighter-than-centre / darker-than-centre candidates, entry = y << 6 | x
         int ncorner = 0;
         bool corner_overflow = false;
-        for (int i0 = 0; i0 < nitems; i0 += WAVE) {
-            const int it = i0 + lane;
+        // a lane keeps its column group for the whole cell (rps rows of ngrp groups per step; the 64 % ngrp lanes left over
+        // idle): column, tail mask and the LDS address are loop invariants and a step costs one add per lane
+        for (int y0 = 0; y0 < sh; y0 += rps) {
+            const int y = y0 + p_rsub;
             unsigned pb = 0, pd = 0;
-            unsigned e0 = 0;
-            if (it < nitems) {
-                const int y = (int)(__umul24(it, inv_g) >> 20);
-                const int x0 = (it - y * ngrp) * 4;
-                e0 = (unsigned)((y << 6) | x0);
+            const unsigned e0 = (unsigned)((y << 6) | p_x0);
+            if (p_active && y < sh) {
+                const int x0 = p_x0;
                 const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(y + 3) * PITCH + x0 + SC_COL0]);
                 const unsigned C = rowc[0], Dm = rowc[-1], Dp = rowc[1];
                 const unsigned N = *reinterpret_cast<const uint32_t*>(&tile[y * PITCH + x0 + SC_COL0]);
@@ -531,27 +542,24 @@ __device__ __forceinline__ void fast_cell_wave(
 #undef BRIGHT
 #undef DARK
                 // two adjacent compass points of one polarity: NE | ES | SW | WN == (N | S) & (E | W); v_bitop3 is full rate
-                unsigned vmask = 0x80808080u;
-                const int over = x0 + 4 - sw;            // pixels of this group beyond the scan row (0..3)
-                if (over > 0) vmask >>= 8 * over;
-                pb = __builtin_amdgcn_bitop3_b32(bN | bS, bE, bW, 0xE0) & vmask;
-                pd = __builtin_amdgcn_bitop3_b32(dN | dS, dE, dW, 0xE0) & vmask;
+                pb = __builtin_amdgcn_bitop3_b32(bN | bS, bE, bW, 0xE0) & p_vmask;
+                pd = __builtin_amdgcn_bitop3_b32(dN | dS, dE, dW, 0xE0) & p_vmask;
             }
             // compaction: one ballot per pixel slot and polarity; a pixel that passed both tests is on both stacks
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool pass = ((pb >> (8 * j)) & 0xFFu) != 0u;   // byte select: one v_cmp_ne_u32_sdwa
-                const unsigned long long mk = __ballot(pass);
-                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)nB));
-                if (pass) s_listB[pos] = (unsigned short)(e0 + j);
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                if (pass) (s_listB + nB)[pos] = (unsigned short)(e0 + j);
                 nB += __popcll(mk);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool pass = ((pd >> (8 * j)) & 0xFFu) != 0u;
-                const unsigned long long mk = __ballot(pass);
-                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)nD));
-                if (pass) s_listD[pos] = (unsigned short)(e0 + j);
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                if (pass) (s_listD + nD)[pos] = (unsigned short)(e0 + j);
                 nD += __popcll(mk);
             }
             // scoring: 64 + 64 candidates per pass off the tops of the stacks, whenever one of them holds 64 (after the
@@ -560,7 +568,7 @@ __device__ __forceinline__ void fast_cell_wave(
             // (neg_hi): min / max then compute  max over the 16 arcs of (min over the arc's 9 pixels)  in the low half and
             // -(min over arcs of max over arc)  in the high half.  The lanes hold the integers 0 .. 255 as f16 bit
             // patterns (denormals, kept by the default FP mode) and are only compared.
-            const bool last = i0 + WAVE >= nitems;
+            const bool last = y0 + rps >= sh;
             while (nB >= 64 || nD >= 64 || (last && (nB | nD) != 0)) {
                 wave_sync_lds();
                 FD_STAMP(1);
@@ -601,13 +609,13 @@ __device__ __forceinline__ void fast_cell_wave(
                 {   // the corners are also listed (in the keypoint array: NMS compacts it in place), so that NMS visits the
                     // ~12 % of the pixels that are corners instead of all of them; a cell with more corners than the
                     // array holds falls back to the pass over the whole score tile
-                    const unsigned long long m0 = __ballot(clo), m1 = __ballot(chi);
-                    const int add = __popcll(m0) + __popcll(m1);
+                    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(clo), m1 = __builtin_amdgcn_ballot_w64(chi);
+                    const int n0 = __popcll(m0), add = n0 + __popcll(m1);
                     if (ncorner + add <= kp_cap) {
-                        const unsigned p0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, (unsigned)ncorner));
-                        const unsigned p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, (unsigned)(ncorner + __popcll(m0))));
-                        if (clo) s_kp[p0] = (unsigned short)elo;
-                        if (chi) s_kp[p1] = (unsigned short)ehi;
+                        const unsigned p0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+                        const unsigned p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+                        if (clo) (s_kp + ncorner)[p0] = (unsigned short)elo;
+                        if (chi) (s_kp + ncorner + n0)[p1] = (unsigned short)ehi;
                     } else corner_overflow = true;
                     ncorner += add;
                 }
