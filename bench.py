@@ -242,7 +242,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="independent 640x480 streams per GPU")
+    # 128 streams per step: per-frame cost keeps falling up to about there (launch floor, ramp and tail of ~13 launches per
+    # step, and the octree's one long workgroup per frame, are paid once per step): 64 -> 195.6k frames/s, 96 -> 207k,
+    # 128 -> 215k, 160 -> 216k on one MI355X
+    ap.add_argument("--batch", type=int, default=128, help="independent camera streams per GPU and step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -30,7 +30,8 @@ def test_bench_line_schema_single_gpu():
     assert d["vs_baseline"] is None and d["dtype"] == "u8" and d["scaling"] == "weak" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["launches"] >= 1
-    assert abs(d["value"] - 64 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 0.01
+    frames = d["config"]["frames_per_step_per_gpu"]
+    assert frames == 128 and abs(d["value"] - frames * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 0.01
 
 
 def test_bench_two_rank_rehearsal():
@@ -40,7 +41,8 @@ def test_bench_two_rank_rehearsal():
     out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=600, env=env)
     d = _line(out)
     assert d["n_gpus"] == 2 and d["steps"] == 3
-    assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # whole-job aggregate over both ranks
+    frames = d["config"]["frames_per_step_per_gpu"]
+    assert abs(d["value"] - 2 * frames * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01   # whole-job aggregate over both ranks
 
 
 def test_bench_pipeline_config_single_gpu_and_two_rank_rehearsal():

@@ -163,7 +163,6 @@ def _apply_in_order(n, state, match):
     return owner
 
 
-@pytest.mark.gpu
 def _gemm_row(Rrow, t, X, Y, Z):
     """One row of cv::Mat x3Dc = Rcw * x3Dw + tcw on CV_32F operands: cv::gemm sums in double and rounds once
     (the model the shim templates follow, ORBmatcher.cc:1363, 851, 1497)."""
@@ -171,6 +170,7 @@ def _gemm_row(Rrow, t, X, Y, Z):
     return (f64(Rrow[0]) * X.astype(f64) + f64(Rrow[1]) * Y.astype(f64) + f64(Rrow[2]) * Z.astype(f64) + f64(t)).astype(np.float32)
 
 
+@pytest.mark.gpu
 def test_shim_search_by_projection_local_map(tmp_path):
     """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) through the template + mock types."""
     from oracle import bindings as ob

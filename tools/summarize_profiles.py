@@ -104,8 +104,14 @@ def copy_bench(src, name, dst):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if not frames:   # frames per launch = the bench's default batch, as the collected bench line states it
+        try:
+            line = [l for l in open(os.path.join(src, "bench.json")).read().splitlines() if l.startswith("{")][-1]
+            frames = int(json.loads(line)["config"]["frames_per_step_per_gpu"])
+        except Exception:
+            frames = 128
     dst = os.path.join(ROOT, "profiles")
     done = []
     for sub, out in (("trace", "_bench_kernel_stats.csv"), ("trace720", "_bench_720p_kernel_stats.csv"), ("ba_trace", "_ba_kernel_stats.csv")):

@@ -104,7 +104,8 @@ struct slamit_orb {
     int device;
     hipStream_t stream;
     hipStream_t stream_b;     // side stream: the blur of a call runs beside its FAST / octree / orientation launches
-    hipEvent_t ev_pyr, ev_blur;
+    hipEvent_t ev_pyr, ev_mid, ev_blur;
+    int blur_split;       // levels 0 .. blur_split are blurred beside the tail of the pyramid chain (-1: all after FAST)
     int overlap;              // 0: everything on one stream (SLAMIT_ORB_SERIAL=1)
     int nlevels;
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
@@ -169,6 +170,7 @@ static void orb_free(slamit_orb* h) {
     for (int l = 0; l < ORB_MAX_LEVELS; ++l) { hipFree(h->d_rs_col[l]); hipFree(h->d_rs_row[l]); }
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
     if (h->ev_pyr) hipEventDestroy(h->ev_pyr);
+    if (h->ev_mid) hipEventDestroy(h->ev_mid);
     if (h->ev_blur) hipEventDestroy(h->ev_blur);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -306,6 +308,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming);
     h->overlap = getenv("SLAMIT_ORB_SERIAL") ? 0 : 1;
     if (e == hipSuccess && !empty) e = hipMemcpy(h->d_levels, h->levels.data(), sizeof(OrbLevel) * nl, hipMemcpyHostToDevice);
@@ -427,6 +430,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
             first = last;
         }
         h->pyr_mode = (getenv("SLAMIT_PYR_FUSED") || !rows4_ok) ? 1 : 0;
+        h->blur_split = getenv("SLAMIT_BLUR_SPLIT") ? atoi(getenv("SLAMIT_BLUR_SPLIT")) : 2;
         if (getenv("SLAMIT_PYR_PER_LEVEL")) { okb = false; h->pyr_mode = 1; }   // diagnostic: force the old per-level kernel
         if (!okb) h->pyr_segs.clear();                      // fall back to the per-level kernel
         if (!h->pyr_segs.empty()) {
@@ -517,6 +521,8 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     // K1: pyramid, level l from level l-1
     prof_mark(h, st, ST_RESIZE, true);
     const bool src0_aligned = ((((uintptr_t)d_gray) | stride | frame_stride) & 3) == 0;
+    const bool early_blur = h->overlap && h->prof_on != 1 && h->blur_split >= 1 && h->blur_split < nl - 1;
+    bool early_done = false;
     if (h->pyr_mode == 0 && src0_aligned) {
         for (int l = 1; l < nl; ++l) {
             const OrbLevel& S = h->levels[l - 1];
@@ -524,6 +530,15 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
             const uint8_t* src = l == 1 ? d_gray : h->d_pyr + S.plane_off;
             orbk_resize_rows4(st, src, l == 1 ? stride : (size_t)S.stride, l == 1 ? frame_stride : h->pyr_frame_total,
                               h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride, h->pyr_frame_total, h->d_rs_col[l], h->d_rs_row[l], nframes);
+            if (early_blur && l == h->blur_split) {
+                // the blur of the big levels 0 .. l (most of its bytes) runs on the side stream beside the rest of the chain:
+                // the small levels are a few microseconds of work behind a kernel boundary each and leave the chip idle
+                HIP_TRY(hipEventRecord(h->ev_mid, st));
+                HIP_TRY(hipStreamWaitEvent(h->stream_b, h->ev_mid, 0));
+                orbk_blur(h->stream_b, h->d_levels, h->d_blur_tiles, h->levels[l + 1].blur_tile_base, d_gray, stride, frame_stride, h->d_pyr,
+                          h->d_blur, nframes);
+                early_done = true;
+            }
         }
     } else if (!h->pyr_segs.empty()) {
         for (const slamit_orb::PyrSeg& sg : h->pyr_segs)
@@ -571,7 +586,9 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     if (side && !fork_early) {
         HIP_TRY(hipEventRecord(h->ev_pyr, st));
         HIP_TRY(hipStreamWaitEvent(h->stream_b, h->ev_pyr, 0));
-        orbk_blur(h->stream_b, h->d_levels, h->d_blur_tiles, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
+        const int t0 = early_done ? h->levels[h->blur_split + 1].blur_tile_base : 0;   // the levels the early launch left
+        orbk_blur(h->stream_b, h->d_levels, h->d_blur_tiles + 4 * (size_t)t0, h->blur_tiles - t0, d_gray, stride, frame_stride, h->d_pyr,
+                  h->d_blur, nframes);
         HIP_TRY(hipEventRecord(h->ev_blur, h->stream_b));
     }
     // K4: octree
