@@ -245,7 +245,8 @@ def main():
     # 128 streams per step: per-frame cost keeps falling up to about there (launch floor, ramp and tail of ~13 launches per
     # step, and the octree's one long workgroup per frame, are paid once per step): 64 -> 195.6k frames/s, 96 -> 207k,
     # 128 -> 215k, 160 -> 216k on one MI355X
-    ap.add_argument("--batch", type=int, default=128, help="independent camera streams per GPU and step")
+    ap.add_argument("--batch", type=int, default=None, help="independent camera streams per GPU and step (default: 128 at VGA, 64 at 720p "
+                    "as BASELINE configs[2] words it)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -292,7 +293,7 @@ def main():
         fa = [synth.synth_frame(W, H, 5000 + sid) for sid in mine]
         fb = [synth.warp_frame(fa[i], 5000 + sid) for i, sid in enumerate(mine)]
     else:
-        B = args.batch
+        B = args.batch if args.batch else (128 if args.config == "vga" else 64)
         # each rank owns its own B streams (different seeds per rank); two consecutive frames per stream; 16 distinct
         # frame pairs per rank, each used by B / 16 streams (the kernels are issue bound: content repeats do not help them)
         uniq = min(B, 16)

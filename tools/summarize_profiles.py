@@ -140,9 +140,16 @@ def main():
                "kernels": kernels}
         json.dump(doc, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1); done.append("_hbm_traffic.json")
     # ---- FAST issue counters ----
-    geo = {"vga": (640 * 480, 950532, "trace"), "720p": (1280 * 720, 2853088, "trace720")}
+    geo = {"vga": (640 * 480, 950532, "trace", "bench.json"), "720p": (1280 * 720, 2853088, "trace720", "bench_720p.json")}
     fast = {}
-    for cfg, (_, pyr_px, tr) in geo.items():
+    frames_vga = frames
+    for cfg, (_, pyr_px, tr, bj) in geo.items():
+        frames = frames_vga
+        try:   # frames per launch of this geometry's runs = the default batch of its bench line
+            line = [l for l in open(os.path.join(src, bj)).read().splitlines() if l.startswith("{")][-1]
+            frames = int(json.loads(line)["config"]["frames_per_step_per_gpu"])
+        except Exception:
+            pass
         c = {}
         for part in ("sq_a_", "sq_b_"):
             for (k, grid), v in counters_by_kernel_and_grid(os.path.join(src, part + cfg), want=("fast_cells_kernel",)).items():
@@ -151,7 +158,7 @@ def main():
             continue
         us = kernel_avg_us(os.path.join(src, tr), "fast_cells_kernel")
         px = pyr_px * frames
-        e = {"pyramid_pixels_per_launch": px, "counters_per_launch": {k: round(v) for k, v in sorted(c.items())},
+        e = {"frames_per_launch": frames, "pyramid_pixels_per_launch": px, "counters_per_launch": {k: round(v) for k, v in sorted(c.items())},
              "avg_launch_us_rocprof": round(us, 2) if us else None}
         if "SQ_INSTS_VALU" in c:
             total = c.get("SQ_INSTS_VALU", 0) + c.get("SQ_INSTS_SALU", 0) + c.get("SQ_INSTS_LDS", 0) + c.get("SQ_INSTS_VMEM_RD", 0)
@@ -166,11 +173,12 @@ def main():
         fast[cfg] = e
     if fast:
         doc = {"_about": "SQ counters of the shipped fast_cells_kernel (rocprofv3 --kernel-trace --pmc, two passes of 8 counters, `python3 "
-                         "bench.py --no-ba --no-cpu --config <cfg> --steps 3 --warmup 1`), means per launch of %d frames, with the launch duration of "
+                         "bench.py --no-ba --no-cpu --config <cfg> --steps 3 --warmup 1`), means per launch (frames_per_launch: the configuration's default batch), with the launch duration of "
                          "the --kernel-trace --stats run of the same build.  1024 SIMDs.  Measured issue cost on this chip "
                          "(tools/diag/ubench, wall clock at 4 waves per SIMD): 2.29 ns per half-rate VALU wave-instruction per SIMD "
-                         "(v_lerp_u8, v_perm, v_pk_*, 3-operand integer ops), 1.53 ns per full-rate one (v_and/or/xor/add, v_bitop3)." % frames,
+                         "(v_lerp_u8, v_perm, v_pk_*, 3-operand integer ops), 1.53 ns per full-rate one (v_and/or/xor/add, v_bitop3).",
                "kernel_src_sha16": sha16(os.path.join(ROOT, "weiner_slamit_v2_amd", "csrc", "orb_kernels.hip")), "geometries": fast}
+        frames = frames_vga
         json.dump(doc, open(os.path.join(dst, tag + "_fast_issue.json"), "w"), indent=1); done.append("_fast_issue.json")
     # ---- BA matrix-core counters per kernel and grid shape ----
     ba = counters_by_kernel_and_grid(os.path.join(src, "ba_mfma"), want=("k_schur", "k_ldlt_solve"))
