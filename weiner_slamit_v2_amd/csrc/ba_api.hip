@@ -283,6 +283,9 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
                 w.panel_hi[i] = (int16_t)std::min(hi, n - 1);
                 w.back_lo[i] = (int16_t)lo;
             }
+            int band = 0;   // a window whose keyframes only share points with their neighbours has a narrow band: LDLt inside LDS
+            for (int c = 0; c < nfree; ++c) band = std::max(band, 6 * c + 5 - 6 * fcol[c]);
+            w.band = std::min(band, std::max(n - 1, 0));
         }
         // ---- inputs, straight into the pinned block: CSR by point / by keyframe (counting sort, caller order kept
         // inside each list), points in device order ----
@@ -382,6 +385,10 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             fprintf(stderr, "[ba diag] ldlt shader cycles %llu, realtime ticks (100 MHz) %llu -> %.0f MHz, %.1f us\n",
                     S0.dbg[2] - S0.dbg[0], S0.dbg[3] - S0.dbg[1],
                     100.0 * (double)(S0.dbg[2] - S0.dbg[0]) / (double)(S0.dbg[3] - S0.dbg[1] + 1), (double)(S0.dbg[3] - S0.dbg[1]) / 100.0);
+            fprintf(stderr, "[ba diag] dbg7 raw %llx\n", S0.dbg[7]);
+            if (S0.dbg[7])
+                fprintf(stderr, "[ba diag] band step, cycles (1023 = clipped): matrix wave wait %llu compute+store %llu barrier %llu | pivot wave wait %llu compute+store %llu barrier %llu\n",
+                        (S0.dbg[7] >> 50) & 1023, (S0.dbg[7] >> 40) & 1023, (S0.dbg[7] >> 30) & 1023, (S0.dbg[7] >> 20) & 1023, (S0.dbg[7] >> 10) & 1023, S0.dbg[7] & 1023);
             fprintf(stderr, "[ba diag] ldlt phase cycles: load %llu factor %llu rows %llu writeback %llu trailing %llu backsub %llu\n",
                     S0.dbg[4] >> 32, S0.dbg[4] & 0xffffffffull, S0.dbg[5] >> 32, S0.dbg[5] & 0xffffffffull, S0.dbg[6] >> 32, S0.dbg[6] & 0xffffffffull);
         }

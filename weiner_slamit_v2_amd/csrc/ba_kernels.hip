@@ -432,35 +432,44 @@ __device__ __forceinline__ void ldlt_factor_diag(double* Dg, double* s_invd, dou
     }
     const bool two_entries = tid < LD_NB * (LD_NB + 1) / 2 - LD_THREADS;
     double v0 = Dg[r0 * LD_P + c0], v1 = two_entries ? Dg[r1 * LD_P + c1] : 0.0;
+    // The step is bound by the instructions every wave issues (two waves per SIMD run the same stream), not by latency:
+    // every load is unconditional (rows and columns < 32 are always inside the block; an inactive entry computes on
+    // whatever it reads and keeps its old value through a select), the second entry of threads 0..15 sits behind a
+    // wave-uniform branch, and 1/d1 comes from the 2x2 determinant so that both reciprocals start at once:
+    //     1/d1 = d0 / (d0 d11 - l10^2).
+    const double* pr0 = Dg + r0 * LD_P;
+    const double* pc0 = Dg + c0 * LD_P;
+    const double* pr1 = Dg + r1 * LD_P;
+    const double* pc1 = Dg + c1 * LD_P;
+    const bool in0 = r0 < nb, in1 = two_entries && r1 < nb;
     for (int k = 0; k < nb; k += 2) {
-        const bool two = k + 1 < nb;
-        const double d0 = Dg[k * LD_P + k];
-        const double l10 = two ? Dg[(k + 1) * LD_P + k] : 0.0;
-        const double d11 = two ? Dg[(k + 1) * LD_P + k + 1] : 1.0;
-        const bool act0 = c0 >= k + 2 && r0 < nb, act1 = two_entries && c1 >= k + 2 && r1 < nb;
-        const double ark0 = act0 ? Dg[r0 * LD_P + k] : 0.0, ack0 = act0 ? Dg[c0 * LD_P + k] : 0.0;
-        const double ar10 = act0 ? Dg[r0 * LD_P + k + 1] : 0.0, ac10 = act0 ? Dg[c0 * LD_P + k + 1] : 0.0;
-        const double ark1 = act1 ? Dg[r1 * LD_P + k] : 0.0, ack1 = act1 ? Dg[c1 * LD_P + k] : 0.0;
-        const double ar11 = act1 ? Dg[r1 * LD_P + k + 1] : 0.0, ac11 = act1 ? Dg[c1 * LD_P + k + 1] : 0.0;
+        const bool two = k + 1 < nb;   // (row / column nb of a short block hold zeros)
+        const double d0 = Dg[k * LD_P + k], l10 = Dg[(k + 1) * LD_P + k], d11 = Dg[(k + 1) * LD_P + k + 1];
+        const double ark0 = pr0[k], ar10 = pr0[k + 1], ack0 = pc0[k], ac10 = pc0[k + 1];
         const bool bad0 = (d0 == 0.0 || !(fabs(d0) <= DBL_MAX));
+        const double det = d0 * d11 - l10 * l10;
         const double inv0 = bad0 ? 0.0 : fast_recip(d0);
+        const bool bad1 = two && (det == 0.0 || !(fabs(det) <= DBL_MAX));
+        const double inv1 = (two && !bad1 && !bad0) ? d0 * fast_recip(det) : 0.0;
         const double f = l10 * inv0;
-        const double d1 = two ? d11 - l10 * f : 1.0;
-        const bool bad1 = two && (d1 == 0.0 || !(fabs(d1) <= DBL_MAX));
-        const double inv1 = (two && !bad1) ? fast_recip(d1) : 0.0;
-        if (act0) {
+        {
             const double ar1 = ar10 - ark0 * f, ac1 = ac10 - ack0 * f;
-            v0 -= ark0 * ack0 * inv0 + ar1 * ac1 * inv1;
-            if (c0 <= k + 3) Dg[r0 * LD_P + c0] = v0;   // column c0 is a pivot column of the next step
+            const double nv = v0 - (ark0 * ack0 * inv0 + ar1 * ac1 * inv1);
+            const bool act0 = in0 && c0 >= k + 2;
+            v0 = act0 ? nv : v0;
+            if (act0 && c0 <= k + 3) Dg[r0 * LD_P + c0] = v0;   // column c0 is a pivot column of the next step
         }
-        if (act1) {
+        if (tid < 64) {   // wave-uniform: the 16 leftover entries (tail of row 31) live in wave 0
+            const double ark1 = pr1[k], ar11 = pr1[k + 1], ack1 = pc1[k], ac11 = pc1[k + 1];
             const double ar1 = ar11 - ark1 * f, ac1 = ac11 - ack1 * f;
-            v1 -= ark1 * ack1 * inv0 + ar1 * ac1 * inv1;
-            if (c1 <= k + 3) Dg[r1 * LD_P + c1] = v1;
+            const double nv = v1 - (ark1 * ack1 * inv0 + ar1 * ac1 * inv1);
+            const bool act1 = in1 && c1 >= k + 2;
+            v1 = act1 ? nv : v1;
+            if (act1 && c1 <= k + 3) Dg[r1 * LD_P + c1] = v1;
         }
         if (tid == 0) {
             s_invd[k] = inv0;
-            if (two) { s_invd[k + 1] = inv1; s_corr[k + 1] = f; s_dval[k + 1] = d1; }
+            if (two) { s_invd[k + 1] = inv1; s_corr[k + 1] = f; s_dval[k + 1] = d11 - l10 * f; }
             if (bad0 || bad1) *s_fail = 1;
         }
         __syncthreads();
@@ -524,6 +533,257 @@ __device__ __forceinline__ void ldlt_back_block(const gdouble* S, int N, double*
     if (k < nb) xs[jb + k] = v;
 }
 
+// ---- banded path ---------------------------------------------------------------------------------------------
+// A local window whose keyframes share points only with their neighbours (ORB-SLAM's local BA: co-visibility falls off
+// with the distance along the trajectory) gives a reduced system with a narrow row envelope, and LDLt without pivoting
+// never fills outside it.  With half bandwidth bw the lower band (n rows of bw + 2 doubles: column r - bw - 1, always
+// zero, .. column r) fits the CU's LDS for n = 300, bw <= 60, and the whole solve runs there: no panel staging from L2,
+// no write-back, no trailing update through L2 -- just n / 2 right-looking steps of TWO columns each (the rank-2 update
+// of ldlt_factor_diag, applied to the bw x bw triangle under the pivots and to the right-hand side, which rides along
+// as "row n"), one barrier per step, then the unit-L form and a blocked backward substitution, all out of LDS.
+// Entry (r, c) of the band lives at Ab[r * RS + c - r + bw + 1].
+#define LD_BAND_LDS (150 * 1024)     // dynamic LDS the kernel may use (bak_ldlt_smem requests at least this much when it fits)
+// Row stride EVEN: a column of the band, A(c, k) for c = k + 1, k + 2, .., is a walk of RS - 1 doubles per row, and an odd number
+// of doubles per step spreads 32 lanes over 32 different bank pairs (with RS = 49 they all fell on two: 3,500 cycles per step).
+__host__ __device__ inline int ldlt_band_rs(int bw) { return (bw + 3) & ~1; }
+__host__ __device__ inline size_t ldlt_band_bytes(int n, int bw) { return sizeof(double) * ((size_t)(n + 1) * ldlt_band_rs(bw) + 3 * (size_t)(n + 2)); }
+__host__ __device__ inline bool ldlt_band_ok(int n, int bw) {
+    int chunks = 0;   // chunks of 8 columns per row of the update triangle: one per thread of four waves; the rhs: one lane per entry
+    for (int r = 0; r < bw; ++r) chunks += (r + 8) / 8;
+    return n > 0 && bw >= 2 && bw <= 64 && chunks <= 256 && ldlt_band_bytes(n, bw) <= LD_BAND_LDS;
+}
+
+__device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, double* sm, int* s_fail) {
+    const int n = W.nS, N = W.Npad, bw = W.band, RS = ldlt_band_rs(bw);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* Ab = sm;                         // (n + 1) x RS, the extra row is zero (pivot reads of an odd n)
+    double* y = Ab + (size_t)(n + 1) * RS;   // n + 2: right-hand side -> D^-1 L^-1 b -> x
+    double* invd = y + n + 2;                // n + 2: 1 / d_k
+    double* corr = invd + n + 2;             // n + 2: f of the odd column of each pair
+#ifdef BA_DIAG_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    if (tid == 0) { st->dbg[0] = tprev; st->dbg[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    const gdouble* S = (const gdouble*)W.S;
+    for (int i = tid; i < (n + 1) * RS; i += LD_THREADS) {
+        const int r = i / RS, j = i - r * RS, c = r - bw - 1 + j;
+        Ab[i] = (r < n && j >= 1 && j <= bw + 1 && c >= 0) ? S[(size_t)r * N + c] : 0.0;
+    }
+    for (int i = tid; i < n + 2; i += LD_THREADS) { y[i] = i < n ? W.rhs[i] : 0.0; invd[i] = 0.0; corr[i] = 0.0; }
+    // Division of labour (the step is bound by the instructions a wave issues -- fp64, one wave per SIMD at best -- so no wave
+    // does anything twice):
+    //   waves 0..3  the bw x bw triangle under the pivot pair (k, k + 1): a thread owns a chunk of EIGHT consecutive columns
+    //               dc0 .. dc0 + 7 of ONE row dr (r = k + 2 + dr, c = k + 2 + dc, dc <= dr); it reads 1 / d0, 1 / d1, f of the
+    //               pair from LDS and does no pivot arithmetic;
+    //   wave 4      the right-hand side ("row n", one entry per lane) and the PIVOT LOOK-AHEAD: the next pair's pivot block
+    //               from its values before this step (its rank-2 update is three more entries), its determinant and two
+    //               reciprocals (a Newton step each), published for the next step in a two-deep LDS slot.  The three entries
+    //               of that block are therefore never stored in their last step (rows dr = 0, 1 are not stored at all: the
+    //               look-ahead's reads would race with the store); their final values only live on as invd / corr, and
+    //               L(k + 1, k) = f;
+    //   waves 5..7  only meet the barriers.
+    // Offsets are doubles from `sm` at k = 0 and advance by a constant per step.  Every load of a step is unconditional (an
+    // address past the band reads zeros or another row's data -- inside the kernel's LDS or, beyond it, zeros -- and only
+    // the stores are predicated): no branch sits between a load and its use.
+    __shared__ double s_piv[2][4];   // [step parity][inv0, inv1, f, -]
+    auto pivots = [&](double d0, double l10, double d11, bool two, double* out, bool& bad) {
+        const bool bad0 = (d0 == 0.0 || !(fabs(d0) <= DBL_MAX));
+        const double det = d0 * d11 - l10 * l10;
+        const double i0 = bad0 ? 0.0 : fast_recip(d0);
+        const bool bad1 = two && (det == 0.0 || !(fabs(det) <= DBL_MAX));
+        out[0] = i0;
+        out[1] = (two && !bad1 && !bad0) ? d0 * fast_recip(det) : 0.0;
+        out[2] = l10 * i0;
+        bad = bad0 || bad1;
+    };
+#ifdef LD_BAND_DIAG_TIMES
+    unsigned long long dg_m[3] = {0, 0, 0}, dg_p[3] = {0, 0, 0};
+#endif
+    int dr = -1, dc0 = 0;
+    if (wv < 4) {
+        int q = tid, row = 0;
+        for (; row < bw; ++row) { const int nch = (row + 8) >> 3; if (q < nch) break; q -= nch; }
+        if (row < bw) { dr = row; dc0 = 8 * q; }
+    }
+    const int edr = max(dr, 0);
+    int o_r = (2 + edr) * RS + (bw - 1 - edr);            // A(r, k), A(r, k + 1)
+    int o_v = (2 + edr) * RS + (bw + 1 - edr + dc0);      // A(r, c0 .. c0 + 7)
+    int o_c = (2 + dc0) * RS + (bw - 1 - dc0);            // A(c0 + i, k), A(c0 + i, k + 1): + i (RS - 1)
+    const int klim_m = dr >= 2 ? n - 2 - dr : 0;          // row r = k + 2 + dr exists while k < klim_m
+    const int ncol = dr >= 0 ? min(8, dr + 1 - dc0) : 0;  // entries of the chunk inside the triangle
+    // wave 4: rhs entry c = k + 2 + lane
+    const int Y = (int)(y - sm);
+    int o_yc = (2 + lane) * RS + (bw - 1 - lane);
+    bool pbad = false;
+    if (tid == 0) { double pv3[3]; pivots(Ab[bw + 1], Ab[RS + bw], Ab[RS + bw + 1], n > 1, pv3, pbad); s_piv[0][0] = pv3[0]; s_piv[0][1] = pv3[1]; s_piv[0][2] = pv3[2]; if (pbad) *s_fail = 1; }
+    __syncthreads();
+#ifdef BA_DIAG_STAMPS
+    { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[0] += tn - tprev; tprev = tn; }
+#endif
+    for (int k = 0; k < n; k += 2) {
+        const int par = (k >> 1) & 1;
+#ifdef LD_BAND_DIAG_EMPTY
+        if (false) {
+#elif defined(LD_BAND_DIAG_NOMAT)
+        if (false) {
+#else
+        if (wv < 4) {
+#endif
+            const double inv0 = s_piv[par][0], inv1 = s_piv[par][1], f = s_piv[par][2];
+            const double ark = sm[o_r], ar1k = sm[o_r + 1];
+            double ack[8], ac1k[8], v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ack[i] = sm[o_c + i * (RS - 1)]; ac1k[i] = sm[o_c + i * (RS - 1) + 1]; v[i] = sm[o_v + i]; }
+#ifdef LD_BAND_DIAG_TIMES
+            const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
+            const double ar1 = ar1k - ark * f, s0 = ark * inv0, s1 = ar1 * inv1;
+            double nv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nv[i] = v[i] - (s0 * ack[i] + s1 * (ac1k[i] - ack[i] * f));
+            const bool live = k < klim_m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (live && i < ncol) sm[o_v + i] = nv[i];
+            o_r += 2 * RS; o_v += 2 * RS; o_c += 2 * RS;
+#ifdef LD_BAND_DIAG_TIMES
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+            if (tid == 0) { dg_m[0] += tm1 - tm0; dg_m[1] += tm2 - tm1; }
+#endif
+#ifdef LD_BAND_DIAG_EMPTY
+        } else if (false) {
+#else
+        } else if (wv == 4) {
+#endif
+            const bool two = k + 1 < n;
+            const double* Ak = Ab + (size_t)k * RS;
+            const double inv0 = s_piv[par][0], inv1 = s_piv[par][1], f = s_piv[par][2];
+            // rows p = k + 2, q = k + 3 of the next pivot block: their entries in columns k, k + 1 and the block itself
+            const double* Ap = Ak + 2 * RS;
+            const double ap0 = Ap[bw - 1], ap1k = Ap[bw], e00 = Ap[bw + 1];
+            const double aq0 = Ap[RS + bw - 2], aq1k = Ap[RS + bw - 1], e10 = Ap[RS + bw], e11 = Ap[RS + bw + 1];
+            // right-hand side: y[c] -= y[k] A(c, k) / d0 + y'[k + 1] A'(c, k + 1) / d1
+            const double yk = y[k], yk1 = y[k + 1];
+            const double ack = sm[o_yc], ac1k = sm[o_yc + 1], yc = y[k + 2 + lane];
+#ifdef LD_BAND_DIAG_TIMES
+            const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
+#endif
+            const double ap1 = ap1k - ap0 * f, aq1 = aq1k - aq0 * f;
+            const double t0 = ap0 * inv0, t1 = ap1 * inv1, u0 = aq0 * inv0, u1 = aq1 * inv1;
+            const double d0n = e00 - (t0 * ap0 + t1 * ap1), l10n = e10 - (t0 * aq0 + t1 * aq1), d11n = e11 - (u0 * aq0 + u1 * aq1);
+            double nxt[3];
+            bool nbad;
+            pivots(d0n, l10n, d11n, k + 3 < n, nxt, nbad);   // (past the end: rows of zeros or beyond the band -- never used)
+            const double y1 = yk1 - yk * f;
+            const double ny = yc - (yk * inv0 * ack + y1 * inv1 * (ac1k - ack * f));
+            if (lane < bw && k + 2 + lane < n) y[k + 2 + lane] = ny;
+            if (lane == 0) {
+                invd[k] = inv0;
+                if (two) { invd[k + 1] = inv1; corr[k + 1] = f; }
+                s_piv[par ^ 1][0] = nxt[0]; s_piv[par ^ 1][1] = nxt[1]; s_piv[par ^ 1][2] = nxt[2];
+                if (nbad && k + 2 < n) *s_fail = 1;
+            }
+            o_yc += 2 * RS;
+#ifdef LD_BAND_DIAG_TIMES
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
+            if (lane == 0) { dg_p[0] += tp1 - tp0; dg_p[1] += tp2 - tp1; }
+#endif
+        }
+#ifdef LD_BAND_DIAG_TIMES
+        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (tid == 0) dg_m[2] += __builtin_amdgcn_s_memtime() - tb0;
+        if (tid == 256) dg_p[2] += __builtin_amdgcn_s_memtime() - tb0;
+#else
+        __syncthreads();
+#endif
+    }
+#ifdef LD_BAND_DIAG_TIMES
+    if (tid == 256) { s_piv[0][3] = (double)dg_p[0]; s_piv[1][3] = (double)dg_p[1]; corr[n + 1] = (double)dg_p[2]; }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long steps = (unsigned long long)((n + 1) / 2);
+        auto clip = [](unsigned long long x) { return x > 1023ull ? 1023ull : x; };
+        st->dbg[7] = (clip(dg_m[0] / steps) << 50) | (clip(dg_m[1] / steps) << 40) | (clip(dg_m[2] / steps) << 30) |
+                     (clip((unsigned long long)s_piv[0][3] / steps) << 20) | (clip((unsigned long long)s_piv[1][3] / steps) << 10) | clip((unsigned long long)corr[n + 1] / steps);
+    }
+#endif
+#ifdef BA_DIAG_STAMPS
+    { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[1] += tn - tprev; tprev = tn; }
+#endif
+    if (*s_fail) { if (tid == 0) st->ok2 = 0; return; }
+    // unit-L form of the band (column pairs: L(r, k) = A(r, k) / d_k, L(r, k + 1) = (A(r, k + 1) - A(r, k) f) / d_{k+1}) and
+    // z = D^-1 L^-1 b in y
+    for (int i = tid; i < n * ((bw + 3) / 2); i += LD_THREADS) {
+        const int r = i / ((bw + 3) / 2), jp = i - r * ((bw + 3) / 2);
+        const int c0 = ((r - bw - 1) & ~1) + 2 * jp;    // even column of the pair (may start one left of the band: slot < 0 skipped)
+        if (c0 > r) continue;
+        const int j0 = c0 - r + bw + 1;
+        double* row = Ab + (size_t)r * RS;
+        const double a0 = (j0 >= 0 && c0 >= 0) ? row[j0] : 0.0;
+        if (j0 >= 0 && c0 >= 0 && c0 < r) row[j0] = (r == c0 + 1) ? corr[r] : a0 * invd[c0];   // (the pair's own off-diagonal entry was never stored)
+        if (c0 + 1 < r && c0 + 1 >= 0) row[j0 + 1] = (row[j0 + 1] - a0 * corr[c0 + 1]) * invd[c0 + 1];
+    }
+    __syncthreads();
+    for (int k = 2 * tid; k < n; k += 2 * LD_THREADS) {
+        const double y0 = y[k], y1 = y[k + 1];
+        y[k] = y0 * invd[k];
+        if (k + 1 < n) y[k + 1] = (y1 - y0 * corr[k + 1]) * invd[k + 1];
+    }
+    __syncthreads();
+#ifdef BA_DIAG_STAMPS
+    { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[2] += tn - tprev; tprev = tn; }
+#endif
+    // backward substitution x = L^-T z over 32-row blocks from the bottom: wavefront 0 solves the block (lane k owns x_k,
+    // its column of the block's L in registers, v_readlane broadcasts), then the <= bw unknowns above take the block's part
+    const int jb_last = ((n - 1) / LD_NB) * LD_NB;
+    for (int jb = jb_last; jb >= 0; jb -= LD_NB) {
+        const int nb = min(LD_NB, n - jb);
+        if (wv == 0) {
+            const int k = lane & 31;
+            double col[LD_NB];
+#pragma unroll
+            for (int m = 0; m < LD_NB; ++m) {   // L(jb + m, jb + k); loaded unconditionally (rows past n: zeros or beyond the LDS), selected after
+                const double l = Ab[(size_t)(jb + m) * RS + bw + 1 - (m - k)];
+                col[m] = (lane < nb && m < nb && m > k && m - k <= bw) ? l : 0.0;
+            }
+            double v = (lane < nb) ? y[jb + k] : 0.0;
+#pragma unroll
+            for (int m = LD_NB - 1; m >= 0; --m) {
+                const double xm = readlane_d(v, m);
+                v -= col[m] * xm;   // col[m] = 0 where the term does not exist
+            }
+            if (lane < nb) y[jb + k] = v;
+        }
+        __syncthreads();
+        if (tid < min(bw, jb)) {
+            const int i = jb - 1 - tid;
+            // L(jb + m, i) sits at slot bw + 1 - (jb + m - i) = bw - tid - m of row jb + m: all 32 loads first, then the sum
+            double l[LD_NB], x[LD_NB];
+#pragma unroll
+            for (int m = 0; m < LD_NB; ++m) { l[m] = Ab[(size_t)(jb + m) * RS + (bw - tid - m)]; x[m] = y[jb + m]; }
+            double acc = y[i];
+#pragma unroll
+            for (int m = 0; m < LD_NB; ++m) acc -= (m < nb && tid + m + 1 <= bw) ? l[m] * x[m] : 0.0;
+            y[i] = acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += LD_THREADS) W.rhs[i] = y[i];
+#ifdef BA_DIAG_STAMPS
+    { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[5] += tn - tprev; tprev = tn; }
+    if (tid == 0) { st->dbg[2] = __builtin_amdgcn_s_memtime(); st->dbg[3] = __builtin_amdgcn_s_memrealtime();
+                    st->dbg[4] = (ph[0] << 32) | ph[1]; st->dbg[5] = (ph[2] << 32) | ph[3]; st->dbg[6] = (ph[4] << 32) | ph[5]; }
+#endif
+    if (tid == 0) st->ok2 = 1;
+}
+
 __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
     BaState* st = W.st;
@@ -537,6 +797,13 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     __shared__ double s_invd[LD_NB], s_corr[LD_NB], s_dval[LD_NB];
     if (tid == 0) s_fail = 0;
     if (n == 0) { if (tid == 0) st->ok2 = 1; return; }
+#ifndef LD_NO_BAND
+    if (ldlt_band_ok(n, W.band)) {   // wave-uniform: the window's structure (host, ba_api.hip)
+        __syncthreads();
+        ldlt_band_solve(W, st, sm, &s_fail);
+        return;
+    }
+#endif
 #ifdef BA_DIAG_STAMPS
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define STAMP(i) do { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[i] += tn - tprev; tprev = tn; } while (0)
@@ -985,7 +1252,9 @@ __global__ __launch_bounds__(256) void k_import(BaWin* wins, const BaIo* io) {
 }
 
 // ---- launch wrappers -----------------------------------------------------------------------------------------
-size_t bak_ldlt_smem(int Npad) { return sizeof(double) * ((size_t)LD_NB * LD_P + ((size_t)Npad + 16) * LD_P); }
+size_t bak_ldlt_smem(int Npad) {   // the blocked path's need, raised to the banded path's budget (one 512-thread workgroup per CU either way)
+    return std::max(sizeof(double) * ((size_t)LD_NB * LD_P + ((size_t)Npad + 16) * LD_P), (size_t)LD_BAND_LDS);
+}
 
 hipError_t bak_prepare(int Npad) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_solve), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -61,6 +61,7 @@ struct BaWin {
     int32_t tile_blo[BA_MAX_TILES], tile_bhi[BA_MAX_TILES];   // ... of GB's (the tile that holds row nS = bl spans every point)
     int16_t panel_hi[BA_MAX_PANELS];   // last matrix row with an entry in the 32 columns of LDLt panel i (>= the panel's last row)
     int16_t back_lo[BA_MAX_PANELS];    // first column any row of panel i's 32 rows reaches (back-substitution)
+    int32_t band;      // half bandwidth of the reduced system's row envelope: max over rows r of r - first column of r (nS - 1: full)
     // vertices
     BA_G double* pose;      // n_kf x 7: q(x,y,z,w), t
     BA_G double* pose_bak;
