@@ -385,10 +385,6 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             fprintf(stderr, "[ba diag] ldlt shader cycles %llu, realtime ticks (100 MHz) %llu -> %.0f MHz, %.1f us\n",
                     S0.dbg[2] - S0.dbg[0], S0.dbg[3] - S0.dbg[1],
                     100.0 * (double)(S0.dbg[2] - S0.dbg[0]) / (double)(S0.dbg[3] - S0.dbg[1] + 1), (double)(S0.dbg[3] - S0.dbg[1]) / 100.0);
-            fprintf(stderr, "[ba diag] dbg7 raw %llx\n", S0.dbg[7]);
-            if (S0.dbg[7])
-                fprintf(stderr, "[ba diag] band step, cycles (1023 = clipped): matrix wave wait %llu compute+store %llu barrier %llu | pivot wave wait %llu compute+store %llu barrier %llu\n",
-                        (S0.dbg[7] >> 50) & 1023, (S0.dbg[7] >> 40) & 1023, (S0.dbg[7] >> 30) & 1023, (S0.dbg[7] >> 20) & 1023, (S0.dbg[7] >> 10) & 1023, S0.dbg[7] & 1023);
             fprintf(stderr, "[ba diag] ldlt phase cycles: load %llu factor %llu rows %llu writeback %llu trailing %llu backsub %llu\n",
                     S0.dbg[4] >> 32, S0.dbg[4] & 0xffffffffull, S0.dbg[5] >> 32, S0.dbg[5] & 0xffffffffull, S0.dbg[6] >> 32, S0.dbg[6] & 0xffffffffull);
         }

@@ -565,9 +565,15 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     if (tid == 0) { st->dbg[0] = tprev; st->dbg[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     const gdouble* S = (const gdouble*)W.S;
-    for (int i = tid; i < (n + 1) * RS; i += LD_THREADS) {
-        const int r = i / RS, j = i - r * RS, c = r - bw - 1 + j;
-        Ab[i] = (r < n && j >= 1 && j <= bw + 1 && c >= 0) ? S[(size_t)r * N + c] : 0.0;
+    for (int i0 = tid; i0 < (n + 1) * RS; i0 += 8 * LD_THREADS) {   // eight loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * LD_THREADS, r = i / RS, j = i - r * RS, c = r - bw - 1 + j;
+            v[u] = (i < (n + 1) * RS && r < n && j >= 1 && j <= bw + 1 && c >= 0) ? S[(size_t)r * N + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * LD_THREADS; if (i < (n + 1) * RS) Ab[i] = v[u]; }
     }
     for (int i = tid; i < n + 2; i += LD_THREADS) { y[i] = i < n ? W.rhs[i] : 0.0; invd[i] = 0.0; corr[i] = 0.0; }
     // Division of labour (the step is bound by the instructions a wave issues -- fp64, one wave per SIMD at best -- so no wave
@@ -596,9 +602,6 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
         out[2] = l10 * i0;
         bad = bad0 || bad1;
     };
-#ifdef LD_BAND_DIAG_TIMES
-    unsigned long long dg_m[3] = {0, 0, 0}, dg_p[3] = {0, 0, 0};
-#endif
     int dr = -1, dc0 = 0;
     if (wv < 4) {
         int q = tid, row = 0;
@@ -612,7 +615,6 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     const int klim_m = dr >= 2 ? n - 2 - dr : 0;          // row r = k + 2 + dr exists while k < klim_m
     const int ncol = dr >= 0 ? min(8, dr + 1 - dc0) : 0;  // entries of the chunk inside the triangle
     // wave 4: rhs entry c = k + 2 + lane
-    const int Y = (int)(y - sm);
     int o_yc = (2 + lane) * RS + (bw - 1 - lane);
     bool pbad = false;
     if (tid == 0) { double pv3[3]; pivots(Ab[bw + 1], Ab[RS + bw], Ab[RS + bw + 1], n > 1, pv3, pbad); s_piv[0][0] = pv3[0]; s_piv[0][1] = pv3[1]; s_piv[0][2] = pv3[2]; if (pbad) *s_fail = 1; }
@@ -622,23 +624,12 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
 #endif
     for (int k = 0; k < n; k += 2) {
         const int par = (k >> 1) & 1;
-#ifdef LD_BAND_DIAG_EMPTY
-        if (false) {
-#elif defined(LD_BAND_DIAG_NOMAT)
-        if (false) {
-#else
         if (wv < 4) {
-#endif
             const double inv0 = s_piv[par][0], inv1 = s_piv[par][1], f = s_piv[par][2];
             const double ark = sm[o_r], ar1k = sm[o_r + 1];
             double ack[8], ac1k[8], v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { ack[i] = sm[o_c + i * (RS - 1)]; ac1k[i] = sm[o_c + i * (RS - 1) + 1]; v[i] = sm[o_v + i]; }
-#ifdef LD_BAND_DIAG_TIMES
-            const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
-#endif
             const double ar1 = ar1k - ark * f, s0 = ark * inv0, s1 = ar1 * inv1;
             double nv[8];
 #pragma unroll
@@ -648,16 +639,7 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
             for (int i = 0; i < 8; ++i)
                 if (live && i < ncol) sm[o_v + i] = nv[i];
             o_r += 2 * RS; o_v += 2 * RS; o_c += 2 * RS;
-#ifdef LD_BAND_DIAG_TIMES
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
-            if (tid == 0) { dg_m[0] += tm1 - tm0; dg_m[1] += tm2 - tm1; }
-#endif
-#ifdef LD_BAND_DIAG_EMPTY
-        } else if (false) {
-#else
         } else if (wv == 4) {
-#endif
             const bool two = k + 1 < n;
             const double* Ak = Ab + (size_t)k * RS;
             const double inv0 = s_piv[par][0], inv1 = s_piv[par][1], f = s_piv[par][2];
@@ -668,11 +650,6 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
             // right-hand side: y[c] -= y[k] A(c, k) / d0 + y'[k + 1] A'(c, k + 1) / d1
             const double yk = y[k], yk1 = y[k + 1];
             const double ack = sm[o_yc], ac1k = sm[o_yc + 1], yc = y[k + 2 + lane];
-#ifdef LD_BAND_DIAG_TIMES
-            const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
-#endif
             const double ap1 = ap1k - ap0 * f, aq1 = aq1k - aq0 * f;
             const double t0 = ap0 * inv0, t1 = ap1 * inv1, u0 = aq0 * inv0, u1 = aq1 * inv1;
             const double d0n = e00 - (t0 * ap0 + t1 * ap1), l10n = e10 - (t0 * aq0 + t1 * aq1), d11n = e11 - (u0 * aq0 + u1 * aq1);
@@ -689,31 +666,9 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
                 if (nbad && k + 2 < n) *s_fail = 1;
             }
             o_yc += 2 * RS;
-#ifdef LD_BAND_DIAG_TIMES
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
-            if (lane == 0) { dg_p[0] += tp1 - tp0; dg_p[1] += tp2 - tp1; }
-#endif
         }
-#ifdef LD_BAND_DIAG_TIMES
-        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
         __syncthreads();
-        if (tid == 0) dg_m[2] += __builtin_amdgcn_s_memtime() - tb0;
-        if (tid == 256) dg_p[2] += __builtin_amdgcn_s_memtime() - tb0;
-#else
-        __syncthreads();
-#endif
     }
-#ifdef LD_BAND_DIAG_TIMES
-    if (tid == 256) { s_piv[0][3] = (double)dg_p[0]; s_piv[1][3] = (double)dg_p[1]; corr[n + 1] = (double)dg_p[2]; }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long steps = (unsigned long long)((n + 1) / 2);
-        auto clip = [](unsigned long long x) { return x > 1023ull ? 1023ull : x; };
-        st->dbg[7] = (clip(dg_m[0] / steps) << 50) | (clip(dg_m[1] / steps) << 40) | (clip(dg_m[2] / steps) << 30) |
-                     (clip((unsigned long long)s_piv[0][3] / steps) << 20) | (clip((unsigned long long)s_piv[1][3] / steps) << 10) | clip((unsigned long long)corr[n + 1] / steps);
-    }
-#endif
 #ifdef BA_DIAG_STAMPS
     { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[1] += tn - tprev; tprev = tn; }
 #endif
@@ -768,10 +723,13 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
             double l[LD_NB], x[LD_NB];
 #pragma unroll
             for (int m = 0; m < LD_NB; ++m) { l[m] = Ab[(size_t)(jb + m) * RS + (bw - tid - m)]; x[m] = y[jb + m]; }
-            double acc = y[i];
+            double acc0 = y[i], acc1 = 0.0;
 #pragma unroll
-            for (int m = 0; m < LD_NB; ++m) acc -= (m < nb && tid + m + 1 <= bw) ? l[m] * x[m] : 0.0;
-            y[i] = acc;
+            for (int m = 0; m < LD_NB; m += 2) {
+                acc0 -= (m < nb && tid + m + 1 <= bw) ? l[m] * x[m] : 0.0;
+                acc1 -= (m + 1 < nb && tid + m + 2 <= bw) ? l[m + 1] * x[m + 1] : 0.0;
+            }
+            y[i] = acc0 + acc1;
         }
         __syncthreads();
     }
