@@ -64,6 +64,35 @@ def test_vs_oracle_fresh(opt, k, p, o, seed, nfix):
     _close(opt.LocalBundleAdjustment(prob), ob.ba_solve(prob), "fresh%d" % seed)
 
 
+@pytest.mark.parametrize("k,p,o,seed,nfix", [(50, 2000, 8, 12345, 2), (50, 1200, 3, 41, 1), (50, 1500, 10, 42, 3), (12, 300, 4, 43, 1),
+                                             (9, 200, 8, 44, 2), (41, 900, 5, 45, 1)])
+def test_banded_windows_in_lds_and_through_the_blocked_path(opt, k, p, o, seed, nfix):
+    """Windows with a narrow row envelope are factored inside LDS (csrc/ba_kernels.hip: ldlt_band_solve); the same windows
+    through the blocked dense path (SLAMIT_BA_NO_BAND=1 in a child process: the switch is read once) and the CPU oracle give
+    the same poses, points, flags and iteration counts.  Half bandwidths from 6 * 3 - 1 = 17 to the whole system."""
+    import json, subprocess, sys, tempfile
+    prob = synth.synth_ba(k, p, o, seed=seed, n_fixed=nfix)
+    res = opt.LocalBundleAdjustment(prob)
+    _close(res, ob.ba_solve(prob), "band%d" % seed)
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "from weiner_slamit_v2_amd import api, synth\n"
+            "prob = synth.synth_ba(%d, %d, %r, seed=%d, n_fixed=%d)\n"
+            "o = api.Optimizer(max_kf=64, max_pt=2048, max_edge=110000, max_batch=1)\n"
+            "r = o.LocalBundleAdjustment(prob)\n"
+            "np.savez(sys.argv[1], kf_pose=r['kf_pose'], pt_xyz=r['pt_xyz'], edge_outlier=r['edge_outlier'], n_its=np.array(r['stats']['n_its']))\n"
+            % (ROOT, k, p, o, seed, nfix))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "r.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, SLAMIT_BA_NO_BAND="1"), cwd=ROOT, timeout=300)
+        d = np.load(out)
+    scale = max(np.abs(d["kf_pose"]).max(), 1.0)
+    # two elimination orders of the same system: a window where every point is seen by only three keyframes is poorly conditioned
+    # and the roundings differ by up to 6e-9 relative; the tolerance asked of either path is 1e-5
+    assert np.abs(res["kf_pose"] - d["kf_pose"]).max() / scale <= 1e-7
+    assert np.abs(res["pt_xyz"] - d["pt_xyz"]).max() / max(np.abs(d["pt_xyz"]).max(), 1.0) <= 1e-7
+    assert (res["edge_outlier"] == d["edge_outlier"]).all() and list(d["n_its"]) == list(res["stats"]["n_its"])
+
+
 def test_config4_dense_50kf_2000pt(opt):
     """BASELINE config 4, dense visibility: 50 KF x 2000 points, 100,000 edges."""
     prob = synth.synth_ba(50, 2000, None, seed=12345)

@@ -285,7 +285,8 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             }
             int band = 0;   // a window whose keyframes only share points with their neighbours has a narrow band: LDLt inside LDS
             for (int c = 0; c < nfree; ++c) band = std::max(band, 6 * c + 5 - 6 * fcol[c]);
-            w.band = std::min(band, std::max(n - 1, 0));
+            static const bool no_band = getenv("SLAMIT_BA_NO_BAND") != nullptr;   // A/B and parity runs: every window through the blocked path
+            w.band = no_band ? std::max(n - 1, 0) : std::min(band, std::max(n - 1, 0));
         }
         // ---- inputs, straight into the pinned block: CSR by point / by keyframe (counting sort, caller order kept
         // inside each list), points in device order ----
