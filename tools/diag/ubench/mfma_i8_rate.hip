@@ -73,6 +73,46 @@ void runmix(const char* name, int blocks) {
     hipFree(out); hipFree(cyc); hipFree(src);
 }
 
+// the matcher's epilogue alone: 4 x 16 keys folded into (best, second) with v_min_i32 + v_med3_i32 (asm) or min / max / min
+__device__ __forceinline__ int med3_asm(int a, int b, int c, int after) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c), "v"(after)); return r; }
+template <int MODE>
+__global__ __launch_bounds__(256) void kepi(int iters, int* out, unsigned long long* cyc, const int* src) {
+    int c[4][16];
+    for (int u = 0; u < 4; ++u) for (int r = 0; r < 16; ++r) c[u][r] = src[(threadIdx.x + 17 * u + 3 * r) & 255];
+    int kb[4] = {1 << 30, 1 << 30, 1 << 30, 1 << 30}, ks[4] = {1 << 30, 1 << 30, 1 << 30, 1 << 30};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = c[u][r] + i;
+                const int n = min(kb[u], k);
+                if (MODE == 0) ks[u] = med3_asm(kb[u], ks[u], k, n);
+                else ks[u] = max(kb[u], min(ks[u], k));
+                kb[u] = n;
+            }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = kb[0] + kb[1] + kb[2] + kb[3] + ks[0] + ks[1] + ks[2] + ks[3];
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int MODE>
+void runepi(const char* name, int blocks) {
+    int* out; unsigned long long* cyc; int* src;
+    hipMalloc(&out, sizeof(int) * blocks * 256); hipMalloc(&cyc, 8); hipMalloc(&src, 1024); hipMemset(src, 0x11, 1024);
+    const int iters = 1000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kepi<MODE><<<blocks, 256>>>(10, out, cyc, src);
+    hipEventRecord(e0);
+    kepi<MODE><<<blocks, 256>>>(iters, out, cyc, src);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long hc; hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
+    printf("%-44s blocks %4d: %.1f ns per 64-key epilogue per SIMD, %.0f ticks per epilogue of one wave\n", name, blocks, ms * 1e6 / (iters * (blocks / 256.0)), (double)hc / iters);
+    hipFree(out); hipFree(cyc); hipFree(src);
+}
+
 template <int KIND, int CHAINS>
 void run(const char* name, int blocks) {
     int* out; unsigned long long* cyc;
@@ -99,6 +139,10 @@ int main() {
     run<1, 4>("16x16x64 i8, 4 chains", 256);
     run<1, 4>("16x16x64 i8, 4 chains", 512);
     run<1, 1>("16x16x64 i8, 1 chain", 256);
+    runepi<0>("epilogue, add + min + med3(asm) per key", 256);
+    runepi<0>("epilogue, add + min + med3(asm) per key", 512);
+    runepi<1>("epilogue, add + min + max + min per key", 256);
+    runepi<1>("epilogue, add + min + max + min per key", 512);
     runmix<0>("loop of 8 steps x 4 MFMA, A from registers", 256);
     runmix<0>("loop of 8 steps x 4 MFMA, A from registers", 512);
     runmix<1>("... A unpacked by VALU per step (invariant w)", 256);

@@ -161,18 +161,13 @@ __device__ __forceinline__ int imed3_after(int a, int b, int c, int after) {
 // shared by all the query tiles of the wave) at ~4 cycles each.  A wave therefore carries FOUR query tiles (128
 // queries, 128 VGPRs of unpacked queries + 64 of accumulators -> 2 waves per SIMD): 30 + 64 instructions per 16 MFMAs.
 // Workgroup = 4 wavefronts = 4 train slices (a slice takes every 4th train tile) of the same 128 queries, one wave per
-// SIMD; they merge through LDS at the end.
+// SIMD; they merge through LDS at the end.  Measured (tools/diag/ubench/mfma_i8_rate.hip): a wave's
+// MFMAs (16 ns each per SIMD) and its ~190 vector instructions per tile (~2 ns each) ADD UP -- 0.51 + 0.38 us per tile of 128
+// queries x 32 train rows, the two waves of a SIMD running in step; starting one of them half a period late (s_sleep) or
+// interleaving the epilogue of one half of the query tiles with the MFMAs of the other inside the wave (which doubles the
+// unpacking) both left the time unchanged, so neither is kept.
 #define HMM_WAVES 4                   // train slices = wavefronts per workgroup
 #define HMM_NT 4                      // query tiles (32 queries each) per wavefront
-#ifndef HMM_DIAG_EPI
-#define HMM_DIAG_EPI 16
-#endif
-#ifndef HMM_DIAG_STEPS
-#define HMM_DIAG_STEPS 8
-#endif
-#ifndef HMM_STAGGER
-#define HMM_STAGGER 14                // x 64 cycles
-#endif
 
 __device__ __forceinline__ void hm_merge2(int& kb, int& ks, int ob, int os) {   // two smallest of the union of two (best, second) pairs
     ks = min(min(ks, os), max(kb, ob));
@@ -214,18 +209,10 @@ __global__ __launch_bounds__(64 * HMM_WAVES) __attribute__((amdgpu_waves_per_eu(
     const int ntiles = (nt + 31) >> 5;
     uint4 wt = make_uint4(0u, 0u, 0u, 0u);
     if (wv < ntiles) wt = T[2 * (size_t)min(wv * 32 + col, nt - 1) + h];
-    // The two waves of a SIMD start together and would stay in step -- both in the MFMA phase (sharing the matrix pipe),
-    // then both in the min / median phase (sharing vector issue), neither phase overlapping the other.  The wave in the
-    // odd slot starts half a period late, so one wave's epilogue runs under the other's MFMAs.
-    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u) __builtin_amdgcn_s_sleep(HMM_STAGGER);
     int tile = wv;
     for (; tile < ntiles; tile += HMM_WAVES) {
         const uint4 w = wt;
-#ifndef HMM_DIAG_NOLOAD
         if (tile + HMM_WAVES < ntiles) wt = T[2 * (size_t)min((tile + HMM_WAVES) * 32 + col, nt - 1) + h];   // travels during this tile
-#else
-        wt.x += 0x01020304u * tile;
-#endif
         hm_v16i c[HMM_NT];
         {
             const hm_v4i a = hm_unpack_t(w, 0);
@@ -238,7 +225,7 @@ __global__ __launch_bounds__(64 * HMM_WAVES) __attribute__((amdgpu_waves_per_eu(
             for (int u = 0; u < HMM_NT; ++u) c[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][0], cm, 0, 0, 0);
         }
 #pragma unroll
-        for (int s = 1; s < HMM_DIAG_STEPS; ++s) {
+        for (int s = 1; s < 8; ++s) {
             const hm_v4i a = hm_unpack_t(w, s);
 #pragma unroll
             for (int u = 0; u < HMM_NT; ++u) c[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[u][s], c[u], 0, 0, 0);
@@ -250,13 +237,9 @@ __global__ __launch_bounds__(64 * HMM_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int u = 0; u < HMM_NT; ++u) {
 #pragma unroll
-            for (int r = 0; r < HMM_DIAG_EPI; ++r) {
+            for (int r = 0; r < 16; ++r) {
                 const int n = min(kb[u], c[u][r]);
-#ifndef HMM_DIAG_NOASM
                 ks[u] = imed3_after(kb[u], ks[u], c[u][r], n);   // kb <= ks: the median of the three is the new second smallest
-#else
-                ks[u] = max(kb[u], min(ks[u], c[u][r]));
-#endif
                 kb[u] = n;
             }
         }
