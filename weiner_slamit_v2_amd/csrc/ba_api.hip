@@ -330,10 +330,13 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
     bak_import(st, h->d_wins, h->d_io, mk, mp, me, Npad, nwin);   // also zeroes the Schur operands' ranges and the LM states
 
     // ---- two-stage schedule (Optimizer.cc:659-707) ----
-    // LM trial slots are enqueued two at a time; the windows' states come back through the pinned block one chunk LATE
-    // (the next chunk is already queued when the host looks at the previous one: no bubble between chunks), and *stop is
-    // polled before every chunk like SparseOptimizer::terminate() (sparse_optimizer.cpp:376) is before every iteration.
-    // Slots of a finished stage return at once, so a chunk queued in vain costs a few launches.
+    // LM trial slots are enqueued in chunks; the windows' states come back through the pinned block one chunk LATE (the
+    // next chunk is already queued when the host looks at the previous one: no bubble between chunks), and *stop is polled
+    // before every chunk like SparseOptimizer::terminate() (sparse_optimizer.cpp:376) is before every iteration.  Slots of
+    // a finished stage return at once, but a slot queued in vain still costs its eleven launches (~30 us): the first chunk
+    // of a stage is the number of trials the stage cannot do without (one per iteration in the robust stage; three in the
+    // final one, whose "no progress three times" rule can end it that early), the chunks after it are single slots.
+    // (Chunks of two throughout queued 20 slots for the 14 trials of a window-8 solve.)
     BaState* hs[2] = {reinterpret_cast<BaState*>(h->h_pin + st_off), reinterpret_cast<BaState*>(h->h_pin + st_off) + nwin};
     bool stopped = opts->stop && *opts->stop;  // :655-657
     for (int stage = 0; stage < 2 && !stopped; ++stage) {
@@ -341,11 +344,14 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
         bak_stage_begin(st, h->d_wins, nwin, me, stage, its, stage == 0 ? 1 : 0, stage == 1);
         int budget = its * 10 + 1;  // at most 10 LM trials per iteration
         int cur = 0, pending = -1;
-        bool all_done = false;
+        bool all_done = false, first = true;
+        static const int chunk_env = getenv("SLAMIT_BA_CHUNK") ? atoi(getenv("SLAMIT_BA_CHUNK")) : 0;   // > 0: fixed chunk size (A/B runs)
         while (!all_done) {
             if (opts->stop && *opts->stop) { stopped = true; break; }
             if (budget > 0) {
-                const int nslots = std::min(2, budget);
+                const int want = chunk_env > 0 ? chunk_env : first ? std::max(1, std::min(stage == 0 ? its : 3, std::min(its, 4))) : 1;
+                const int nslots = std::min(want, budget);
+                first = false;
                 for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad);
                 budget -= nslots;
                 HIP_TRY(hipMemcpyAsync(hs[cur], h->d_states, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));
