@@ -551,7 +551,9 @@ __device__ __forceinline__ void fast_cell_wave(
                 const bool pass = ((pb >> (8 * j)) & 0xFFu) != 0u;   // byte select: one v_cmp_ne_u32_sdwa
                 const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
                 const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                if (pass) (s_listB + nB)[pos] = (unsigned short)(e0 + j);
+                // no exec-mask region around the store: lanes that did not pass write the stack's spare last slot (a stack never holds
+                // more than 63 + 256 entries); a select costs one vector instruction, the masked region five scalar ones and a branch
+                s_listB[pass ? (unsigned)nB + pos : (unsigned)(FAST_LIST_CAP / 2 - 1)] = (unsigned short)(e0 + j);
                 nB += __popcll(mk);
             }
 #pragma unroll
@@ -559,7 +561,7 @@ __device__ __forceinline__ void fast_cell_wave(
                 const bool pass = ((pd >> (8 * j)) & 0xFFu) != 0u;
                 const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
                 const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                if (pass) (s_listD + nD)[pos] = (unsigned short)(e0 + j);
+                s_listD[pass ? (unsigned)nD + pos : (unsigned)(FAST_LIST_CAP / 2 - 1)] = (unsigned short)(e0 + j);
                 nD += __popcll(mk);
             }
             // scoring: 64 + 64 candidates per pass off the tops of the stacks, whenever one of them holds 64 (after the
