@@ -1413,16 +1413,29 @@ __global__ __launch_bounds__(256) void describe_kernel(
             if (lrow[it] < DESC_ROWS) *reinterpret_cast<uint32_t*>(&s_patch[wv][k][__mul24(lrow[it], DESC_PITCH) + 4 * lcol[it]]) = ld[k][it];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // The rotated tap (row, col) = (cvRound(x b + y a), cvRound(x a - y b)) of a pattern point (ORBextractor.cc:121-123) on packed
+    // f32 lanes: x * (b, a) + y * (a, -b) is two v_pk_mul_f32 and one v_pk_add_f32 with the same four products and two sums
+    // (x a - y b == x a + (-(y b)) bit for bit, no contraction); adding 1.5 * 2^23 rounds both halves to the nearest integer,
+    // ties to even like cvRound, and leaves it in the low mantissa bits (|value| <= 18.4 << 2^22), so the LDS address
+    // row * PITCH + col is one 24-bit multiply-add of the two bit patterns plus a per-keypoint base that carries the
+    // constant -- 6 vector instructions per tap instead of 13 (4 multiplies, 2 adds, 2 x (v_rndne + v_cvt), address).
+    typedef float desc_f2 __attribute__((ext_vector_type(2)));
+    const desc_f2 magic = {12582912.0f, 12582912.0f};
+    // low 24 bits of (0x4B400000 + r) = 0x400000 + r, so umul24(bits_r, PITCH) + bits_c = r PITCH + c + DESC_BIAS
+    const unsigned DESC_BIAS = 0x400000u * (unsigned)DESC_PITCH + 0x4B400000u;
     int tv0[DESC_KP_PER_WAVE][4], tv1[DESC_KP_PER_WAVE][4];
 #pragma unroll
     for (int k = 0; k < DESC_KP_PER_WAVE; ++k) {
         const float a = kp[k].cs, b = kp[k].sn;  // a = cos, b = sin   (ORBextractor.cc:117-118; computed by ic_angle_kernel)
+        const desc_f2 ba = {b, a}, anb = {a, -b};
         const uint8_t* center = &s_patch[wv][k][DESC_R * DESC_PITCH + DESC_R + ((kp[k].x - DESC_R) & 3)];
+        const uint8_t* biased = center - DESC_BIAS;   // (an LDS address: 32-bit wrap-around arithmetic)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            int r0 = slamit_round_f(px0[t] * b + py0[t] * a), c0 = slamit_round_f(px0[t] * a - py0[t] * b);
-            int r1 = slamit_round_f(px1[t] * b + py1[t] * a), c1 = slamit_round_f(px1[t] * a - py1[t] * b);
-            tv0[k][t] = center[__mul24(r0, DESC_PITCH) + c0]; tv1[k][t] = center[__mul24(r1, DESC_PITCH) + c1];
+            const desc_f2 p0 = {px0[t], px0[t]}, q0 = {py0[t], py0[t]}, p1 = {px1[t], px1[t]}, q1 = {py1[t], py1[t]};
+            const desc_f2 m0 = (p0 * ba + q0 * anb) + magic, m1 = (p1 * ba + q1 * anb) + magic;
+            tv0[k][t] = biased[__umul24(__float_as_uint(m0.x), (unsigned)DESC_PITCH) + __float_as_uint(m0.y)];
+            tv1[k][t] = biased[__umul24(__float_as_uint(m1.x), (unsigned)DESC_PITCH) + __float_as_uint(m1.y)];
         }
     }
 #pragma unroll
