@@ -23,7 +23,7 @@ void orbk_resize(hipStream_t st, const uint8_t* src, int sw, int sh, size_t sstr
                  const short* ialpha, const int* yofs, const short* ibeta, int nframes);
 bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const short* ialpha, const int* yofs,
                         const short* ibeta, std::vector<uint32_t>& col, std::vector<uint32_t>& row);
-void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, uint8_t* dst, int dw, int dh,
+void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, int sh, uint8_t* dst, int dw, int dh,
                        size_t dstride, size_t dframe, const uint32_t* d_col, const uint32_t* d_row, int nframes);
 hipError_t orbk_pyramid_prepare(int smem_bytes);
 void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const PyrBox* boxes, const PyrTabs* tabs,
@@ -528,7 +528,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
             const OrbLevel& S = h->levels[l - 1];
             const OrbLevel& D = h->levels[l];
             const uint8_t* src = l == 1 ? d_gray : h->d_pyr + S.plane_off;
-            orbk_resize_rows4(st, src, l == 1 ? stride : (size_t)S.stride, l == 1 ? frame_stride : h->pyr_frame_total,
+            orbk_resize_rows4(st, src, l == 1 ? stride : (size_t)S.stride, l == 1 ? frame_stride : h->pyr_frame_total, S.h,
                               h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride, h->pyr_frame_total, h->d_rs_col[l], h->d_rs_row[l], nframes);
             if (early_blur && l == h->blur_split) {
                 // the blur of the big levels 0 .. l (most of its bytes) runs on the side stream beside the rest of the chain:

@@ -76,12 +76,13 @@ __global__ __launch_bounds__(256) void resize_level_kernel(
 // of one dst pixel is ONE dot product); no LDS, no halo, no barrier.
 // --------------------------------------------------------------------------------------------
 typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
+typedef unsigned rs_u3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ uint32_t rs_dot2(uint32_t taps, uint32_t alpha) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(rs_us2, taps), __builtin_bit_cast(rs_us2, alpha), 0u, false);
 }
 
 template <int RP>   // RP row pairs (2 * RP dst rows) per lane; S / D: the frame's source and destination planes
-__device__ __forceinline__ void rs_item(const int item, const uint8_t* S, const unsigned ss, uint8_t* D, const unsigned dstride,
+__device__ __forceinline__ void rs_item(const int item, const uint8_t* S, const unsigned ss, const unsigned sbytes, uint8_t* D, const unsigned dstride,
                                         const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, const int ngroups,
                                         const unsigned inv_groups, const int dh) {
     const int yq = (int)__umulhi((unsigned)item, inv_groups);
@@ -102,13 +103,17 @@ __device__ __forceinline__ void rs_item(const int item, const uint8_t* S, const 
     const unsigned b = c0.x & 0xFFFFu, sh = (c0.x >> 16) & 3u, off1 = (c0.x >> 20) & 15u, off2 = (c0.x >> 24) & 15u;
     const uint32_t sel[4] = {c0.y, c0.z, c0.w, c1.x}, al[4] = {c1.y, c1.z, c1.w, c2x};
     uint32_t w[4 * RP][3];   // the 12-byte windows of the source rows (two per dst row)
+    // ONE 12-byte buffer load per window instead of three dword loads (the kernel waits on vector-memory ISSUE: 72 % of its
+    // wave cycles): the buffer resource bounds the plane, so the window of a row's last group may run past the row end
+    // (into the next row, or past the plane's last byte, where the hardware returns 0) -- bytes no selector ever picks.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(S), 0, sbytes, 0x00020000);
+    (void)off1; (void)off2;
 #pragma unroll
     for (int r = 0; r < 4 * RP; ++r) {
         const unsigned srow = (r & 1) ? (rt[r >> 1].x >> 16) : (rt[r >> 1].x & 0xFFFFu);
         const unsigned ro = __umul24(srow, ss) + b;   // rows < 2^16, pitch < 2^24
-        w[r][0] = *reinterpret_cast<const uint32_t*>(S + ro);
-        w[r][1] = *reinterpret_cast<const uint32_t*>(S + (ro + off1));
-        w[r][2] = *reinterpret_cast<const uint32_t*>(S + (ro + off2));
+        const rs_u3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)ro, 0, 0);
+        w[r][0] = v.x; w[r][1] = v.y; w[r][2] = v.z;
     }
 #pragma unroll
     for (int k = 0; k < 2 * RP; ++k) {
@@ -134,10 +139,10 @@ template <int RP>
 __global__ __launch_bounds__(256) void resize_rows4_kernel(
     const uint8_t* __restrict__ src, size_t sstride, size_t sframe,
     uint8_t* __restrict__ dst, size_t dstride, size_t dframe,
-    const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, int ngroups, unsigned inv_groups, int nitems, int dh) {
+    const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, int ngroups, unsigned inv_groups, int nitems, int dh, unsigned sbytes) {
     const int item = blockIdx.x * 256 + threadIdx.x;
     if (item >= nitems) return;
-    rs_item<RP>(item, src + (size_t)blockIdx.y * sframe, (unsigned)sstride, dst + (size_t)blockIdx.y * dframe, (unsigned)dstride, coltab, rowtab,
+    rs_item<RP>(item, src + (size_t)blockIdx.y * sframe, (unsigned)sstride, sbytes, dst + (size_t)blockIdx.y * dframe, (unsigned)dstride, coltab, rowtab,
                 ngroups, inv_groups, dh);
 }
 
@@ -181,7 +186,7 @@ bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const s
     return true;
 }
 
-void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, uint8_t* dst, int dw, int dh,
+void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, int sh, uint8_t* dst, int dw, int dh,
                        size_t dstride, size_t dframe, const uint32_t* d_col, const uint32_t* d_row, int nframes) {
     static const int rp_env = getenv("SLAMIT_RESIZE_RP") ? atoi(getenv("SLAMIT_RESIZE_RP")) : 0;
     const int rp = rp_env == 1 || rp_env == 2 || rp_env == 4 ? rp_env : 2;
@@ -189,7 +194,7 @@ void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_
     const unsigned inv = (unsigned)((0x100000000ull + (unsigned)ng - 1) / (unsigned)ng);
     const dim3 grid((nitems + 255) / 256, nframes);
 #define RS_LAUNCH(RP) hipLaunchKernelGGL(resize_rows4_kernel<RP>, grid, dim3(256), 0, st, src, sstride, sframe, dst, dstride, dframe, \
-                                          reinterpret_cast<const uint4*>(d_col), reinterpret_cast<const uint2*>(d_row), ng, inv, nitems, dh)
+                                          reinterpret_cast<const uint4*>(d_col), reinterpret_cast<const uint2*>(d_row), ng, inv, nitems, dh, (unsigned)(sstride * (size_t)sh))
     if (rp == 1) RS_LAUNCH(1); else if (rp == 2) RS_LAUNCH(2); else RS_LAUNCH(4);
 #undef RS_LAUNCH
 }
