@@ -1344,8 +1344,8 @@ __constant__ __attribute__((aligned(16))) signed char c_pattern[SLAMIT_ORB_PATTE
 #define DESC_KP_PER_WAVE 4
 #define DESC_R 18                 // reach of the rotated pattern
 #define DESC_ROWS (2 * DESC_R + 1)
-#define DESC_PITCH 44             // 37 columns + up to 3 of alignment, in whole dwords
-#define DESC_LOADS 7              // ceil(37 * 11 / 64) dwords per lane and keypoint
+#define DESC_PITCH 48             // 37 columns + up to 3 of alignment, in 16-byte chunks
+#define DESC_LOADS 2              // ceil(37 * 3 / 64) 16-byte chunks per lane and keypoint
 
 __global__ __launch_bounds__(256) void describe_kernel(
     const OrbLevel* __restrict__ levels, int nlevels,
@@ -1388,34 +1388,32 @@ __global__ __launch_bounds__(256) void describe_kernel(
     // line per row and is bound by the L1 tag rate), then the 8 taps per lane are LDS byte reads.
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][DESC_KP_PER_WAVE][DESC_ROWS * DESC_PITCH];
     const int wv = threadIdx.x >> 6;
+    // a lane stages chunk (row, c) = (idx / 3, idx % 3) of a patch for idx = lane and lane + 64: ONE 16-byte buffer load each (2 per
+    // keypoint instead of 7 dword loads: the pass waits on vector-memory issue like the pyramid did), bounded by the plane's
+    // buffer resource (a chunk may run up to 10 bytes past a row end: the next row, or zeros past the plane)
     int lrow[DESC_LOADS], lcol[DESC_LOADS];
-#pragma unroll
-    for (int it = 0; it < DESC_LOADS; ++it) {
-        const int idx = lane + 64 * it;
-        lrow[it] = (int)(((unsigned)idx * 5958u) >> 16);   // idx / 11 for idx < 448
-        lcol[it] = idx - __mul24(lrow[it], DESC_PITCH / 4);
-    }
-    // byte offset of each staged dword inside a patch: the same for every keypoint, so it is computed once (24-bit
-    // multiplies are full rate; the v_mul_lo_u32 the compiler would otherwise issue per keypoint and dword is quarter
-    // rate -- the empty asm keeps it from folding these offsets back into (row + y) * pitch)
     unsigned poff[DESC_LOADS];
 #pragma unroll
     for (int it = 0; it < DESC_LOADS; ++it) {
-        poff[it] = __umul24((unsigned)min(lrow[it], DESC_ROWS - 1), step) + 4u * (unsigned)lcol[it];
-        asm volatile("" : "+v"(poff[it]));
+        const int idx = lane + 64 * it;
+        lrow[it] = (int)(((unsigned)idx * 21846u) >> 16);   // idx / 3 for idx < 128
+        lcol[it] = idx - 3 * lrow[it];
+        poff[it] = __umul24((unsigned)min(lrow[it], DESC_ROWS - 1), step) + 16u * (unsigned)lcol[it];
     }
-    uint32_t ld[DESC_KP_PER_WAVE][DESC_LOADS];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, (unsigned)L.stride * (unsigned)L.h, 0x00020000);
+    typedef unsigned desc_u4 __attribute__((ext_vector_type(4)));
+    desc_u4 ld[DESC_KP_PER_WAVE][DESC_LOADS];
 #pragma unroll
     for (int k = 0; k < DESC_KP_PER_WAVE; ++k) {
         const unsigned base = __umul24((unsigned)(kp[k].y - DESC_R), step) + (unsigned)((kp[k].x - DESC_R) & ~3);
 #pragma unroll
-        for (int it = 0; it < DESC_LOADS; ++it) ld[k][it] = *reinterpret_cast<const uint32_t*>(img + (base + poff[it]));
+        for (int it = 0; it < DESC_LOADS; ++it) ld[k][it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + poff[it]), 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < DESC_KP_PER_WAVE; ++k)
 #pragma unroll
         for (int it = 0; it < DESC_LOADS; ++it)
-            if (lrow[it] < DESC_ROWS) *reinterpret_cast<uint32_t*>(&s_patch[wv][k][__mul24(lrow[it], DESC_PITCH) + 4 * lcol[it]]) = ld[k][it];
+            if (lrow[it] < DESC_ROWS) *reinterpret_cast<desc_u4*>(&s_patch[wv][k][__mul24(lrow[it], DESC_PITCH) + 16 * lcol[it]]) = ld[k][it];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // The rotated tap (row, col) = (cvRound(x b + y a), cvRound(x a - y b)) of a pattern point (ORBextractor.cc:121-123) on packed
