@@ -95,10 +95,15 @@ __device__ __forceinline__ void rs_item(const int item, const uint8_t* S, const 
     // whole lane is straight-line code with every load issued before the first use
     int yrow[2 * RP];
     uint2 rt[2 * RP];
+    {   // the table carries copies of its last row behind it: the lane's rows are one run of 16-byte pairs (RP loads, not 2 RP)
+        const uint4* rp4 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(rowtab) + 16u * (unsigned)(RP * yq));
 #pragma unroll
-    for (int r = 0; r < 2 * RP; ++r) {
-        yrow[r] = min(2 * RP * yq + r, dh - 1);
-        rt[r] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(rowtab) + 8u * (unsigned)yrow[r]);
+        for (int r = 0; r < RP; ++r) {
+            const uint4 v = rp4[r];
+            rt[2 * r] = make_uint2(v.x, v.y); rt[2 * r + 1] = make_uint2(v.z, v.w);
+        }
+#pragma unroll
+        for (int r = 0; r < 2 * RP; ++r) yrow[r] = min(2 * RP * yq + r, dh - 1);
     }
     const unsigned b = c0.x & 0xFFFFu, sh = (c0.x >> 16) & 3u, off1 = (c0.x >> 20) & 15u, off2 = (c0.x >> 24) & 15u;
     const uint32_t sel[4] = {c0.y, c0.z, c0.w, c1.x}, al[4] = {c1.y, c1.z, c1.w, c2x};
@@ -175,13 +180,14 @@ bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const s
             c[5 + j] = a[j];
         }
     }
-    row.assign((size_t)dh * 2, 0u);
+    row.assign((size_t)(dh + 7) * 2, 0u);   // + 7 copies of the last row: a lane loads its (up to 8) rows as whole 16-byte pairs
     for (int y = 0; y < dh; ++y) {
         const int sy0 = std::min(std::max(yofs[y], 0), sh - 1), sy1 = std::min(std::max(yofs[y] + 1, 0), sh - 1);
         row[2 * (size_t)y] = (uint32_t)sy0 | ((uint32_t)sy1 << 16);
         row[2 * (size_t)y + 1] = (uint32_t)(unsigned short)ibeta[2 * y] | ((uint32_t)(unsigned short)ibeta[2 * y + 1] << 16);
         if (ibeta[2 * y] < 0 || ibeta[2 * y + 1] < 0) return false;
     }
+    for (int y = dh; y < dh + 7; ++y) { row[2 * (size_t)y] = row[2 * (size_t)(dh - 1)]; row[2 * (size_t)y + 1] = row[2 * (size_t)(dh - 1) + 1]; }
     for (int x = 0; x < dw; ++x) if (ialpha[2 * x] < 0 || ialpha[2 * x + 1] < 0) return false;
     return true;
 }
