@@ -1131,16 +1131,22 @@ __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
 // One wavefront per keypoint; integer moments reduced with cross-lane shuffles.
 // --------------------------------------------------------------------------------------------
 // offsets (u, v) of the 749 pixels of the radius-15 disc, rows v = -15..15, |u| <= umax[|v|]
-struct DiscTable { signed char u[768], v[768]; int n; };
+// per LANE: its 12 disc pixels (index lane + 64 j) as (u, v) byte pairs, 24 bytes in a row: a lane fetches them with two loads
+// (dwordx4 + dwordx2) instead of 24 byte loads -- a wave of this kernel only handles four keypoints, so its table loads are a
+// third of its vector-memory instructions
+struct DiscTable { signed char uv[64][32]; int n; };   // [lane][2 j], [lane][2 j + 1] = u, v; 8 bytes of padding per lane
 __constant__ DiscTable c_disc;
 
 static DiscTable make_disc() {
     static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     DiscTable t;
+    for (int l = 0; l < 64; ++l) for (int k = 0; k < 32; ++k) t.uv[l][k] = 0;   // padding entries are (0, 0): weight zero
     t.n = 0;
     for (int v = -15; v <= 15; ++v)
-        for (int u = -umax[v < 0 ? -v : v]; u <= umax[v < 0 ? -v : v]; ++u) { t.u[t.n] = (signed char)u; t.v[t.n] = (signed char)v; ++t.n; }
-    for (int i = t.n; i < 768; ++i) { t.u[i] = 0; t.v[i] = 0; }
+        for (int u = -umax[v < 0 ? -v : v]; u <= umax[v < 0 ? -v : v]; ++u) {
+            t.uv[t.n & 63][2 * (t.n >> 6)] = (signed char)u; t.uv[t.n & 63][2 * (t.n >> 6) + 1] = (signed char)v;
+            ++t.n;
+        }
     return t;
 }
 
@@ -1173,11 +1179,16 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
     else { src = pyr + L.plane_off + (size_t)frame * L.plane_bytes; stride = L.stride; }
     // this lane's 12 disc pixels (749 = 11 * 64 + 45): offsets and weights live in registers
     int off[12], wu[12], wv[12];
+    {
+        const uint4 t0 = *reinterpret_cast<const uint4*>(&c_disc.uv[lane][0]);
+        const uint2 t1 = *reinterpret_cast<const uint2*>(&c_disc.uv[lane][16]);
+        const uint32_t tw[6] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y};
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        const int idx = lane + 64 * j;
-        const int u = c_disc.u[idx], v = c_disc.v[idx];   // padding entries are (0,0): weight zero
-        off[j] = __mul24(v, stride) + u; wu[j] = u; wv[j] = v;   // |v| <= 15, pitch < 2^23: full-rate 24-bit multiply
+        for (int j = 0; j < 12; ++j) {
+            const uint32_t pr = tw[j >> 1] >> (16 * (j & 1));
+            const int u = (int)(signed char)(pr & 0xFFu), v = (int)(signed char)((pr >> 8) & 0xFFu);
+            off[j] = __mul24(v, stride) + u; wu[j] = u; wv[j] = v;   // |v| <= 15, pitch < 2^23: full-rate 24-bit multiply
+        }
     }
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     // all the wave's keypoints at once: their 12 x IC_KP_PER_WAVE byte loads are in flight together, and the
