@@ -1085,7 +1085,8 @@ __device__ __forceinline__ void octree_body(
 #endif
 }
 
-__global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
+template <int OCT_NT>
+__global__ __launch_bounds__(OCT_NT) void octree_kernel(
     const OrbLevel* __restrict__ levels, int nlevels,
     const unsigned long long* __restrict__ cand, size_t cand_frame_stride,
     int* __restrict__ cand_count,
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
     OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, int* __restrict__ kp_count,
     int node_cap, int key_cap, int level_override /* -1: blockIdx.x */, int* __restrict__ fb_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // node arrays | k_xy[key_cap] | k_nd[key_cap]
-    __shared__ int wave_tmp[OCT_THREADS / 64];
+    __shared__ int wave_tmp[OCT_NT / 64];
     __shared__ int s_vars[4];
     uint32_t* k_xy = reinterpret_cast<uint32_t*>(smem + orbk_octree_node_bytes(node_cap));
     uint16_t* k_nd = reinterpret_cast<uint16_t*>(k_xy + key_cap);
@@ -1119,9 +1120,9 @@ __global__ __launch_bounds__(OCT_THREADS) void octree_kernel(
         return;
     }
     if (n_keys <= key_cap)
-        octree_body<OCT_THREADS, true>(L, K, n_keys, k_xy, k_nd, OUT, &kp_count[kidx], smem, node_cap, wave_tmp, s_vars);
+        octree_body<OCT_NT, true>(L, K, n_keys, k_xy, k_nd, OUT, &kp_count[kidx], smem, node_cap, wave_tmp, s_vars);
     else
-        octree_body<OCT_THREADS, false>(L, K, n_keys, ws_xy + L.cand_off + (size_t)frame * cand_frame_stride,
+        octree_body<OCT_NT, false>(L, K, n_keys, ws_xy + L.cand_off + (size_t)frame * cand_frame_stride,
                                         ws_node + L.cand_off + (size_t)frame * cand_frame_stride, OUT, &kp_count[kidx], smem,
                                         node_cap, wave_tmp, s_vars);
 }
@@ -1662,7 +1663,9 @@ hipError_t orbk_octree_prepare(int node_cap, int key_cap) {
     const int want = (int)orbk_octree_smem(node_cap, key_cap);
     if (want <= prepared) return hipSuccess;
     prepared = want;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
 }
 
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
@@ -1670,9 +1673,19 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
                  OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int key_cap, int nframes,
                  int level_override, int* fb_count) {
     dim3 grid(nframes, level_override >= 0 ? 1 : nlevels);
-    hipLaunchKernelGGL(octree_kernel, grid, dim3(OCT_THREADS), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
-                       cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
-                       key_cap, level_override, fb_count);
+    // Workgroups of 512 threads finish a (frame, level) soonest; with a hundred frames or more per call 256-thread workgroups take 10 %
+    // longer alone (74 vs 67 us at 128 frames) but leave the side stream's blur more of the chip, and the STEP is 2 % shorter
+    // (0.551 vs 0.562 ms); at 64 frames they cost 5 %.
+    static const int nt_env = getenv("SLAMIT_OCT_THREADS") ? atoi(getenv("SLAMIT_OCT_THREADS")) : 0;
+    const int nt = nt_env == 256 || nt_env == 512 ? nt_env : (nframes >= 96 ? 256 : OCT_THREADS);
+    if (nt == 256)
+        hipLaunchKernelGGL(octree_kernel<256>, grid, dim3(256), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
+                           cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
+                           key_cap, level_override, fb_count);
+    else
+        hipLaunchKernelGGL(octree_kernel<OCT_THREADS>, grid, dim3(OCT_THREADS), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
+                           cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
+                           key_cap, level_override, fb_count);
 }
 
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0,
