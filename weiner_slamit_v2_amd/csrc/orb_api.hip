@@ -430,7 +430,7 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
             first = last;
         }
         h->pyr_mode = (getenv("SLAMIT_PYR_FUSED") || !rows4_ok) ? 1 : 0;
-        h->blur_split = getenv("SLAMIT_BLUR_SPLIT") ? atoi(getenv("SLAMIT_BLUR_SPLIT")) : 2;
+        h->blur_split = getenv("SLAMIT_BLUR_SPLIT") ? atoi(getenv("SLAMIT_BLUR_SPLIT")) : 1;   // (2 until the pyramid chain got its wide loads: its tail is shorter now)
         if (getenv("SLAMIT_PYR_PER_LEVEL")) { okb = false; h->pyr_mode = 1; }   // diagnostic: force the old per-level kernel
         if (!okb) h->pyr_segs.clear();                      // fall back to the per-level kernel
         if (!h->pyr_segs.empty()) {
