@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     # 128 streams per step: per-frame cost keeps falling up to about there (launch floor, ramp and tail of ~13 launches per
-    # step, and the octree's one long workgroup per frame, are paid once per step): 64 -> 207k frames/s, 128 -> 225k on one
+    # step, and the octree's one long workgroup per frame, are paid once per step): 64 -> 208k frames/s, 128 -> 236k on one
     # MI355X
     ap.add_argument("--batch", type=int, default=None, help="independent camera streams per GPU and step (default: 128 at VGA, 64 at 720p "
                     "as BASELINE configs[2] words it)")
