@@ -242,10 +242,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    # 128 streams per step: per-frame cost keeps falling up to about there (launch floor, ramp and tail of ~13 launches per
-    # step, and the octree's one long workgroup per frame, are paid once per step): 64 -> 208k frames/s, 128 -> 236k on one
-    # MI355X
-    ap.add_argument("--batch", type=int, default=None, help="independent camera streams per GPU and step (default: 128 at VGA, 64 at 720p "
+    # 256 streams per step: per-frame cost keeps falling with the batch (launch floor, ramp and tail of ~14 launches per step, the
+    # octree's one long workgroup per frame, and the side stream's overlap all improve): 64 -> 208k frames/s, 128 -> 236k,
+    # 256 -> 248k, 512 -> 259k on one MI355X; 256 keeps a step at one millisecond
+    ap.add_argument("--batch", type=int, default=None, help="independent camera streams per GPU and step (default: 256 at VGA, 64 at 720p "
                     "as BASELINE configs[2] words it)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ba", action="store_true")
@@ -293,7 +293,7 @@ def main():
         fa = [synth.synth_frame(W, H, 5000 + sid) for sid in mine]
         fb = [synth.warp_frame(fa[i], 5000 + sid) for i, sid in enumerate(mine)]
     else:
-        B = args.batch if args.batch else (128 if args.config == "vga" else 64)
+        B = args.batch if args.batch else (256 if args.config == "vga" else 64)
         # each rank owns its own B streams (different seeds per rank); two consecutive frames per stream; 16 distinct
         # frame pairs per rank, each used by B / 16 streams (the kernels are issue bound: content repeats do not help them)
         uniq = min(B, 16)

@@ -31,7 +31,7 @@ def test_bench_line_schema_single_gpu():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["launches"] >= 1
     frames = d["config"]["frames_per_step_per_gpu"]
-    assert frames == 128 and abs(d["value"] - frames * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 0.01
+    assert frames == 256 and abs(d["value"] - frames * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 0.01
 
 
 def test_bench_two_rank_rehearsal():
