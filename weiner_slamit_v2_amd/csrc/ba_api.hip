@@ -23,7 +23,7 @@ size_t bak_ldlt_smem(int Npad);
 hipError_t bak_prepare(int Npad);
 void bak_import(hipStream_t st, BaWin* wins, const BaIo* io, int max_kf, int max_pt, int max_edge, int Npad, int nwin);
 void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int stage, int max_it, int robust, bool gate);
-void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad);
+void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first);
 void bak_final(hipStream_t st, BaWin* wins, const BaIo* io, int nwin, int max_kf, int max_pt, int max_edge);
 
 static_assert(BA_MAX_ITS == SLAMIT_BA_MAX_ITS, "stats capacity");
@@ -351,8 +351,10 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             if (budget > 0) {
                 const int want = chunk_env > 0 ? chunk_env : first ? std::max(1, std::min(stage == 0 ? its : 3, std::min(its, 4))) : 1;
                 const int nslots = std::min(want, budget);
+                const bool was_first = first;
                 first = false;
-                for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad);
+                static const bool no_fuse = getenv("SLAMIT_BA_NO_FUSE") && atoi(getenv("SLAMIT_BA_NO_FUSE"));   // A/B runs: every slot as the first
+                for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad, (was_first && sl == 0) || no_fuse);
                 budget -= nslots;
                 HIP_TRY(hipMemcpyAsync(hs[cur], h->d_states, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipEventRecord(h->ev[cur], st));

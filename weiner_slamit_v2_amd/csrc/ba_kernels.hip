@@ -66,13 +66,7 @@ __device__ __forceinline__ EdgeGeom edge_eval(const BaWin& W, int e) {
 }
 
 // ---- S1: Jacobians + weights of every active edge --------------------------------------------
-__global__ __launch_bounds__(256) void k_linearize(BaWin* wins) {
-    const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
-    if (st->done || !st->need_linearize) return;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e == 0 && st->it == 0) st->maxdiag_bits = 0ull;
-    if (e >= W.n_edge || !W.e_active[e]) return;
+__device__ __forceinline__ void edge_jacobian(const BaWin& W, bool robust, int e, double* J /*[21]*/) {
     const EdgeGeom g = edge_eval(W, e);
     const int kf = W.e_kf[e];
     const double* in = W.intr + 4 * kf;
@@ -81,7 +75,6 @@ __global__ __launch_bounds__(256) void k_linearize(BaWin* wins) {
     quat_to_R(W.pose + 7 * kf, R);
     const double x = g.x, y = g.y, z = g.z, z_2 = z * z;
     const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
-    double* J = W.e_jac + 21 * (size_t)e;
     for (int r = 0; r < 2; ++r)
         for (int c = 0; c < 3; ++c)
             J[3 * r + c] = -1. / z * (tmp[3 * r] * R[c] + tmp[3 * r + 1] * R[3 + c] + tmp[3 * r + 2] * R[6 + c]);
@@ -91,11 +84,25 @@ __global__ __launch_bounds__(256) void k_linearize(BaWin* wins) {
     J[15] = 0; J[16] = -1. / z * fy; J[17] = y / z_2 * fy;
     const double dsqr = W.huber_delta * W.huber_delta;
     double rho1 = 1.0;
-    if (st->robust && g.chi2 > dsqr) rho1 = W.huber_delta / sqrt(g.chi2);
+    if (robust && g.chi2 > dsqr) rho1 = W.huber_delta / sqrt(g.chi2);
     const double w = W.e_w[e];
     J[18] = rho1 * w;                 // weightedOmega
     J[19] = -w * g.err0 * rho1;       // omega_r
     J[20] = -w * g.err1 * rho1;
+}
+
+__global__ __launch_bounds__(256) void k_linearize(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done || !st->need_linearize) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e == 0 && st->it == 0) st->maxdiag_bits = 0ull;
+    if (e >= W.n_edge || !W.e_active[e]) return;
+    double Jr[21];
+    edge_jacobian(W, st->robust != 0, e, Jr);
+    double* J = W.e_jac + 21 * (size_t)e;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) J[i] = Jr[i];
 }
 
 __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v) {
@@ -263,6 +270,80 @@ __global__ __launch_bounds__(256) void k_prepare(BaWin* wins) {   // BA_PG lanes
         if (col < 0) continue;
         double H[18];
         hpl_of(W.e_jac + 21 * (size_t)e, H);
+        for (int r = 0; r < 6; ++r) {
+            const double h0 = H[3 * r], h1 = H[3 * r + 1], h2 = H[3 * r + 2];
+            const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)p;
+            W.GB[o] = h0; W.GB[o + 1] = h1; W.GB[o + 2] = h2;
+            W.GA[o] = h0 * Di[0] + h1 * Di[1] + h2 * Di[2];
+            W.GA[o + 1] = h0 * Di[1] + h1 * Di[3] + h2 * Di[4];
+            W.GA[o + 2] = h0 * Di[2] + h1 * Di[4] + h2 * Di[5];
+        }
+    }
+}
+
+// ---- S1 + S2 + S5 in one launch for every slot after a stage's first: only the first trial of a stage takes its lambda
+// from the maximum over ALL diagonal blocks (computeLambdaInit) and therefore needs a kernel boundary between the
+// reductions and the damping; from then on lambda is in the state when the slot starts.  The lane that k_point_reduce
+// and k_prepare give an edge to computes that edge's Jacobian itself (and stores it for k_pose_reduce and
+// k_backsub_update); after a rejected trial only the damping part runs.  Same expressions, same summation order.
+__global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (st->done) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int p = t / BA_PG, g = t % BA_PG;
+    const bool live = p < W.n_pt;
+    const bool lin = st->need_linearize != 0;
+    double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    if (lin) {
+        const bool robust = st->robust != 0;
+        if (live)
+            for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
+                const int e = W.pt_edges[i];
+                if (!W.e_active[e]) continue;
+                double J[21];
+                edge_jacobian(W, robust, e, J);
+                double* Jm = W.e_jac + 21 * (size_t)e;
+#pragma unroll
+                for (int k = 0; k < 21; ++k) Jm[k] = J[k];
+                const double wO = J[18], r0 = J[19], r1 = J[20];
+                b[0] += J[0] * r0 + J[3] * r1; b[1] += J[1] * r0 + J[4] * r1; b[2] += J[2] * r0 + J[5] * r1;
+                h[0] += (J[0] * J[0] + J[3] * J[3]) * wO; h[1] += (J[0] * J[1] + J[3] * J[4]) * wO; h[2] += (J[0] * J[2] + J[3] * J[5]) * wO;
+                h[3] += (J[1] * J[1] + J[4] * J[4]) * wO; h[4] += (J[1] * J[2] + J[4] * J[5]) * wO; h[5] += (J[2] * J[2] + J[5] * J[5]) * wO;
+            }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) h[i] = group_sum(h[i]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i] = group_sum(b[i]);
+        if (live && g == 0) {
+            for (int i = 0; i < 6; ++i) W.Hll[6 * (size_t)p + i] = h[i];
+            for (int i = 0; i < 3; ++i) W.bl[3 * (size_t)p + i] = b[i];
+        }
+    } else if (live) {
+        for (int i = 0; i < 6; ++i) h[i] = W.Hll[6 * (size_t)p + i];
+        for (int i = 0; i < 3; ++i) b[i] = W.bl[3 * (size_t)p + i];
+    }
+    if (!live) return;
+    const double lambda = st->lambda;
+    const double a = h[0] + lambda, bq = h[1], c = h[2], d = h[3] + lambda, e_ = h[4], f = h[5] + lambda;
+    const double c0 = d * f - e_ * e_, c1 = e_ * c - bq * f, c2 = bq * e_ - d * c;
+    const double det = a * c0 + bq * c1 + c * c2;
+    const double id = 1.0 / det;
+    double Di[6];
+    Di[0] = c0 * id; Di[1] = c1 * id; Di[2] = c2 * id;
+    Di[3] = (a * f - c * c) * id; Di[4] = (bq * c - a * e_) * id; Di[5] = (a * d - bq * bq) * id;
+    const size_t K = (size_t)W.Kpad;
+    if (g == 0) {
+        for (int i = 0; i < 6; ++i) W.Dinv[6 * (size_t)p + i] = Di[i];
+        for (int j = 0; j < 3; ++j) W.GB[(size_t)W.nS * K + 3 * (size_t)p + j] = b[j];
+    }
+    for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
+        const int e = W.pt_edges[i];
+        if (!W.e_active[e]) continue;
+        const int col = W.pose_col[W.e_kf[e]];
+        if (col < 0) continue;
+        double H[18];
+        hpl_of(W.e_jac + 21 * (size_t)e, H);   // this lane's own store when lin (same address, same thread)
         for (int r = 0; r < 6; ++r) {
             const double h0 = H[3 * r], h1 = H[3 * r + 1], h2 = H[3 * r + 2];
             const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)p;
@@ -748,6 +829,9 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     if (st->done) return;
     const int n = W.nS, N = W.Npad;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // k_iter_begin's bookkeeping for the slots without that launch (bak_slot, first == false): this is the first
+    // single-workgroup kernel behind the last reader of need_linearize (k_pose_reduce)
+    if (tid == 0 && st->need_linearize) { st->iniChi = st->currentChi; st->qmax = 0; st->need_linearize = 0; }
     extern __shared__ double sm[];
     double* Dg = sm;                      // LD_NB x LD_P: diagonal block (unit L below, D on the diagonal)
     double* Wd = Dg + LD_NB * LD_P;       // (rows below + rhs row, padded to 16) x LD_P: L21 * D
@@ -1145,8 +1229,14 @@ __global__ __launch_bounds__(256) void k_stage_begin(BaWin* wins, int stage, int
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    int c = 0;
-    for (int e = threadIdx.x; e < W.n_edge; e += 256) c += W.e_active[e] != 0;
+    int c = 0;   // flags are 0 / 1 and the array starts on a 256-byte boundary (carve_work): 16 per load
+    const uint4* a16 = reinterpret_cast<const uint4*>(W.e_active);
+    const int full = W.n_edge >> 4;
+    for (int i = threadIdx.x; i < full; i += 256) {
+        const uint4 v = a16[i];
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    for (int e = 16 * full + threadIdx.x; e < W.n_edge; e += 256) c += W.e_active[e] != 0;
     if (c) atomicAdd(&cnt, c);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1234,13 +1324,20 @@ void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int st
 }
 
 // one LM trial slot for every window of the batch
-void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad) {
+// (`first`: the first slot of a stage, whose lambda comes out of the reductions; every later slot runs them and the
+// damping in one launch and leaves the iteration bookkeeping to k_ldlt_solve: 8 launches instead of 11)
+void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first) {
     const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt * BA_PG + 255) / 256, nwin);
-    hipLaunchKernelGGL(k_linearize, ge, dim3(256), 0, st, wins);
-    hipLaunchKernelGGL(k_point_reduce, gp, dim3(256), 0, st, wins);
-    hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(256), 0, st, wins);
-    hipLaunchKernelGGL(k_iter_begin, dim3(1, nwin), dim3(64), 0, st, wins);
-    hipLaunchKernelGGL(k_prepare, gp, dim3(256), 0, st, wins);
+    if (first) {
+        hipLaunchKernelGGL(k_linearize, ge, dim3(256), 0, st, wins);
+        hipLaunchKernelGGL(k_point_reduce, gp, dim3(256), 0, st, wins);
+        hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(256), 0, st, wins);
+        hipLaunchKernelGGL(k_iter_begin, dim3(1, nwin), dim3(64), 0, st, wins);
+        hipLaunchKernelGGL(k_prepare, gp, dim3(256), 0, st, wins);
+    } else {
+        hipLaunchKernelGGL(k_point_pass, gp, dim3(256), 0, st, wins);
+        hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(256), 0, st, wins);
+    }
     const int T = Npad / BA_TILE;
     hipLaunchKernelGGL(k_schur, dim3(T * (T + 1) / 2, BA_SPLITS, nwin), dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins);
