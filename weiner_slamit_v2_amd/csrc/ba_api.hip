@@ -394,8 +394,8 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             fprintf(stderr, "[ba diag] ldlt shader cycles %llu, realtime ticks (100 MHz) %llu -> %.0f MHz, %.1f us\n",
                     S0.dbg[2] - S0.dbg[0], S0.dbg[3] - S0.dbg[1],
                     100.0 * (double)(S0.dbg[2] - S0.dbg[0]) / (double)(S0.dbg[3] - S0.dbg[1] + 1), (double)(S0.dbg[3] - S0.dbg[1]) / 100.0);
-            fprintf(stderr, "[ba diag] ldlt phase cycles: load %llu factor %llu rows %llu writeback %llu trailing %llu backsub %llu\n",
-                    S0.dbg[4] >> 32, S0.dbg[4] & 0xffffffffull, S0.dbg[5] >> 32, S0.dbg[5] & 0xffffffffull, S0.dbg[6] >> 32, S0.dbg[6] & 0xffffffffull);
+            fprintf(stderr, "[ba diag] ldlt phase cycles: load %llu factor %llu rows %llu writeback / wave-0 busy %llu trailing / rhs-wave busy %llu backsub %llu, pivot-wave busy %llu\n",
+                    S0.dbg[4] >> 32, S0.dbg[4] & 0xffffffffull, S0.dbg[5] >> 32, S0.dbg[5] & 0xffffffffull, S0.dbg[6] >> 32, S0.dbg[6] & 0xffffffffull, S0.dbg[7]);
         }
         slamit_ba_stats* S = R.stats;
         if (!S) continue;

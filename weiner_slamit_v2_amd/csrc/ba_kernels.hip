@@ -617,30 +617,97 @@ __device__ __forceinline__ void ldlt_back_block(const gdouble* S, int N, double*
 // ---- banded path ---------------------------------------------------------------------------------------------
 // A local window whose keyframes share points only with their neighbours (ORB-SLAM's local BA: co-visibility falls off
 // with the distance along the trajectory) gives a reduced system with a narrow row envelope, and LDLt without pivoting
-// never fills outside it.  With half bandwidth bw the lower band (n rows of bw + 2 doubles: column r - bw - 1, always
-// zero, .. column r) fits the CU's LDS for n = 300, bw <= 60, and the whole solve runs there: no panel staging from L2,
-// no write-back, no trailing update through L2 -- just n / 2 right-looking steps of TWO columns each (the rank-2 update
-// of ldlt_factor_diag, applied to the bw x bw triangle under the pivots and to the right-hand side, which rides along
-// as "row n"), one barrier per step, then the unit-L form and a blocked backward substitution, all out of LDS.
-// Entry (r, c) of the band lives at Ab[r * RS + c - r + bw + 1].
+// never fills outside it.  With half bandwidth bw the lower band (n rows of bw + 4 doubles: columns r - bw - 3 ..
+// r - bw - 1, always zero -- a four-column read may begin up to three columns left of the band --, then r - bw .. r)
+// fits the CU's LDS for n = 300, bw <= 59, and the whole solve runs there: no panel staging from L2, no write-back, no
+// trailing update through L2.  Entry (r, c) of the band lives at Ab[r * RS + c - r + bw + 3].
+//
+// The factorisation is a right-looking BLOCK LDLt with 4 x 4 pivot blocks, n / 4 steps, one barrier per step.  With
+// E the pivot block of step k as it stands after the earlier steps, R the rows below it in the pivot's four columns
+// ("raw panel": also final after the earlier steps) and G = E^-1, the trailing matrix takes
+//     A(r, c) -= R_r G R_c^T,
+// a rank-4 update -- exactly one v_mfma_f64_16x16x4_f64 per 16 x 16 tile: A operand R_r G (four raw entries and one
+// row of G per lane), B operand the raw entry itself.  The window the update can reach (rows / columns k + 4 ..
+// k + 3 + bw) lies inside a 5 x 5 triangle of tiles; the tiles LIVE IN ACCUMULATORS for as long as they are in the
+// window (wave I mod 5 owns block row I: its tiles share one A operand) and are read from the band once, when their
+// block row enters.  What goes back to LDS per step is
+// only the next raw panel (4 columns) and the next-but-one pivot block.
+//   waves 0..4  tiles: operands, MFMA, the next raw panel (columns k + 4 .. k + 7) and a preview of the block
+//               (k + 8 .. k + 11)^2 for the look-ahead;
+//   wave 5      PIVOT LOOK-AHEAD: the next block E' = E_preview - P G P^T (P = its rows of the current raw panel), its
+//               LDLt, G' = E'^-1 for the next step's operands and T' = L4^-T D4^-1 / L4 for the unit-L form;
+//   wave 6      the right-hand side ("row n"): y_c -= R_c G y_k;
+//   wave 7      only meets the barriers.
+// Afterwards the raw panels become the scalar unit-L factor (L(r, k..k+3) = R_r T, L4 inside a block), z = T^T y, and
+// the blocked backward substitution runs out of LDS as before.
+#ifndef LB_PIV_WAVE
+#define LB_PIV_WAVE 3
+#define LB_RHS_WAVE 7
+#endif
 #define LD_BAND_LDS (150 * 1024)     // dynamic LDS the kernel may use (bak_ldlt_smem requests at least this much when it fits)
 // Row stride EVEN: a column of the band, A(c, k) for c = k + 1, k + 2, .., is a walk of RS - 1 doubles per row, and an odd number
-// of doubles per step spreads 32 lanes over 32 different bank pairs (with RS = 49 they all fell on two: 3,500 cycles per step).
-__host__ __device__ inline int ldlt_band_rs(int bw) { return (bw + 3) & ~1; }
-__host__ __device__ inline size_t ldlt_band_bytes(int n, int bw) { return sizeof(double) * ((size_t)(n + 1) * ldlt_band_rs(bw) + 3 * (size_t)(n + 2)); }
-__host__ __device__ inline bool ldlt_band_ok(int n, int bw) {
-    int chunks = 0;   // chunks of 8 columns per row of the update triangle: one per thread of four waves; the rhs: one lane per entry
-    for (int r = 0; r < bw; ++r) chunks += (r + 8) / 8;
-    return n > 0 && bw >= 2 && bw <= 64 && chunks <= 256 && ldlt_band_bytes(n, bw) <= LD_BAND_LDS;
+// of doubles per step spreads 32 lanes over 32 different bank pairs (with RS = 49 they all fell on two).
+__host__ __device__ inline int ldlt_band_rs(int bw) { return (bw + 5) & ~1; }
+__host__ __device__ inline int ldlt_band_ylen(int n) { return (n + 9) & ~1; }
+__host__ __device__ inline size_t ldlt_band_bytes(int n, int bw) {
+    return sizeof(double) * ((size_t)(n + 1) * ldlt_band_rs(bw) + ldlt_band_ylen(n) + 16 * (size_t)((n + 3) / 4 + 1));
 }
+// bw <= 59: the reachable rows k + 4 .. k + 3 + bw stay within five block rows of the pivot's block column
+__host__ __device__ inline bool ldlt_band_ok(int n, int bw) { return n > 0 && bw >= 8 && bw <= 59 && ldlt_band_bytes(n, bw) <= LD_BAND_LDS; }
+
+// LDLt of a symmetric 4 x 4 block (lower entries e: 00 10 11 20 21 22 30 31 32 33; rows >= nv are padding and count as
+// identity) and its NEGATED inverse G (row-major, symmetric: every user subtracts).
+__device__ __forceinline__ void ldlt_piv4(const double* e, int nv, double* G, bool& bad) {
+    double e00 = e[0], e10 = e[1], e11 = e[2], e20 = e[3], e21 = e[4], e22 = e[5], e30 = e[6], e31 = e[7], e32 = e[8], e33 = e[9];
+    if (nv < 4) { e30 = 0; e31 = 0; e32 = 0; e33 = 1; }
+    if (nv < 3) { e20 = 0; e21 = 0; e22 = 1; }
+    if (nv < 2) { e10 = 0; e11 = 1; }
+    // The four pivots are a dependent chain (this wave's step is the solve's critical path): every pivot is formed as
+    // d' = d - (a a x) w with x = v_rcp_f64(d_prev), w = 2 - d_prev x its Newton factor, so that only rcp -> {w, a a x} -> fma
+    // lie between two reciprocals; everything else (the multipliers l, the other entries) hangs off the side.
+    const double x0 = __builtin_amdgcn_rcp(e00), w0 = 2.0 - e00 * x0, i0 = x0 * w0;
+    const double d1 = e11 - ((e10 * e10) * x0) * w0;
+    const double l10 = e10 * i0, l20 = e20 * i0, l30 = e30 * i0;
+    e21 -= l20 * e10; e31 -= l30 * e10; e22 -= l20 * e20; e32 -= l30 * e20; e33 -= l30 * e30;
+    const double x1 = __builtin_amdgcn_rcp(d1), w1 = 2.0 - d1 * x1, i1 = x1 * w1;
+    const double d2 = e22 - ((e21 * e21) * x1) * w1;
+    const double l21 = e21 * i1, l31 = e31 * i1;
+    e32 -= l31 * e21; e33 -= l31 * e31;
+    const double x2 = __builtin_amdgcn_rcp(d2), w2 = 2.0 - d2 * x2, i2 = x2 * w2;
+    const double d3 = e33 - ((e32 * e32) * x2) * w2;
+    const double l32 = e32 * i2;
+    const double x3 = __builtin_amdgcn_rcp(d3), i3 = x3 * (2.0 - d3 * x3);
+    auto isbad = [](double d) { return d == 0.0 || !(fabs(d) <= DBL_MAX); };
+    bad = isbad(e00) || isbad(d1) || isbad(d2) || isbad(d3);
+    // M = L^-1 (unit lower)
+    const double m10 = -l10, m21 = -l21, m32 = -l32;
+    const double m20 = -(l20 + l21 * m10), m31 = -(l31 + l32 * m21);
+    const double m30 = -(l30 + l31 * m10 + l32 * m20);
+    const double t01 = m10 * i1, t02 = m20 * i2, t12 = m21 * i2, t03 = m30 * i3, t13 = m31 * i3, t23 = m32 * i3;
+    const double g33 = i3, g23 = t23, g13 = t13, g03 = t03;
+    const double g22 = i2 + t23 * m32, g12 = t12 + t13 * m32, g02 = t02 + t03 * m32;
+    const double g11 = (i1 + t12 * m21) + t13 * m31, g01 = (t01 + t02 * m21) + t03 * m31;
+    const double g00 = (i0 + t01 * m10) + (t02 * m20 + t03 * m30);
+    G[0] = -g00; G[1] = -g01; G[2] = -g02; G[3] = -g03;
+    G[4] = -g01; G[5] = -g11; G[6] = -g12; G[7] = -g13;
+    G[8] = -g02; G[9] = -g12; G[10] = -g22; G[11] = -g23;
+    G[12] = -g03; G[13] = -g13; G[14] = -g23; G[15] = -g33;
+}
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, double* sm, int* s_fail) {
     const int n = W.nS, N = W.Npad, bw = W.band, RS = ldlt_band_rs(bw);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double* Ab = sm;                         // (n + 1) x RS, the extra row is zero (pivot reads of an odd n)
-    double* y = Ab + (size_t)(n + 1) * RS;   // n + 2: right-hand side -> D^-1 L^-1 b -> x
-    double* invd = y + n + 2;                // n + 2: 1 / d_k
-    double* corr = invd + n + 2;             // n + 2: f of the odd column of each pair
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // roles: waves 0, 1, 2, 4, 5 update (block rows uw mod 5), wave 3 is the pivot wave, wave 7 the right-hand side: with waves dealt
+    // round-robin to the four SIMDs the pivot chain then shares its SIMD only with the rhs wave, not with fp64 MFMAs
+    const int uw = wv < 3 ? wv : (wv == 4 || wv == 5) ? wv - 1 : -1;
+    const bool is_piv = wv == LB_PIV_WAVE, is_rhs = wv == LB_RHS_WAVE;
+    double* Ab = sm;                          // (n + 1) x RS, the extra row is zero
+    double* y = Ab + (size_t)(n + 1) * RS;    // right-hand side -> block forward substitution -> z -> x (zeros behind n)
+    double* fac = y + ldlt_band_ylen(n);      // 16 doubles per pivot block: -E^-1 (ldlt_piv4), written one step ahead
+    __shared__ __attribute__((aligned(16))) double s_E[2][16];   // [step parity] the next pivot block before the step's update
 #ifdef BA_DIAG_STAMPS
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
     if (tid == 0) { st->dbg[0] = tprev; st->dbg[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -650,175 +717,228 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * LD_THREADS, r = i / RS, j = i - r * RS, c = r - bw - 1 + j;
-            v[u] = (i < (n + 1) * RS && r < n && j >= 1 && j <= bw + 1 && c >= 0) ? S[(size_t)r * N + c] : 0.0;
+            const int i = i0 + u * LD_THREADS, r = i / RS, j = i - r * RS, c = r - bw - 3 + j;
+            v[u] = (i < (n + 1) * RS && r < n && j >= 3 && j <= bw + 3 && c >= 0) ? S[(size_t)r * N + c] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int i = i0 + u * LD_THREADS; if (i < (n + 1) * RS) Ab[i] = v[u]; }
     }
-    for (int i = tid; i < n + 2; i += LD_THREADS) { y[i] = i < n ? W.rhs[i] : 0.0; invd[i] = 0.0; corr[i] = 0.0; }
-    // Division of labour (the step is bound by the instructions a wave issues -- fp64, one wave per SIMD at best -- so no wave
-    // does anything twice):
-    //   waves 0..3  the bw x bw triangle under the pivot pair (k, k + 1): a thread owns a chunk of EIGHT consecutive columns
-    //               dc0 .. dc0 + 7 of ONE row dr (r = k + 2 + dr, c = k + 2 + dc, dc <= dr); it reads 1 / d0, 1 / d1, f of the
-    //               pair from LDS and does no pivot arithmetic;
-    //   wave 4      the right-hand side ("row n", one entry per lane) and the PIVOT LOOK-AHEAD: the next pair's pivot block
-    //               from its values before this step (its rank-2 update is three more entries), its determinant and two
-    //               reciprocals (a Newton step each), published for the next step in a two-deep LDS slot.  The three entries
-    //               of that block are therefore never stored in their last step (rows dr = 0, 1 are not stored at all: the
-    //               look-ahead's reads would race with the store); their final values only live on as invd / corr, and
-    //               L(k + 1, k) = f;
-    //   waves 5..7  only meet the barriers.
-    // Offsets are doubles from `sm` at k = 0 and advance by a constant per step.  Every load of a step is unconditional (an
-    // address past the band reads zeros or another row's data -- inside the kernel's LDS or, beyond it, zeros -- and only
-    // the stores are predicated): no branch sits between a load and its use.
-    __shared__ double s_piv[2][4];   // [step parity][inv0, inv1, f, -]
-    auto pivots = [&](double d0, double l10, double d11, bool two, double* out, bool& bad) {
-        const bool bad0 = (d0 == 0.0 || !(fabs(d0) <= DBL_MAX));
-        const double det = d0 * d11 - l10 * l10;
-        const double i0 = bad0 ? 0.0 : fast_recip(d0);
-        const bool bad1 = two && (det == 0.0 || !(fabs(det) <= DBL_MAX));
-        out[0] = i0;
-        out[1] = (two && !bad1 && !bad0) ? d0 * fast_recip(det) : 0.0;
-        out[2] = l10 * i0;
-        bad = bad0 || bad1;
-    };
-    int dr = -1, dc0 = 0;
-    if (wv < 4) {
-        int q = tid, row = 0;
-        for (; row < bw; ++row) { const int nch = (row + 8) >> 3; if (q < nch) break; q -= nch; }
-        if (row < bw) { dr = row; dc0 = 8 * q; }
+    for (int i = tid; i < ldlt_band_ylen(n); i += LD_THREADS) y[i] = i < n ? W.rhs[i] : 0.0;
+    __syncthreads();
+    if (is_piv) {   // the first pivot block and the preview of the second
+        double e[10], G[16];
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) { const double v = Ab[min(i, n) * RS + j - i + bw + 3]; e[q++] = i < n ? v : 0.0; }
+        bool bad;
+        ldlt_piv4(e, min(4, n), G, bad);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) reinterpret_cast<double2_t*>(fac)[i] = (double2_t){G[2 * i], G[2 * i + 1]};
+            if (bad) *s_fail = 1;
+        }
+        if (lane < 16) {
+            const int i = lane >> 2, j = lane & 3, r = 4 + i;
+            const double v = Ab[min(r, n) * RS + j - i + bw + 3];
+            s_E[0][lane] = (j <= i && r < n) ? v : 0.0;
+        }
     }
-    const int edr = max(dr, 0);
-    int o_r = (2 + edr) * RS + (bw - 1 - edr);            // A(r, k), A(r, k + 1)
-    int o_v = (2 + edr) * RS + (bw + 1 - edr + dc0);      // A(r, c0 .. c0 + 7)
-    int o_c = (2 + dc0) * RS + (bw - 1 - dc0);            // A(c0 + i, k), A(c0 + i, k + 1): + i (RS - 1)
-    const int klim_m = dr >= 2 ? n - 2 - dr : 0;          // row r = k + 2 + dr exists while k < klim_m
-    const int ncol = dr >= 0 ? min(8, dr + 1 - dc0) : 0;  // entries of the chunk inside the triangle
-    // wave 4: rhs entry c = k + 2 + lane
-    int o_yc = (2 + lane) * RS + (bw - 1 - lane);
-    bool pbad = false;
-    if (tid == 0) { double pv3[3]; pivots(Ab[bw + 1], Ab[RS + bw], Ab[RS + bw + 1], n > 1, pv3, pbad); s_piv[0][0] = pv3[0]; s_piv[0][1] = pv3[1]; s_piv[0][2] = pv3[2]; if (pbad) *s_fail = 1; }
     __syncthreads();
 #ifdef BA_DIAG_STAMPS
     { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[0] += tn - tprev; tprev = tn; }
 #endif
-    for (int k = 0; k < n; k += 2) {
-        const int par = (k >> 1) & 1;
-        if (wv < 4) {
-            const double inv0 = s_piv[par][0], inv1 = s_piv[par][1], f = s_piv[par][2];
-            const double ark = sm[o_r], ar1k = sm[o_r + 1];
-            double ack[8], ac1k[8], v[8];
+    const int nb16 = (n + 15) >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ZA = n * RS;            // four zeros (the extra row): where a lane without an operand reads
+    const int BIG = 0x40000000;
+    double4_t acc[5];
+    // Wave w < 5 owns the block rows I = w (mod 5): one A operand per step for all its tiles (cell b: block column J = b (mod 5)).
+    // Renewed whenever the pivot enters a new block column: the block row (scalar), the lane's operand addresses at k = 0
+    // (they advance with k), "row - 4" / "column - 4" for the reach test 0 <= x - 4 - k < bw (BIG: never), and where the
+    // lane's four accumulator entries of each tile live in the band (mask: inside the band and the matrix).
+    int rowI = 0, ara = 0, art = BIG, cJt[5], cba[5], cbt[5], cwa[5], cwm[5];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { ack[i] = sm[o_c + i * (RS - 1)]; ac1k[i] = sm[o_c + i * (RS - 1) + 1]; v[i] = sm[o_v + i]; }
-            const double ar1 = ar1k - ark * f, s0 = ark * inv0, s1 = ar1 * inv1;
-            double nv[8];
+    for (int b = 0; b < 5; ++b) { acc[b] = (double4_t){0, 0, 0, 0}; cJt[b] = 0; cba[b] = 0; cbt[b] = BIG; cwa[b] = 0; cwm[b] = 0; }
+#ifdef BA_DIAG_PIV
+    unsigned long long pv[4] = {0, 0, 0, 0}, tp = 0;
+#endif
+    for (int k = 0; k < n; k += 4) {
+        const int par = (k >> 2) & 1;
+#ifdef BA_DIAG_STAMPS
+        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (uw >= 0) {
+            const int Jlo = k >> 4;
+            const int Ihi = min((k + 3 + bw) >> 4, nb16 - 1);
+            const int Iprev = k > 0 ? min((k - 1 + bw) >> 4, nb16 - 1) : -1;
+            const int Jn = (k + 4) >> 4, Jp = (k + 8) >> 4;
+            const unsigned jn = (unsigned)(li - ((k + 4) & 15)), jp = (unsigned)(li - ((k + 8) & 15));
+            const int op = (k + 8) & 15;
+            if ((k & 15) == 0) {
+                const int Jm = Jlo % 5;
+                int di = uw - Jm; if (di < 0) di += 5;
+                rowI = Jlo + di;
+                const int r = 16 * rowI + li, r0 = 16 * rowI + lk;
+                ara = r * RS + (bw + 3 - r); art = r < n ? r - 4 : BIG;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) nv[i] = v[i] - (s0 * ack[i] + s1 * (ac1k[i] - ack[i] * f));
-            const bool live = k < klim_m;
+                for (int b = 0; b < 5; ++b) {
+                    int dj = b - Jm; if (dj < 0) dj += 5;
+                    const int Jt = Jlo + dj, c = 16 * Jt + li;
+                    cJt[b] = Jt;
+                    cba[b] = c * RS + (lk + bw + 3 - c); cbt[b] = (Jt <= rowI && c < n) ? c - 4 : BIG;
+                    cwa[b] = r0 * (RS - 1) + c + bw + 3;
+                    int m = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (live && i < ncol) sm[o_v + i] = nv[i];
-            o_r += 2 * RS; o_v += 2 * RS; o_c += 2 * RS;
-        } else if (wv == 4) {
-            const bool two = k + 1 < n;
-            const double* Ak = Ab + (size_t)k * RS;
-            const double inv0 = s_piv[par][0], inv1 = s_piv[par][1], f = s_piv[par][2];
-            // rows p = k + 2, q = k + 3 of the next pivot block: their entries in columns k, k + 1 and the block itself
-            const double* Ap = Ak + 2 * RS;
-            const double ap0 = Ap[bw - 1], ap1k = Ap[bw], e00 = Ap[bw + 1];
-            const double aq0 = Ap[RS + bw - 2], aq1k = Ap[RS + bw - 1], e10 = Ap[RS + bw], e11 = Ap[RS + bw + 1];
-            // right-hand side: y[c] -= y[k] A(c, k) / d0 + y'[k + 1] A'(c, k + 1) / d1
-            const double yk = y[k], yk1 = y[k + 1];
-            const double ack = sm[o_yc], ac1k = sm[o_yc + 1], yc = y[k + 2 + lane];
-            const double ap1 = ap1k - ap0 * f, aq1 = aq1k - aq0 * f;
-            const double t0 = ap0 * inv0, t1 = ap1 * inv1, u0 = aq0 * inv0, u1 = aq1 * inv1;
-            const double d0n = e00 - (t0 * ap0 + t1 * ap1), l10n = e10 - (t0 * aq0 + t1 * aq1), d11n = e11 - (u0 * aq0 + u1 * aq1);
-            double nxt[3];
-            bool nbad;
-            pivots(d0n, l10n, d11n, k + 3 < n, nxt, nbad);   // (past the end: rows of zeros or beyond the band -- never used)
-            const double y1 = yk1 - yk * f;
-            const double ny = yc - (yk * inv0 * ack + y1 * inv1 * (ac1k - ack * f));
-            if (lane < bw && k + 2 + lane < n) y[k + 2 + lane] = ny;
-            if (lane == 0) {
-                invd[k] = inv0;
-                if (two) { invd[k + 1] = inv1; corr[k + 1] = f; }
-                s_piv[par ^ 1][0] = nxt[0]; s_piv[par ^ 1][1] = nxt[1]; s_piv[par ^ 1][2] = nxt[2];
-                if (nbad && k + 2 < n) *s_fail = 1;
+                    for (int g = 0; g < 4; ++g) { const int rr = r0 + 4 * g; if (Jt <= rowI && c <= rr && rr - c <= bw && rr < n) m |= 1 << g; }
+                    cwm[b] = m;
+                }
             }
-            o_yc += 2 * RS;
+            const int It = __builtin_amdgcn_readfirstlane(rowI);
+            if (It <= Ihi) {   // (a block row the update cannot reach yet has nothing to do)
+                if (It > Iprev) {   // the block row enters the window: its tiles come out of the band (untouched so far)
+#pragma unroll
+                    for (int b = 0; b < 5; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[b][g] = Ab[(cwm[b] >> g & 1) ? cwa[b] + 4 * g * (RS - 1) : ZA];
+                }
+                const double2_t ga = reinterpret_cast<const double2_t*>(fac + 4 * k)[2 * lk], gb = reinterpret_cast<const double2_t*>(fac + 4 * k)[2 * lk + 1];
+                const int aa = (unsigned)(art - k) < (unsigned)bw ? ara + k : ZA;
+                const double r0 = Ab[aa], r1 = Ab[aa + 1], r2 = Ab[aa + 2], r3 = Ab[aa + 3];
+                double bvl[5];
+#pragma unroll
+                for (int b = 0; b < 5; ++b) bvl[b] = Ab[(unsigned)(cbt[b] - k) < (unsigned)bw ? cba[b] + k : ZA];
+                const double av = (r0 * ga.x + r1 * ga.y) + (r2 * gb.x + r3 * gb.y);   // R_r (-G)
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {
+                    const int Jt = __builtin_amdgcn_readfirstlane(cJt[b]);
+                    if (Jt > It) continue;   // wave-uniform
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bvl[b], acc[b], 0, 0, 0);
+                    if (Jt == Jn && k + 4 < n && jn < 4u) {   // the next raw panel: the lanes whose column is one of k + 4 .. k + 7
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (cwm[b] >> g & 1) Ab[cwa[b] + 4 * g * (RS - 1)] = acc[b][g];
+                    }
+                    if (It == Jp && Jt == Jp && k + 8 < n) {   // the pivot block after the next, as it stands now (rows op .. op + 3 of the tile: register op / 4)
+                        const double v = op == 0 ? acc[b][0] : op == 4 ? acc[b][1] : op == 8 ? acc[b][2] : acc[b][3];
+                        if (jp < 4u) s_E[par ^ 1][4 * lk + (int)jp] = v;
+                    }
+                }
+            }
+        } else if (is_piv) {
+            if (k + 4 < n) {
+                const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
+                const int nv = min(4, n - (k + 4));
+                const double* Pi = Ab + (size_t)min(k + 4 + i, n) * RS + (bw - 1 - i);
+                const double* Pj = Ab + (size_t)min(k + 4 + j, n) * RS + (bw - 1 - j);
+                double pi[4], pj[4], gj[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { pi[m] = Pi[m]; pj[m] = Pj[m]; gj[m] = fac[4 * k + 4 * j + m]; }
+                const double eij = s_E[par][4 * max(i, j) + min(i, j)];
+#ifdef BA_DIAG_PIV
+                __builtin_amdgcn_s_waitcnt(0); { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[0] += t - tb0; tp = t; }
+#endif
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { if (i >= nv) pi[m] = 0.0; if (j >= nv) pj[m] = 0.0; }
+                const double qij = (pi[0] * gj[0] + pi[1] * gj[1]) + (pi[2] * gj[2] + pi[3] * gj[3]);   // (P (-G))(i, j)
+                const double en = (eij + dpp_xchg_d<0x00>(qij) * pj[0] + dpp_xchg_d<0x55>(qij) * pj[1]) + (dpp_xchg_d<0xAA>(qij) * pj[2] + dpp_xchg_d<0xFF>(qij) * pj[3]);
+                double e[10], G[16];
+                e[0] = readlane_d(en, 0);
+                e[1] = readlane_d(en, 4); e[2] = readlane_d(en, 5);
+                e[3] = readlane_d(en, 8); e[4] = readlane_d(en, 9); e[5] = readlane_d(en, 10);
+                e[6] = readlane_d(en, 12); e[7] = readlane_d(en, 13); e[8] = readlane_d(en, 14); e[9] = readlane_d(en, 15);
+#ifdef BA_DIAG_PIV
+                { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[1] += t - tp; tp = t; }
+#endif
+                bool bad;
+                ldlt_piv4(e, nv, G, bad);
+#ifdef BA_DIAG_PIV
+                if (G[0] == 1.2345) pv[3] += 1;
+                { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[2] += t - tp; tp = t; }
+#endif
+                if (lane == 0) {
+                    double2_t* fo = reinterpret_cast<double2_t*>(fac + 4 * (k + 4));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) fo[u] = (double2_t){G[2 * u], G[2 * u + 1]};
+                    if (bad) *s_fail = 1;
+                }
+#ifdef BA_DIAG_PIV
+                __builtin_amdgcn_s_waitcnt(0); { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[3] += t - tp; tp = t; }
+#endif
+            }
+        } else if (is_rhs) {
+            double gy[4];
+            {
+                const double y0 = y[k], y1 = y[k + 1], y2 = y[k + 2], y3 = y[k + 3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gy[j] = (fac[4 * k + 4 * j] * y0 + fac[4 * k + 4 * j + 1] * y1) + (fac[4 * k + 4 * j + 2] * y2 + fac[4 * k + 4 * j + 3] * y3);
+            }
+            const int c = k + 4 + lane;
+            const bool cv = lane < bw && c < n;
+            const int ca = cv ? c * RS + (k - c + bw + 3) : ZA;   // entries left of the band are the row's zero slots
+            const double r0 = Ab[ca], r1 = Ab[ca + 1], r2 = Ab[ca + 2], r3 = Ab[ca + 3];
+            const double yc = y[cv ? c : 0];
+            if (cv) y[c] = yc + (r0 * gy[0] + r1 * gy[1] + r2 * gy[2] + r3 * gy[3]);   // gy = -G y_k
         }
+#ifdef BA_DIAG_STAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        ph[3] += __builtin_amdgcn_s_memtime() - tb0;   // busy part of the step, per wave
+#endif
         __syncthreads();
     }
 #ifdef BA_DIAG_STAMPS
     { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[1] += tn - tprev; tprev = tn; }
 #endif
     if (*s_fail) { if (tid == 0) st->ok2 = 0; return; }
-    // unit-L form of the band (column pairs: L(r, k) = A(r, k) / d_k, L(r, k + 1) = (A(r, k + 1) - A(r, k) f) / d_{k+1}) and
-    // z = D^-1 L^-1 b in y
-    for (int i = tid; i < n * ((bw + 3) / 2); i += LD_THREADS) {
-        const int r = i / ((bw + 3) / 2), jp = i - r * ((bw + 3) / 2);
-        const int c0 = ((r - bw - 1) & ~1) + 2 * jp;    // even column of the pair (may start one left of the band: slot < 0 skipped)
-        if (c0 > r) continue;
-        const int j0 = c0 - r + bw + 1;
-        double* row = Ab + (size_t)r * RS;
-        const double a0 = (j0 >= 0 && c0 >= 0) ? row[j0] : 0.0;
-        if (j0 >= 0 && c0 >= 0 && c0 < r) row[j0] = (r == c0 + 1) ? corr[r] : a0 * invd[c0];   // (the pair's own off-diagonal entry was never stored)
-        if (c0 + 1 < r && c0 + 1 >= 0) row[j0 + 1] = (row[j0 + 1] - a0 * corr[c0 + 1]) * invd[c0 + 1];
+    // Block back-substitution, right-looking, on ONE wave: with v = y (the block forward substitution), for the pivot blocks
+    // s from the last to the first:  x_s = G_s v_s,  then  v_c -= sum_j R(4 s + j, c) x_{s, j}  for the columns c left of the
+    // block inside the band -- rows 4 s .. 4 s + 3 of the raw band, one column per lane, no reduction across lanes.  Lane l
+    // holds the column c = l (mod 64) of the 64 below the block in a register; a column takes its y the step it comes into
+    // reach (distance d = 4 s - 1 - c <= bw - 1).  The block's own quad multiplies by G (quad broadcasts), v_readlane
+    // hands x to every lane.
+    if (wv == 0) {
+        const int S4 = (n + 3) >> 2;
+        const int lj = lane & 3;
+        double v;
+        { const int d = (4 * S4 - 1 - lane) & 63, c = 4 * S4 - 1 - d; v = y[max(c, 0)]; if (c < 0) v = 0.0; }
+        const double2_t* gp = reinterpret_cast<const double2_t*>(fac + 4 * lj);
+        double2_t ga = gp[8 * (S4 - 1)], gb = gp[8 * (S4 - 1) + 1];
+        for (int sb = S4 - 1; sb >= 0; --sb) {
+            const int k = 4 * sb;
+            const int d = (k - 1 - lane) & 63, c = k - 1 - d;
+            const bool reach = d <= bw - 1 && c >= 0;
+            const bool enter = d >= bw - 4 && reach;
+            const int ra = reach ? k * (RS - 1) + c + bw + 3 : ZA;   // R(k, c); rows k + 1 .. k + 3 follow at RS - 1 each (rows >= n: zeros)
+            const double ye = y[max(c, 0)];
+            const double r0 = Ab[ra];
+            const double r1 = Ab[(reach && k + 1 < n) ? ra + (RS - 1) : ZA];
+            const double r2 = Ab[(reach && k + 2 < n) ? ra + 2 * (RS - 1) : ZA];
+            const double r3 = Ab[(reach && k + 3 < n) ? ra + 3 * (RS - 1) : ZA];
+            const double2_t na = gp[8 * max(sb - 1, 0)], nb = gp[8 * max(sb - 1, 0) + 1];   // the next block's row of -G
+            const double v0 = dpp_xchg_d<0x00>(v), v1 = dpp_xchg_d<0x55>(v), v2 = dpp_xchg_d<0xAA>(v), v3 = dpp_xchg_d<0xFF>(v);
+            const double x = -((ga.x * v0 + ga.y * v1) + (gb.x * v2 + gb.y * v3));
+            const int q0 = 4 * (sb & 15);
+            const double x0 = readlane_dyn_d(x, q0), x1 = readlane_dyn_d(x, q0 + 1), x2 = readlane_dyn_d(x, q0 + 2), x3 = readlane_dyn_d(x, q0 + 3);
+            if ((lane & 60) == q0) y[k + lj] = x;   // (entries behind n of a ragged last block: the zeros of y's tail take zeros)
+            if (enter) v = ye;
+            v -= (r0 * x0 + r1 * x1) + (r2 * x2 + r3 * x3);
+            ga = na; gb = nb;
+        }
     }
     __syncthreads();
-    for (int k = 2 * tid; k < n; k += 2 * LD_THREADS) {
-        const double y0 = y[k], y1 = y[k + 1];
-        y[k] = y0 * invd[k];
-        if (k + 1 < n) y[k + 1] = (y1 - y0 * corr[k + 1]) * invd[k + 1];
-    }
-    __syncthreads();
-#ifdef BA_DIAG_STAMPS
-    { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[2] += tn - tprev; tprev = tn; }
-#endif
-    // backward substitution x = L^-T z over 32-row blocks from the bottom: wavefront 0 solves the block (lane k owns x_k,
-    // its column of the block's L in registers, v_readlane broadcasts), then the <= bw unknowns above take the block's part
-    const int jb_last = ((n - 1) / LD_NB) * LD_NB;
-    for (int jb = jb_last; jb >= 0; jb -= LD_NB) {
-        const int nb = min(LD_NB, n - jb);
-        if (wv == 0) {
-            const int k = lane & 31;
-            double col[LD_NB];
-#pragma unroll
-            for (int m = 0; m < LD_NB; ++m) {   // L(jb + m, jb + k); loaded unconditionally (rows past n: zeros or beyond the LDS), selected after
-                const double l = Ab[(size_t)(jb + m) * RS + bw + 1 - (m - k)];
-                col[m] = (lane < nb && m < nb && m > k && m - k <= bw) ? l : 0.0;
-            }
-            double v = (lane < nb) ? y[jb + k] : 0.0;
-#pragma unroll
-            for (int m = LD_NB - 1; m >= 0; --m) {
-                const double xm = readlane_d(v, m);
-                v -= col[m] * xm;   // col[m] = 0 where the term does not exist
-            }
-            if (lane < nb) y[jb + k] = v;
-        }
-        __syncthreads();
-        if (tid < min(bw, jb)) {
-            const int i = jb - 1 - tid;
-            // L(jb + m, i) sits at slot bw + 1 - (jb + m - i) = bw - tid - m of row jb + m: all 32 loads first, then the sum
-            double l[LD_NB], x[LD_NB];
-#pragma unroll
-            for (int m = 0; m < LD_NB; ++m) { l[m] = Ab[(size_t)(jb + m) * RS + (bw - tid - m)]; x[m] = y[jb + m]; }
-            double acc0 = y[i], acc1 = 0.0;
-#pragma unroll
-            for (int m = 0; m < LD_NB; m += 2) {
-                acc0 -= (m < nb && tid + m + 1 <= bw) ? l[m] * x[m] : 0.0;
-                acc1 -= (m + 1 < nb && tid + m + 2 <= bw) ? l[m + 1] * x[m + 1] : 0.0;
-            }
-            y[i] = acc0 + acc1;
-        }
-        __syncthreads();
-    }
     for (int i = tid; i < n; i += LD_THREADS) W.rhs[i] = y[i];
 #ifdef BA_DIAG_STAMPS
     { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[5] += tn - tprev; tprev = tn; }
+    if (lane == 0 && is_piv) st->dbg[7] = ph[3];
+    if (lane == 0 && is_rhs) st->dbg[6] = ph[3] << 32;   // (tid 0 ors its part in below: after the barrier of the last loop)
+    __syncthreads();
     if (tid == 0) { st->dbg[2] = __builtin_amdgcn_s_memtime(); st->dbg[3] = __builtin_amdgcn_s_memrealtime();
-                    st->dbg[4] = (ph[0] << 32) | ph[1]; st->dbg[5] = (ph[2] << 32) | ph[3]; st->dbg[6] = (ph[4] << 32) | ph[5]; }
+                    st->dbg[4] = (ph[0] << 32) | ph[1]; st->dbg[5] = (ph[2] << 32) | ph[3]; st->dbg[6] |= ph[5]; }
+#ifdef BA_DIAG_PIV
+    __syncthreads();
+    if (lane == 0 && is_piv) { st->dbg[4] = (pv[0] << 32) | pv[1]; st->dbg[5] = (pv[2] << 32) | pv[3]; }   // pivot wave: reads / E' + gather / factor + inverse / stores
+#endif
 #endif
     if (tid == 0) st->ok2 = 1;
 }
@@ -832,7 +952,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     // k_iter_begin's bookkeeping for the slots without that launch (bak_slot, first == false): this is the first
     // single-workgroup kernel behind the last reader of need_linearize (k_pose_reduce)
     if (tid == 0 && st->need_linearize) { st->iniChi = st->currentChi; st->qmax = 0; st->need_linearize = 0; }
-    extern __shared__ double sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Dg = sm;                      // LD_NB x LD_P: diagonal block (unit L below, D on the diagonal)
     double* Wd = Dg + LD_NB * LD_P;       // (rows below + rhs row, padded to 16) x LD_P: L21 * D
     __shared__ int s_fail;

@@ -94,6 +94,14 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// value of lane `l` (wave-uniform, not a constant) as a wave-uniform scalar
+__device__ __forceinline__ double readlane_dyn_d(double v, int l) {
+    const int ls = __builtin_amdgcn_readfirstlane(l);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), ls);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), ls);
+    return __hiloint2double(hi, lo);
+}
+
 // Sum over the 64 lanes, the same value in every lane, in a fixed order: four DPP exchanges make every 16-lane row hold its
 // row sum (xor 1, xor 2, half-row mirror, row mirror), four v_readlane pairs join the rows.  (The ds_bpermute form of
 // __shfl_xor is an LDS round trip per step: twelve of them per sum, and the optimisers reduce 27-35 sums per iteration.)
