@@ -752,15 +752,20 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     const int nb16 = (n + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
     const int ZA = n * RS;            // four zeros (the extra row): where a lane without an operand reads
+    __shared__ double s_dump[64];
+    const int dump = (int)(s_dump - sm) + lane;   // (a double index relative to sm, like every other offset here)
     const int BIG = 0x40000000;
     double4_t acc[5];
     // Wave w < 5 owns the block rows I = w (mod 5): one A operand per step for all its tiles (cell b: block column J = b (mod 5)).
     // Renewed whenever the pivot enters a new block column: the block row (scalar), the lane's operand addresses at k = 0
     // (they advance with k), "row - 4" / "column - 4" for the reach test 0 <= x - 4 - k < bw (BIG: never), and where the
     // lane's four accumulator entries of each tile live in the band (mask: inside the band and the matrix).
-    int rowI = 0, ara = 0, art = BIG, cJt[5], cba[5], cbt[5], cwa[5], cwm[5];
+    int rowI = 0, ara = 0, art = BIG, cJt[5], cba[5], cbt[5], cwa[5], cwm[5], csh[5];
 #pragma unroll
-    for (int b = 0; b < 5; ++b) { acc[b] = (double4_t){0, 0, 0, 0}; cJt[b] = 0; cba[b] = 0; cbt[b] = BIG; cwa[b] = 0; cwm[b] = 0; }
+    for (int b = 0; b < 5; ++b) { acc[b] = (double4_t){0, 0, 0, 0}; cJt[b] = 0; cba[b] = 0; cbt[b] = BIG; cwa[b] = 0; cwm[b] = 0; csh[b] = 0; }
+#ifdef BA_DIAG_UPD
+    unsigned long long uv[6] = {0, 0, 0, 0, 0, 0};
+#endif
 #ifdef BA_DIAG_PIV
     unsigned long long pv[4] = {0, 0, 0, 0}, tp = 0;
 #endif
@@ -772,66 +777,100 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
         if (uw >= 0) {
             const int Jlo = k >> 4;
             const int Ihi = min((k + 3 + bw) >> 4, nb16 - 1);
-            const int Iprev = k > 0 ? min((k - 1 + bw) >> 4, nb16 - 1) : -1;
             const int Jn = (k + 4) >> 4, Jp = (k + 8) >> 4;
             const unsigned jn = (unsigned)(li - ((k + 4) & 15)), jp = (unsigned)(li - ((k + 8) & 15));
             const int op = (k + 8) & 15;
-            if ((k & 15) == 0) {
-                const int Jm = Jlo % 5;
-                int di = uw - Jm; if (di < 0) di += 5;
-                rowI = Jlo + di;
+            if (k == 0 || ((k & 15) == 0 && rowI < Jlo)) {
+                // The wave's block row has left the window (or the solve begins): it adopts the row five further down -- not in
+                // reach for another step or more, so this costs no step anything -- and takes that row's tiles out of the band,
+                // where nothing has touched them yet.  Cell b holds block column J = b (mod 5) of I - 4 .. I.  Behind the first
+                // adoption everything moves by 80 rows and columns: constants on the addresses, the band's shape stays.
+                if (k == 0) {
+                    rowI = uw;
+                    const int Jb = rowI - 4, Jm = ((Jb % 5) + 5) % 5;
+                    const int r0 = 16 * rowI + lk;
+                    ara = (16 * rowI + li) * (RS - 1) + bw + 3;
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) {
+                        int dj = b - Jm; if (dj < 0) dj += 5;
+                        const int Jt = Jb + dj, c = 16 * Jt + li;
+                        cJt[b] = Jt;
+                        cba[b] = c * (RS - 1) + lk + bw + 3;
+                        cwa[b] = r0 * (RS - 1) + c + bw + 3;
+                        int m = 0;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) if ((unsigned)(r0 + 4 * g - c) <= (unsigned)bw) m |= 1 << g;
+                        csh[b] = m;
+                    }
+                } else {
+                    rowI += 5;
+                    ara += 80 * (RS - 1);
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) { cJt[b] += 5; cba[b] += 80 * (RS - 1); cwa[b] += 80 * RS; }
+                }
                 const int r = 16 * rowI + li, r0 = 16 * rowI + lk;
-                ara = r * RS + (bw + 3 - r); art = r < n ? r - 4 : BIG;
+                art = r < n ? r - 4 : BIG;
+                const int nrow = min(max((n - r0 + 3) >> 2, 0), 4), rowm = (1 << nrow) - 1;   // rows r0 + 4 g inside the matrix
 #pragma unroll
                 for (int b = 0; b < 5; ++b) {
-                    int dj = b - Jm; if (dj < 0) dj += 5;
-                    const int Jt = Jlo + dj, c = 16 * Jt + li;
-                    cJt[b] = Jt;
-                    cba[b] = c * RS + (lk + bw + 3 - c); cbt[b] = (Jt <= rowI && c < n) ? c - 4 : BIG;
-                    cwa[b] = r0 * (RS - 1) + c + bw + 3;
-                    int m = 0;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) { const int rr = r0 + 4 * g; if (Jt <= rowI && c <= rr && rr - c <= bw && rr < n) m |= 1 << g; }
+                    const int c = 16 * cJt[b] + li;
+                    const bool cok = c >= 0 && c < n;
+                    cbt[b] = cok ? c - 4 : BIG;
+                    const int m = cok ? csh[b] & rowm : 0;
                     cwm[b] = m;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[b][g] = Ab[(m >> g & 1) ? cwa[b] + 4 * g * (RS - 1) : ZA];
                 }
             }
+#ifdef BA_DIAG_UPD
+            unsigned long long tu = __builtin_amdgcn_s_memtime(); uv[0] += tu - tb0;
+#endif
             const int It = __builtin_amdgcn_readfirstlane(rowI);
             if (It <= Ihi) {   // (a block row the update cannot reach yet has nothing to do)
-                if (It > Iprev) {   // the block row enters the window: its tiles come out of the band (untouched so far)
-#pragma unroll
-                    for (int b = 0; b < 5; ++b)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[b][g] = Ab[(cwm[b] >> g & 1) ? cwa[b] + 4 * g * (RS - 1) : ZA];
-                }
                 const double2_t ga = reinterpret_cast<const double2_t*>(fac + 4 * k)[2 * lk], gb = reinterpret_cast<const double2_t*>(fac + 4 * k)[2 * lk + 1];
                 const int aa = (unsigned)(art - k) < (unsigned)bw ? ara + k : ZA;
                 const double r0 = Ab[aa], r1 = Ab[aa + 1], r2 = Ab[aa + 2], r3 = Ab[aa + 3];
                 double bvl[5];
 #pragma unroll
                 for (int b = 0; b < 5; ++b) bvl[b] = Ab[(unsigned)(cbt[b] - k) < (unsigned)bw ? cba[b] + k : ZA];
+#ifdef BA_DIAG_UPD
+                { __builtin_amdgcn_s_waitcnt(0); unsigned long long t = __builtin_amdgcn_s_memtime(); uv[2] += t - tu; tu = t; }
+#endif
+#pragma unroll
+                for (int b = 0; b < 5; ++b) asm volatile("" : "+v"(bvl[b]));   // (keeps every load in this block: sunk into its tile's branch it would be waited for alone)
                 const double av = (r0 * ga.x + r1 * ga.y) + (r2 * gb.x + r3 * gb.y);   // R_r (-G)
 #pragma unroll
-                for (int b = 0; b < 5; ++b) {
-                    const int Jt = __builtin_amdgcn_readfirstlane(cJt[b]);
-                    if (Jt > It) continue;   // wave-uniform
-                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bvl[b], acc[b], 0, 0, 0);
-                    if (Jt == Jn && k + 4 < n && jn < 4u) {   // the next raw panel: the lanes whose column is one of k + 4 .. k + 7
+                for (int b = 0; b < 5; ++b)   // the MFMAs back to back (independent accumulators); their consumers follow
+                    if (__builtin_amdgcn_readfirstlane(cJt[b]) >= Jlo) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bvl[b], acc[b], 0, 0, 0);   // (block columns behind the pivot are final)
+#ifdef BA_DIAG_UPD
+                { __builtin_amdgcn_s_waitcnt(0); unsigned long long t = __builtin_amdgcn_s_memtime(); uv[3] += t - tu; tu = t; }
+#endif
+                if (k + 4 < n && Jn <= It) {   // the next raw panel: the lanes whose column is one of k + 4 .. k + 7, in the tile of block column Jn
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            if (cwm[b] >> g & 1) Ab[cwa[b] + 4 * g * (RS - 1)] = acc[b][g];
-                    }
-                    if (It == Jp && Jt == Jp && k + 8 < n) {   // the pivot block after the next, as it stands now (rows op .. op + 3 of the tile: register op / 4)
-                        const double v = op == 0 ? acc[b][0] : op == 4 ? acc[b][1] : op == 8 ? acc[b][2] : acc[b][3];
-                        if (jp < 4u) s_E[par ^ 1][4 * lk + (int)jp] = v;
-                    }
+                    for (int b = 0; b < 5; ++b)
+                        if (__builtin_amdgcn_readfirstlane(cJt[b]) == Jn && jn < 4u) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) sm[(cwm[b] >> g & 1) ? cwa[b] + 4 * g * (RS - 1) : dump] = acc[b][g];   // entries outside the band: into the dump slots
+                        }
+                }
+#ifdef BA_DIAG_UPD
+                { __builtin_amdgcn_s_waitcnt(0); unsigned long long t = __builtin_amdgcn_s_memtime(); uv[4] += t - tu; tu = t; }
+#endif
+                if (It == Jp && k + 8 < n) {   // the pivot block after the next, as it stands now (rows op .. op + 3 of the diagonal tile: register op / 4)
+#pragma unroll
+                    for (int b = 0; b < 5; ++b)
+                        if (__builtin_amdgcn_readfirstlane(cJt[b]) == Jp) {
+                            const double v = op == 0 ? acc[b][0] : op == 4 ? acc[b][1] : op == 8 ? acc[b][2] : acc[b][3];
+                            if (jp < 4u) s_E[par ^ 1][4 * lk + (int)jp] = v;
+                        }
                 }
             }
         } else if (is_piv) {
             if (k + 4 < n) {
                 const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
                 const int nv = min(4, n - (k + 4));
-                const double* Pi = Ab + (size_t)min(k + 4 + i, n) * RS + (bw - 1 - i);
-                const double* Pj = Ab + (size_t)min(k + 4 + j, n) * RS + (bw - 1 - j);
+                const double* Pi = Ab + (i < nv ? (k + 4 + i) * RS + (bw - 1 - i) : ZA);   // (rows behind n: zeros)
+                const double* Pj = Ab + (j < nv ? (k + 4 + j) * RS + (bw - 1 - j) : ZA);
                 double pi[4], pj[4], gj[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) { pi[m] = Pi[m]; pj[m] = Pj[m]; gj[m] = fac[4 * k + 4 * j + m]; }
@@ -839,10 +878,9 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
 #ifdef BA_DIAG_PIV
                 __builtin_amdgcn_s_waitcnt(0); { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[0] += t - tb0; tp = t; }
 #endif
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { if (i >= nv) pi[m] = 0.0; if (j >= nv) pj[m] = 0.0; }
                 const double qij = (pi[0] * gj[0] + pi[1] * gj[1]) + (pi[2] * gj[2] + pi[3] * gj[3]);   // (P (-G))(i, j)
-                const double en = (eij + dpp_xchg_d<0x00>(qij) * pj[0] + dpp_xchg_d<0x55>(qij) * pj[1]) + (dpp_xchg_d<0xAA>(qij) * pj[2] + dpp_xchg_d<0xFF>(qij) * pj[3]);
+                double en = (eij + dpp_xchg_d<0x00>(qij) * pj[0] + dpp_xchg_d<0x55>(qij) * pj[1]) + (dpp_xchg_d<0xAA>(qij) * pj[2] + dpp_xchg_d<0xFF>(qij) * pj[3]);
+                if (max(i, j) >= nv) en = i == j ? 1.0 : 0.0;   // a ragged last block: identity padding
                 double e[10], G[16];
                 e[0] = readlane_d(en, 0);
                 e[1] = readlane_d(en, 4); e[2] = readlane_d(en, 5);
@@ -852,7 +890,7 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
                 { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[1] += t - tp; tp = t; }
 #endif
                 bool bad;
-                ldlt_piv4(e, nv, G, bad);
+                ldlt_piv4(e, 4, G, bad);
 #ifdef BA_DIAG_PIV
                 if (G[0] == 1.2345) pv[3] += 1;
                 { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[2] += t - tp; tp = t; }
@@ -935,6 +973,11 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     __syncthreads();
     if (tid == 0) { st->dbg[2] = __builtin_amdgcn_s_memtime(); st->dbg[3] = __builtin_amdgcn_s_memrealtime();
                     st->dbg[4] = (ph[0] << 32) | ph[1]; st->dbg[5] = (ph[2] << 32) | ph[3]; st->dbg[6] |= ph[5]; }
+#ifdef BA_DIAG_UPD
+    __syncthreads();
+    uv[5] = ph[3]; uv[1] = __builtin_amdgcn_s_getreg(6164) /* HW_ID */;
+    if (lane == 0 && uw == BA_DIAG_UPD) { st->dbg[4] = (uv[0] << 32) | uv[1]; st->dbg[5] = (uv[2] << 32) | uv[3]; st->dbg[6] = (uv[4] << 32) | uv[5]; }   // statics / entering / loads / MFMA / panel
+#endif
 #ifdef BA_DIAG_PIV
     __syncthreads();
     if (lane == 0 && is_piv) { st->dbg[4] = (pv[0] << 32) | pv[1]; st->dbg[5] = (pv[2] << 32) | pv[3]; }   // pivot wave: reads / E' + gather / factor + inverse / stores
