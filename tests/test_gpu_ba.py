@@ -65,11 +65,13 @@ def test_vs_oracle_fresh(opt, k, p, o, seed, nfix):
 
 
 @pytest.mark.parametrize("k,p,o,seed,nfix", [(50, 2000, 8, 12345, 2), (50, 1200, 3, 41, 1), (50, 1500, 10, 42, 3), (12, 300, 4, 43, 1),
-                                             (9, 200, 8, 44, 2), (41, 900, 5, 45, 1)])
+                                             (9, 200, 8, 44, 2), (41, 900, 5, 45, 1), (4, 60, 2, 46, 1), (50, 1000, 2, 47, 1), (23, 500, 9, 48, 1)])
 def test_banded_windows_in_lds_and_through_the_blocked_path(opt, k, p, o, seed, nfix):
-    """Windows with a narrow row envelope are factored inside LDS (csrc/ba_kernels.hip: ldlt_band_solve); the same windows
-    through the blocked dense path (SLAMIT_BA_NO_BAND=1 in a child process: the switch is read once) and the CPU oracle give
-    the same poses, points, flags and iteration counts.  Half bandwidths from 6 * 3 - 1 = 17 to the whole system."""
+    """Windows with a narrow row envelope are factored inside LDS as a block LDLt with 4 x 4 pivots on the fp64 matrix cores
+    (csrc/ba_kernels.hip: ldlt_band_solve); the same windows through the blocked dense path (SLAMIT_BA_NO_BAND=1 in a child
+    process: the switch is read once) and the CPU oracle give the same poses, points, flags and iteration counts.  Half
+    bandwidths from 6 * 2 - 1 = 11 to 59 (the band path's limit) and to the whole system; system sizes from 18 to 294,
+    multiples of four and ragged (n = 2 mod 4: the last pivot block is half padding)."""
     import json, subprocess, sys, tempfile
     prob = synth.synth_ba(k, p, o, seed=seed, n_fixed=nfix)
     res = opt.LocalBundleAdjustment(prob)

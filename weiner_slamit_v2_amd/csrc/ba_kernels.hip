@@ -763,12 +763,6 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     int rowI = 0, ara = 0, art = BIG, cJt[5], cba[5], cbt[5], cwa[5], cwm[5], csh[5];
 #pragma unroll
     for (int b = 0; b < 5; ++b) { acc[b] = (double4_t){0, 0, 0, 0}; cJt[b] = 0; cba[b] = 0; cbt[b] = BIG; cwa[b] = 0; cwm[b] = 0; csh[b] = 0; }
-#ifdef BA_DIAG_UPD
-    unsigned long long uv[6] = {0, 0, 0, 0, 0, 0};
-#endif
-#ifdef BA_DIAG_PIV
-    unsigned long long pv[4] = {0, 0, 0, 0}, tp = 0;
-#endif
     for (int k = 0; k < n; k += 4) {
         const int par = (k >> 2) & 1;
 #ifdef BA_DIAG_STAMPS
@@ -822,9 +816,6 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
                     for (int g = 0; g < 4; ++g) acc[b][g] = Ab[(m >> g & 1) ? cwa[b] + 4 * g * (RS - 1) : ZA];
                 }
             }
-#ifdef BA_DIAG_UPD
-            unsigned long long tu = __builtin_amdgcn_s_memtime(); uv[0] += tu - tb0;
-#endif
             const int It = __builtin_amdgcn_readfirstlane(rowI);
             if (It <= Ihi) {   // (a block row the update cannot reach yet has nothing to do)
                 const double2_t ga = reinterpret_cast<const double2_t*>(fac + 4 * k)[2 * lk], gb = reinterpret_cast<const double2_t*>(fac + 4 * k)[2 * lk + 1];
@@ -833,18 +824,12 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
                 double bvl[5];
 #pragma unroll
                 for (int b = 0; b < 5; ++b) bvl[b] = Ab[(unsigned)(cbt[b] - k) < (unsigned)bw ? cba[b] + k : ZA];
-#ifdef BA_DIAG_UPD
-                { __builtin_amdgcn_s_waitcnt(0); unsigned long long t = __builtin_amdgcn_s_memtime(); uv[2] += t - tu; tu = t; }
-#endif
 #pragma unroll
                 for (int b = 0; b < 5; ++b) asm volatile("" : "+v"(bvl[b]));   // (keeps every load in this block: sunk into its tile's branch it would be waited for alone)
                 const double av = (r0 * ga.x + r1 * ga.y) + (r2 * gb.x + r3 * gb.y);   // R_r (-G)
 #pragma unroll
                 for (int b = 0; b < 5; ++b)   // the MFMAs back to back (independent accumulators); their consumers follow
                     if (__builtin_amdgcn_readfirstlane(cJt[b]) >= Jlo) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bvl[b], acc[b], 0, 0, 0);   // (block columns behind the pivot are final)
-#ifdef BA_DIAG_UPD
-                { __builtin_amdgcn_s_waitcnt(0); unsigned long long t = __builtin_amdgcn_s_memtime(); uv[3] += t - tu; tu = t; }
-#endif
                 if (k + 4 < n && Jn <= It) {   // the next raw panel: the lanes whose column is one of k + 4 .. k + 7, in the tile of block column Jn
 #pragma unroll
                     for (int b = 0; b < 5; ++b)
@@ -853,9 +838,6 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
                             for (int g = 0; g < 4; ++g) sm[(cwm[b] >> g & 1) ? cwa[b] + 4 * g * (RS - 1) : dump] = acc[b][g];   // entries outside the band: into the dump slots
                         }
                 }
-#ifdef BA_DIAG_UPD
-                { __builtin_amdgcn_s_waitcnt(0); unsigned long long t = __builtin_amdgcn_s_memtime(); uv[4] += t - tu; tu = t; }
-#endif
                 if (It == Jp && k + 8 < n) {   // the pivot block after the next, as it stands now (rows op .. op + 3 of the diagonal tile: register op / 4)
 #pragma unroll
                     for (int b = 0; b < 5; ++b)
@@ -875,35 +857,22 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
 #pragma unroll
                 for (int m = 0; m < 4; ++m) { pi[m] = Pi[m]; pj[m] = Pj[m]; gj[m] = fac[4 * k + 4 * j + m]; }
                 const double eij = s_E[par][4 * max(i, j) + min(i, j)];
-#ifdef BA_DIAG_PIV
-                __builtin_amdgcn_s_waitcnt(0); { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[0] += t - tb0; tp = t; }
-#endif
                 const double qij = (pi[0] * gj[0] + pi[1] * gj[1]) + (pi[2] * gj[2] + pi[3] * gj[3]);   // (P (-G))(i, j)
-                double en = (eij + dpp_xchg_d<0x00>(qij) * pj[0] + dpp_xchg_d<0x55>(qij) * pj[1]) + (dpp_xchg_d<0xAA>(qij) * pj[2] + dpp_xchg_d<0xFF>(qij) * pj[3]);
+                double en = (eij + dpp_quad_d<0x00>(qij) * pj[0] + dpp_quad_d<0x55>(qij) * pj[1]) + (dpp_quad_d<0xAA>(qij) * pj[2] + dpp_quad_d<0xFF>(qij) * pj[3]);
                 if (max(i, j) >= nv) en = i == j ? 1.0 : 0.0;   // a ragged last block: identity padding
                 double e[10], G[16];
                 e[0] = readlane_d(en, 0);
                 e[1] = readlane_d(en, 4); e[2] = readlane_d(en, 5);
                 e[3] = readlane_d(en, 8); e[4] = readlane_d(en, 9); e[5] = readlane_d(en, 10);
                 e[6] = readlane_d(en, 12); e[7] = readlane_d(en, 13); e[8] = readlane_d(en, 14); e[9] = readlane_d(en, 15);
-#ifdef BA_DIAG_PIV
-                { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[1] += t - tp; tp = t; }
-#endif
                 bool bad;
                 ldlt_piv4(e, 4, G, bad);
-#ifdef BA_DIAG_PIV
-                if (G[0] == 1.2345) pv[3] += 1;
-                { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[2] += t - tp; tp = t; }
-#endif
                 if (lane == 0) {
                     double2_t* fo = reinterpret_cast<double2_t*>(fac + 4 * (k + 4));
 #pragma unroll
                     for (int u = 0; u < 8; ++u) fo[u] = (double2_t){G[2 * u], G[2 * u + 1]};
                     if (bad) *s_fail = 1;
                 }
-#ifdef BA_DIAG_PIV
-                __builtin_amdgcn_s_waitcnt(0); { unsigned long long t = __builtin_amdgcn_s_memtime(); pv[3] += t - tp; tp = t; }
-#endif
             }
         } else if (is_rhs) {
             double gy[4];
@@ -941,31 +910,37 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
         double v;
         { const int d = (4 * S4 - 1 - lane) & 63, c = 4 * S4 - 1 - d; v = y[max(c, 0)]; if (c < 0) v = 0.0; }
         const double2_t* gp = reinterpret_cast<const double2_t*>(fac + 4 * lj);
-        double2_t ga = gp[8 * (S4 - 1)], gb = gp[8 * (S4 - 1) + 1];
-        for (int sb = S4 - 1; sb >= 0; --sb) {
+        // everything a block needs from LDS is fetched one block ahead: y of the entering columns, the four band rows, G's row
+        auto fetch = [&](int sb, double& ye, double& r0, double& r1, double& r2, double& r3, double2_t& ga, double2_t& gb, bool& enter) {
             const int k = 4 * sb;
             const int d = (k - 1 - lane) & 63, c = k - 1 - d;
             const bool reach = d <= bw - 1 && c >= 0;
-            const bool enter = d >= bw - 4 && reach;
+            enter = d >= bw - 4 && reach;
             const int ra = reach ? k * (RS - 1) + c + bw + 3 : ZA;   // R(k, c); rows k + 1 .. k + 3 follow at RS - 1 each (rows >= n: zeros)
-            const double ye = y[max(c, 0)];
-            const double r0 = Ab[ra];
-            const double r1 = Ab[(reach && k + 1 < n) ? ra + (RS - 1) : ZA];
-            const double r2 = Ab[(reach && k + 2 < n) ? ra + 2 * (RS - 1) : ZA];
-            const double r3 = Ab[(reach && k + 3 < n) ? ra + 3 * (RS - 1) : ZA];
-            const double2_t na = gp[8 * max(sb - 1, 0)], nb = gp[8 * max(sb - 1, 0) + 1];   // the next block's row of -G
-            const double v0 = dpp_xchg_d<0x00>(v), v1 = dpp_xchg_d<0x55>(v), v2 = dpp_xchg_d<0xAA>(v), v3 = dpp_xchg_d<0xFF>(v);
+            ye = y[max(c, 0)];
+            r0 = Ab[ra];
+            r1 = Ab[(reach && k + 1 < n) ? ra + (RS - 1) : ZA];
+            r2 = Ab[(reach && k + 2 < n) ? ra + 2 * (RS - 1) : ZA];
+            r3 = Ab[(reach && k + 3 < n) ? ra + 3 * (RS - 1) : ZA];
+            ga = gp[8 * sb]; gb = gp[8 * sb + 1];
+        };
+        double ye, r0, r1, r2, r3; double2_t ga, gb; bool enter;
+        fetch(S4 - 1, ye, r0, r1, r2, r3, ga, gb, enter);
+        for (int sb = S4 - 1; sb >= 0; --sb) {
+            const int k = 4 * sb;
+            double nye, nr0, nr1, nr2, nr3; double2_t nga, ngb; bool nenter;
+            fetch(max(sb - 1, 0), nye, nr0, nr1, nr2, nr3, nga, ngb, nenter);
+            const double v0 = dpp_quad_d<0x00>(v), v1 = dpp_quad_d<0x55>(v), v2 = dpp_quad_d<0xAA>(v), v3 = dpp_quad_d<0xFF>(v);
             const double x = -((ga.x * v0 + ga.y * v1) + (gb.x * v2 + gb.y * v3));
             const int q0 = 4 * (sb & 15);
             const double x0 = readlane_dyn_d(x, q0), x1 = readlane_dyn_d(x, q0 + 1), x2 = readlane_dyn_d(x, q0 + 2), x3 = readlane_dyn_d(x, q0 + 3);
-            if ((lane & 60) == q0) y[k + lj] = x;   // (entries behind n of a ragged last block: the zeros of y's tail take zeros)
+            if ((lane & 60) == q0 && k + lj < n) W.rhs[k + lj] = x;   // the solution leaves from here
             if (enter) v = ye;
             v -= (r0 * x0 + r1 * x1) + (r2 * x2 + r3 * x3);
-            ga = na; gb = nb;
+            ye = nye; r0 = nr0; r1 = nr1; r2 = nr2; r3 = nr3; ga = nga; gb = ngb; enter = nenter;
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += LD_THREADS) W.rhs[i] = y[i];
 #ifdef BA_DIAG_STAMPS
     { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[5] += tn - tprev; tprev = tn; }
     if (lane == 0 && is_piv) st->dbg[7] = ph[3];
@@ -973,15 +948,6 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     __syncthreads();
     if (tid == 0) { st->dbg[2] = __builtin_amdgcn_s_memtime(); st->dbg[3] = __builtin_amdgcn_s_memrealtime();
                     st->dbg[4] = (ph[0] << 32) | ph[1]; st->dbg[5] = (ph[2] << 32) | ph[3]; st->dbg[6] |= ph[5]; }
-#ifdef BA_DIAG_UPD
-    __syncthreads();
-    uv[5] = ph[3]; uv[1] = __builtin_amdgcn_s_getreg(6164) /* HW_ID */;
-    if (lane == 0 && uw == BA_DIAG_UPD) { st->dbg[4] = (uv[0] << 32) | uv[1]; st->dbg[5] = (uv[2] << 32) | uv[3]; st->dbg[6] = (uv[4] << 32) | uv[5]; }   // statics / entering / loads / MFMA / panel
-#endif
-#ifdef BA_DIAG_PIV
-    __syncthreads();
-    if (lane == 0 && is_piv) { st->dbg[4] = (pv[0] << 32) | pv[1]; st->dbg[5] = (pv[2] << 32) | pv[3]; }   // pivot wave: reads / E' + gather / factor + inverse / stores
-#endif
 #endif
     if (tid == 0) st->ok2 = 1;
 }

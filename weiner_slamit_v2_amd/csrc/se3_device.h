@@ -94,6 +94,15 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// quad_perm exchange in which every lane has a source (CTRL < 0x100): no zero-initialised "old" operand to set up
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_d(double v) {
+    const int l = __double2loint(v), h = __double2hiint(v);
+    const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // value of lane `l` (wave-uniform, not a constant) as a wave-uniform scalar
 __device__ __forceinline__ double readlane_dyn_d(double v, int l) {
     const int ls = __builtin_amdgcn_readfirstlane(l);
