@@ -390,6 +390,7 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             if (R.edge_stage1_outlier) memcpy(R.edge_stage1_outlier, H.out_out1, (size_t)P.n_edge);
         }
         const BaState& S0 = *H.out_state;
+        if (b == 0 && getenv("SLAMIT_BA_DIAG_WAVES")) fprintf(stderr, "[ba diag] busy cycles of waves 0..7: %llu %llu %llu %llu %llu %llu %llu %llu\n", S0.dbg[0], S0.dbg[1], S0.dbg[2], S0.dbg[3], S0.dbg[4], S0.dbg[5], S0.dbg[6], S0.dbg[7]);
         if (b == 0 && getenv("SLAMIT_BA_DIAG")) {  // diagnostic builds only: in-kernel clock and phases of the last LDLt launch
             fprintf(stderr, "[ba diag] ldlt shader cycles %llu, realtime ticks (100 MHz) %llu -> %.0f MHz, %.1f us\n",
                     S0.dbg[2] - S0.dbg[0], S0.dbg[3] - S0.dbg[1],

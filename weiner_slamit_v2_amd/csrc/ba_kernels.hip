@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <float.h>
 #include <stdint.h>
 
@@ -700,10 +701,11 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     const int n = W.nS, N = W.Npad, bw = W.band, RS = ldlt_band_rs(bw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // roles: waves 0, 1, 2, 4, 5 update (block rows uw mod 5), wave 3 is the pivot wave, wave 7 the right-hand side: with waves dealt
-    // round-robin to the four SIMDs the pivot chain then shares its SIMD only with the rhs wave, not with fp64 MFMAs
+    // roles: waves 0, 1, 2, 4, 5 update block rows (uw mod 5), wave 6 helps them with the window's lower left corner, wave 3 is the
+    // pivot wave, wave 7 the right-hand side: with waves dealt round-robin to the four SIMDs the pivot chain then shares its SIMD
+    // only with the rhs wave, not with fp64 MFMAs
     const int uw = wv < 3 ? wv : (wv == 4 || wv == 5) ? wv - 1 : -1;
-    const bool is_piv = wv == LB_PIV_WAVE, is_rhs = wv == LB_RHS_WAVE;
+    const bool is_piv = wv == LB_PIV_WAVE, is_rhs = wv == LB_RHS_WAVE, is_hlp = wv == 6;
     double* Ab = sm;                          // (n + 1) x RS, the extra row is zero
     double* y = Ab + (size_t)(n + 1) * RS;    // right-hand side -> block forward substitution -> z -> x (zeros behind n)
     double* fac = y + ldlt_band_ylen(n);      // 16 doubles per pivot block: -E^-1 (ldlt_piv4), written one step ahead
@@ -755,99 +757,114 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     __shared__ double s_dump[64];
     const int dump = (int)(s_dump - sm) + lane;   // (a double index relative to sm, like every other offset here)
     const int BIG = 0x40000000;
-    double4_t acc[5];
-    // Wave w < 5 owns the block rows I = w (mod 5): one A operand per step for all its tiles (cell b: block column J = b (mod 5)).
-    // Renewed whenever the pivot enters a new block column: the block row (scalar), the lane's operand addresses at k = 0
-    // (they advance with k), "row - 4" / "column - 4" for the reach test 0 <= x - 4 - k < bw (BIG: never), and where the
-    // lane's four accumulator entries of each tile live in the band (mask: inside the band and the matrix).
-    int rowI = 0, ara = 0, art = BIG, cJt[5], cba[5], cbt[5], cwa[5], cwm[5], csh[5];
+    double4_t acc[3];
+    // Tile (I, J) of tile diagonal d = I - J:  d <= 2 belongs to the ROW wave I mod 5 (cell d; the wave's tiles share one A
+    // operand), d = 3, 4 -- the window's lower left corner, three tiles at a time -- to the HELPER wave (cell 0: d = 4, cells
+    // 1, 2: d = 3 with J even / odd; an A operand per cell).  No update wave has more than three tiles at any step.
+    // Per cell: the tile (scalars), the lane's operand addresses at k = 0 (they advance with k), "row - 4" / "column - 4" for
+    // the reach test 0 <= x - 4 - k < bw (BIG: never), where the lane's four accumulator entries live in the band, which of
+    // them exist (shape of the band x inside the matrix).  A cell whose tile has fallen behind the pivot adopts the next one
+    // of its sequence -- constants on the addresses, the band's shape stays -- and reads it from the band, where nothing has
+    // touched it yet: it comes into reach a step or more later (bw <= 59).
+    int cIt[3], cJt[3], cra[3], crt[3], cba[3], cbt[3], cwa[3], cwm[3], csh[3];
 #pragma unroll
-    for (int b = 0; b < 5; ++b) { acc[b] = (double4_t){0, 0, 0, 0}; cJt[b] = 0; cba[b] = 0; cbt[b] = BIG; cwa[b] = 0; cwm[b] = 0; csh[b] = 0; }
-    for (int k = 0; k < n; k += 4) {
-        const int par = (k >> 2) & 1;
+    for (int c = 0; c < 3; ++c) { acc[c] = (double4_t){0, 0, 0, 0}; cIt[c] = 0; cJt[c] = -1; cra[c] = 0; crt[c] = BIG; cba[c] = 0; cbt[c] = BIG; cwa[c] = 0; cwm[c] = 0; csh[c] = 0; }
+    // Every role runs its own copy of the step loop (same number of barriers): no role dispatch inside a step, and the
+    // update code is compiled once for the row waves and once for the helper.
 #ifdef BA_DIAG_STAMPS
-        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#define LB_STEP_BEGIN const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#define LB_STEP_END { __builtin_amdgcn_s_waitcnt(0); ph[3] += __builtin_amdgcn_s_memtime() - tb0; }   // busy part of the step, per wave
+#else
+#define LB_STEP_BEGIN
+#define LB_STEP_END
 #endif
-        if (uw >= 0) {
+    auto update_step = [&](int k, auto hlp_c) {
+        constexpr bool HLP = decltype(hlp_c)::value;
+        const int par = (k >> 2) & 1;
             const int Jlo = k >> 4;
             const int Ihi = min((k + 3 + bw) >> 4, nb16 - 1);
             const int Jn = (k + 4) >> 4, Jp = (k + 8) >> 4;
             const unsigned jn = (unsigned)(li - ((k + 4) & 15)), jp = (unsigned)(li - ((k + 8) & 15));
             const int op = (k + 8) & 15;
-            if (k == 0 || ((k & 15) == 0 && rowI < Jlo)) {
-                // The wave's block row has left the window (or the solve begins): it adopts the row five further down -- not in
-                // reach for another step or more, so this costs no step anything -- and takes that row's tiles out of the band,
-                // where nothing has touched them yet.  Cell b holds block column J = b (mod 5) of I - 4 .. I.  Behind the first
-                // adoption everything moves by 80 rows and columns: constants on the addresses, the band's shape stays.
-                if (k == 0) {
-                    rowI = uw;
-                    const int Jb = rowI - 4, Jm = ((Jb % 5) + 5) % 5;
-                    const int r0 = 16 * rowI + lk;
-                    ara = (16 * rowI + li) * (RS - 1) + bw + 3;
+            if ((k & 15) == 0) {
 #pragma unroll
-                    for (int b = 0; b < 5; ++b) {
-                        int dj = b - Jm; if (dj < 0) dj += 5;
-                        const int Jt = Jb + dj, c = 16 * Jt + li;
-                        cJt[b] = Jt;
-                        cba[b] = c * (RS - 1) + lk + bw + 3;
-                        cwa[b] = r0 * (RS - 1) + c + bw + 3;
+                for (int c = 0; c < 3; ++c) {
+                    // row wave: all three cells follow the row (I += 5); helper: cell 0 moves by one block, cells 1, 2 by two
+                    const int adv = HLP ? (c == 0 ? 1 : 2) : 5;
+                    const bool gone = HLP ? __builtin_amdgcn_readfirstlane(cJt[c]) < Jlo : __builtin_amdgcn_readfirstlane(cIt[c]) < Jlo;
+                    if (k != 0 && !gone) continue;   // (wave-uniform)
+                    if (k == 0) {
+                        const int It = HLP ? (c == 1 ? 3 : 4) : uw, Jt = HLP ? (c == 2 ? 1 : 0) : uw - c;
+                        const int r0 = 16 * It + lk, cc = 16 * Jt + li;
+                        cIt[c] = It; cJt[c] = Jt;
+                        cra[c] = (16 * It + li) * (RS - 1) + bw + 3;
+                        cba[c] = cc * (RS - 1) + lk + bw + 3;
+                        cwa[c] = r0 * (RS - 1) + cc + bw + 3;
                         int m = 0;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) if ((unsigned)(r0 + 4 * g - c) <= (unsigned)bw) m |= 1 << g;
-                        csh[b] = m;
+                        for (int g = 0; g < 4; ++g) if ((unsigned)(r0 + 4 * g - cc) <= (unsigned)bw) m |= 1 << g;
+                        csh[c] = m;
+                    } else {
+                        cIt[c] += adv; cJt[c] += adv;
+                        cra[c] += 16 * adv * (RS - 1); cba[c] += 16 * adv * (RS - 1); cwa[c] += 16 * adv * RS;
                     }
-                } else {
-                    rowI += 5;
-                    ara += 80 * (RS - 1);
+                    const int r = 16 * cIt[c] + li, r0 = 16 * cIt[c] + lk, cc = 16 * cJt[c] + li;
+                    crt[c] = r < n ? r - 4 : BIG;
+                    const bool cok = cc >= 0 && cc < n;
+                    cbt[c] = cok ? cc - 4 : BIG;
+                    const int nrow = min(max((n - r0 + 3) >> 2, 0), 4);   // rows r0 + 4 g inside the matrix
+                    const int m = cok ? csh[c] & ((1 << nrow) - 1) : 0;
+                    cwm[c] = m;
 #pragma unroll
-                    for (int b = 0; b < 5; ++b) { cJt[b] += 5; cba[b] += 80 * (RS - 1); cwa[b] += 80 * RS; }
-                }
-                const int r = 16 * rowI + li, r0 = 16 * rowI + lk;
-                art = r < n ? r - 4 : BIG;
-                const int nrow = min(max((n - r0 + 3) >> 2, 0), 4), rowm = (1 << nrow) - 1;   // rows r0 + 4 g inside the matrix
-#pragma unroll
-                for (int b = 0; b < 5; ++b) {
-                    const int c = 16 * cJt[b] + li;
-                    const bool cok = c >= 0 && c < n;
-                    cbt[b] = cok ? c - 4 : BIG;
-                    const int m = cok ? csh[b] & rowm : 0;
-                    cwm[b] = m;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[b][g] = Ab[(m >> g & 1) ? cwa[b] + 4 * g * (RS - 1) : ZA];
+                    for (int g = 0; g < 4; ++g) acc[c][g] = Ab[(m >> g & 1) ? cwa[c] + 4 * g * (RS - 1) : ZA];
                 }
             }
-            const int It = __builtin_amdgcn_readfirstlane(rowI);
-            if (It <= Ihi) {   // (a block row the update cannot reach yet has nothing to do)
+            bool act[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const int It = __builtin_amdgcn_readfirstlane(cIt[c]), Jt = __builtin_amdgcn_readfirstlane(cJt[c]); act[c] = Jt >= Jlo && It <= Ihi; }
+            if (act[0] || act[1] || act[2]) {
                 const double2_t ga = reinterpret_cast<const double2_t*>(fac + 4 * k)[2 * lk], gb = reinterpret_cast<const double2_t*>(fac + 4 * k)[2 * lk + 1];
-                const int aa = (unsigned)(art - k) < (unsigned)bw ? ara + k : ZA;
-                const double r0 = Ab[aa], r1 = Ab[aa + 1], r2 = Ab[aa + 2], r3 = Ab[aa + 3];
-                double bvl[5];
+                double bvl[3], av[3];
+                if (HLP) {
+                    double q0[3], q1[3], q2[3], q3[3];
 #pragma unroll
-                for (int b = 0; b < 5; ++b) bvl[b] = Ab[(unsigned)(cbt[b] - k) < (unsigned)bw ? cba[b] + k : ZA];
+                    for (int c = 0; c < 3; ++c) {
+                        const int aa = (act[c] && (unsigned)(crt[c] - k) < (unsigned)bw) ? cra[c] + k : ZA;
+                        q0[c] = Ab[aa]; q1[c] = Ab[aa + 1]; q2[c] = Ab[aa + 2]; q3[c] = Ab[aa + 3];
+                        bvl[c] = Ab[(unsigned)(cbt[c] - k) < (unsigned)bw ? cba[c] + k : ZA];
+                    }
 #pragma unroll
-                for (int b = 0; b < 5; ++b) asm volatile("" : "+v"(bvl[b]));   // (keeps every load in this block: sunk into its tile's branch it would be waited for alone)
-                const double av = (r0 * ga.x + r1 * ga.y) + (r2 * gb.x + r3 * gb.y);   // R_r (-G)
+                    for (int c = 0; c < 3; ++c) av[c] = (q0[c] * ga.x + q1[c] * ga.y) + (q2[c] * gb.x + q3[c] * gb.y);   // R_r (-G)
+                } else {
+                    const int aa = (unsigned)(crt[0] - k) < (unsigned)bw ? cra[0] + k : ZA;
+                    const double q0 = Ab[aa], q1 = Ab[aa + 1], q2 = Ab[aa + 2], q3 = Ab[aa + 3];
 #pragma unroll
-                for (int b = 0; b < 5; ++b)   // the MFMAs back to back (independent accumulators); their consumers follow
-                    if (__builtin_amdgcn_readfirstlane(cJt[b]) >= Jlo) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bvl[b], acc[b], 0, 0, 0);   // (block columns behind the pivot are final)
-                if (k + 4 < n && Jn <= It) {   // the next raw panel: the lanes whose column is one of k + 4 .. k + 7, in the tile of block column Jn
+                    for (int c = 0; c < 3; ++c) bvl[c] = Ab[(unsigned)(cbt[c] - k) < (unsigned)bw ? cba[c] + k : ZA];
+                    av[0] = (q0 * ga.x + q1 * ga.y) + (q2 * gb.x + q3 * gb.y);
+                    av[1] = av[0]; av[2] = av[0];
+                }
 #pragma unroll
-                    for (int b = 0; b < 5; ++b)
-                        if (__builtin_amdgcn_readfirstlane(cJt[b]) == Jn && jn < 4u) {
+                for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(bvl[c]), "+v"(av[c]));   // (keeps every load up here: sunk into its tile's branch it would be waited for alone)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) sm[(cwm[b] >> g & 1) ? cwa[b] + 4 * g * (RS - 1) : dump] = acc[b][g];   // entries outside the band: into the dump slots
+                for (int c = 0; c < 3; ++c)   // the MFMAs back to back (independent accumulators); their consumers follow
+                    if (act[c]) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[c], bvl[c], acc[c], 0, 0, 0);
+                if (k + 4 < n) {   // the next raw panel: the lanes whose column is one of k + 4 .. k + 7, in the tiles of block column Jn
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (act[c] && __builtin_amdgcn_readfirstlane(cJt[c]) == Jn && jn < 4u) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) sm[(cwm[c] >> g & 1) ? cwa[c] + 4 * g * (RS - 1) : dump] = acc[c][g];   // entries outside the band: into the dump slots
                         }
                 }
-                if (It == Jp && k + 8 < n) {   // the pivot block after the next, as it stands now (rows op .. op + 3 of the diagonal tile: register op / 4)
-#pragma unroll
-                    for (int b = 0; b < 5; ++b)
-                        if (__builtin_amdgcn_readfirstlane(cJt[b]) == Jp) {
-                            const double v = op == 0 ? acc[b][0] : op == 4 ? acc[b][1] : op == 8 ? acc[b][2] : acc[b][3];
-                            if (jp < 4u) s_E[par ^ 1][4 * lk + (int)jp] = v;
-                        }
+                // the pivot block after the next, as it stands now (rows op .. op + 3 of the diagonal tile (Jp, Jp): a row wave's cell 0, register op / 4)
+                if (!HLP && k + 8 < n && act[0] && __builtin_amdgcn_readfirstlane(cJt[0]) == Jp) {
+                    const double v = op == 0 ? acc[0][0] : op == 4 ? acc[0][1] : op == 8 ? acc[0][2] : acc[0][3];
+                    if (jp < 4u) s_E[par ^ 1][4 * lk + (int)jp] = v;
                 }
             }
-        } else if (is_piv) {
+    };
+    auto pivot_step = [&](int k) {
+        const int par = (k >> 2) & 1;
             if (k + 4 < n) {
                 const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
                 const int nv = min(4, n - (k + 4));
@@ -874,7 +891,8 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
                     if (bad) *s_fail = 1;
                 }
             }
-        } else if (is_rhs) {
+    };
+    auto rhs_step = [&](int k) {
             double gy[4];
             {
                 const double y0 = y[k], y1 = y[k + 1], y2 = y[k + 2], y3 = y[k + 3];
@@ -887,13 +905,20 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
             const double r0 = Ab[ca], r1 = Ab[ca + 1], r2 = Ab[ca + 2], r3 = Ab[ca + 3];
             const double yc = y[cv ? c : 0];
             if (cv) y[c] = yc + (r0 * gy[0] + r1 * gy[1] + r2 * gy[2] + r3 * gy[3]);   // gy = -G y_k
-        }
-#ifdef BA_DIAG_STAMPS
-        __builtin_amdgcn_s_waitcnt(0);
-        ph[3] += __builtin_amdgcn_s_memtime() - tb0;   // busy part of the step, per wave
-#endif
-        __syncthreads();
+    };
+    if (uw >= 0) {
+        for (int k = 0; k < n; k += 4) { LB_STEP_BEGIN update_step(k, std::false_type{}); LB_STEP_END __syncthreads(); }
+    } else if (is_hlp) {
+        for (int k = 0; k < n; k += 4) { LB_STEP_BEGIN update_step(k, std::true_type{}); LB_STEP_END __syncthreads(); }
+    } else if (is_piv) {
+        for (int k = 0; k < n; k += 4) { LB_STEP_BEGIN pivot_step(k); LB_STEP_END __syncthreads(); }
+    } else if (is_rhs) {
+        for (int k = 0; k < n; k += 4) { LB_STEP_BEGIN rhs_step(k); LB_STEP_END __syncthreads(); }
+    } else {
+        for (int k = 0; k < n; k += 4) __syncthreads();
     }
+#undef LB_STEP_BEGIN
+#undef LB_STEP_END
 #ifdef BA_DIAG_STAMPS
     { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[1] += tn - tprev; tprev = tn; }
 #endif
@@ -948,6 +973,10 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     __syncthreads();
     if (tid == 0) { st->dbg[2] = __builtin_amdgcn_s_memtime(); st->dbg[3] = __builtin_amdgcn_s_memrealtime();
                     st->dbg[4] = (ph[0] << 32) | ph[1]; st->dbg[5] = (ph[2] << 32) | ph[3]; st->dbg[6] |= ph[5]; }
+#endif
+#ifdef BA_DIAG_WAVES
+    __syncthreads();
+    if (lane == 0) st->dbg[wv] = ph[3];   // every wave's busy cycles in the factor loop
 #endif
     if (tid == 0) st->ok2 = 1;
 }
