@@ -169,11 +169,9 @@ __device__ __forceinline__ double row16_sum(double v) {   // all 16 lanes of a D
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_pose_reduce(BaWin* wins) {
-    const BaWin& W = wins[blockIdx.y];
+__device__ __forceinline__ void pose_reduce_body(const BaWin& W, int kf) {
     BaState* st = W.st;
     if (st->done || !st->need_linearize) return;
-    const int kf = blockIdx.x;
     if (kf >= W.n_kf) return;
     const int col = W.pose_col[kf];
     if (col < 0) return;
@@ -216,6 +214,8 @@ __global__ __launch_bounds__(256) void k_pose_reduce(BaWin* wins) {
         if (st->it == 0) atomic_max_bits(&st->maxdiag_bits, m);
     }
 }
+
+__global__ __launch_bounds__(256) void k_pose_reduce(BaWin* wins) { pose_reduce_body(wins[blockIdx.y], blockIdx.x); }
 
 // ---- S4: iteration bookkeeping (one thread per window) -----------------------------------------
 __global__ void k_iter_begin(BaWin* wins) {
@@ -363,16 +363,14 @@ __global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
 // MFMA operand pattern lane -> [row = lane&15][k = lane>>4]).
 #define LDS_PITCH 34
 
-__global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
-    const BaWin& W = wins[blockIdx.z];
+__device__ __forceinline__ void schur_body(const BaWin& W, int tile, int s) {
     if (W.st->done) return;
     const int T = W.Npad / BA_TILE;
-    // blockIdx.x enumerates upper-triangular macro tiles
-    int I = 0, rem = blockIdx.x;
+    // `tile` enumerates upper-triangular macro tiles
+    int I = 0, rem = tile;
     while (I < T && rem >= T - I) { rem -= T - I; ++I; }
     const int J = I + rem;
     if (I >= T) return;
-    const int s = blockIdx.y;
     // Only the k range in which BOTH row tiles have non-zeros is multiplied (points are sorted by their first observing
     // keyframe, ba_api.hip): its slabs of BA_KC are dealt to the BA_SPLITS splits; a split without a slab stores zeros.
     const int klo = max(W.tile_alo[I], W.tile_blo[J]), khi = min(W.tile_ahi[I], W.tile_bhi[J]);
@@ -434,6 +432,16 @@ __global__ __launch_bounds__(256) void k_schur(BaWin* wins) {
             const int col = J * BA_TILE + 16 * j + (lane & 15);
             P[(size_t)row * W.Npad + col] = acc[j][r];
         }
+}
+
+__global__ __launch_bounds__(256) void k_schur(BaWin* wins) { schur_body(wins[blockIdx.z], blockIdx.x, blockIdx.y); }
+
+// Both in one launch for the slots after a stage's first (neither needs the other; k_schur_reduce needs both): the pose blocks ride
+// as extra workgroups behind the Schur tiles -- keyframe (x - ntiles) * BA_SPLITS + y.
+__global__ __launch_bounds__(256) void k_schur_pose(BaWin* wins, int ntiles) {
+    const BaWin& W = wins[blockIdx.z];
+    if ((int)blockIdx.x < ntiles) schur_body(W, blockIdx.x, blockIdx.y);
+    else pose_reduce_body(W, ((int)blockIdx.x - ntiles) * BA_SPLITS + (int)blockIdx.y);
 }
 
 // ---- S7: S = Hpp + lambda*I - sum_s part[s],  b_s = bp - coeff --------------------------------------
@@ -1483,7 +1491,8 @@ void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int st
 
 // one LM trial slot for every window of the batch
 // (`first`: the first slot of a stage, whose lambda comes out of the reductions; every later slot runs them and the
-// damping in one launch and leaves the iteration bookkeeping to k_ldlt_solve: 8 launches instead of 11)
+// damping in one launch, the pose blocks ride with the Schur product, and the iteration bookkeeping is left to k_ldlt_solve: 7 launches
+// instead of 11)
 void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first) {
     const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt * BA_PG + 255) / 256, nwin);
     if (first) {
@@ -1494,10 +1503,10 @@ void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int
         hipLaunchKernelGGL(k_prepare, gp, dim3(256), 0, st, wins);
     } else {
         hipLaunchKernelGGL(k_point_pass, gp, dim3(256), 0, st, wins);
-        hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(256), 0, st, wins);
     }
-    const int T = Npad / BA_TILE;
-    hipLaunchKernelGGL(k_schur, dim3(T * (T + 1) / 2, BA_SPLITS, nwin), dim3(256), 0, st, wins);
+    const int T = Npad / BA_TILE, ntiles = T * (T + 1) / 2;
+    if (first) hipLaunchKernelGGL(k_schur, dim3(ntiles, BA_SPLITS, nwin), dim3(256), 0, st, wins);
+    else hipLaunchKernelGGL(k_schur_pose, dim3(ntiles + (max_kf + BA_SPLITS - 1) / BA_SPLITS, BA_SPLITS, nwin), dim3(256), 0, st, wins, ntiles);
     hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_ldlt_solve, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);
     const int nb = (max_pt * BA_PG > max_kf ? max_pt * BA_PG : max_kf);
