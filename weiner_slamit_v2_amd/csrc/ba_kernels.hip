@@ -836,13 +836,15 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
                 if (HLP) {
                     double q0[3], q1[3], q2[3], q3[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int aa = (act[c] && (unsigned)(crt[c] - k) < (unsigned)bw) ? cra[c] + k : ZA;
+                    for (int c = 0; c < 3; ++c) {   // (only the cells in the window: one of three when bw < 49)
+                        q0[c] = 0; q1[c] = 0; q2[c] = 0; q3[c] = 0; bvl[c] = 0;
+                        if (!act[c]) continue;
+                        const int aa = (unsigned)(crt[c] - k) < (unsigned)bw ? cra[c] + k : ZA;
                         q0[c] = Ab[aa]; q1[c] = Ab[aa + 1]; q2[c] = Ab[aa + 2]; q3[c] = Ab[aa + 3];
                         bvl[c] = Ab[(unsigned)(cbt[c] - k) < (unsigned)bw ? cba[c] + k : ZA];
                     }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) av[c] = (q0[c] * ga.x + q1[c] * ga.y) + (q2[c] * gb.x + q3[c] * gb.y);   // R_r (-G)
+                    for (int c = 0; c < 3; ++c) { asm volatile("" : "+v"(q0[c]), "+v"(q2[c])); av[c] = 0; if (act[c]) av[c] = (q0[c] * ga.x + q1[c] * ga.y) + (q2[c] * gb.x + q3[c] * gb.y); }   // R_r (-G)
                 } else {
                     const int aa = (unsigned)(crt[0] - k) < (unsigned)bw ? cra[0] + k : ZA;
                     const double q0 = Ab[aa], q1 = Ab[aa + 1], q2 = Ab[aa + 2], q3 = Ab[aa + 3];
