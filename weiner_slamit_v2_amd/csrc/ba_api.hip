@@ -108,7 +108,7 @@ size_t carve_work(uint8_t* base, BaWin& w, int max_kf, int max_pt, int max_edge,
     w.Hpp = c.take<double>(36 * (size_t)max_kf); w.bp = c.take<double>(6 * (size_t)max_kf + 8);
     w.GA = c.take<double>((size_t)Npad * Kpad); w.GB = c.take<double>((size_t)Npad * Kpad);
     w.part = c.take<double>((size_t)BA_SPLITS * Npad * Npad);
-    w.S = c.take<double>((size_t)Npad * Npad); w.rhs = c.take<double>(Npad);
+    w.S = c.take<double>((size_t)Npad * Npad); w.Sb = c.take<double>(((size_t)Npad + 1) * 64); w.rhs = c.take<double>(Npad);
     w.x_l = c.take<double>(3 * (size_t)max_pt);
     w.chi_part = c.take<double>(n_part); w.scale_part = c.take<double>(n_part);
     return rup(c.off, 4096);

@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void k_schur_pose(BaWin* wins, int ntiles) {
     else pose_reduce_body(W, ((int)blockIdx.x - ntiles) * BA_SPLITS + (int)blockIdx.y);
 }
 
+__host__ __device__ inline int ldlt_band_rs(int bw);
+__host__ __device__ inline bool ldlt_band_ok(int n, int bw);
+
 // ---- S7: S = Hpp + lambda*I - sum_s part[s],  b_s = bp - coeff --------------------------------------
 __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
@@ -467,6 +470,9 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins) {
     const double sv = hv - v;
     W.S[(size_t)r * N + c] = sv;
     W.S[(size_t)c * N + r] = sv;
+    // a banded window's solve reads its LDS image instead: entry (row c, column r) of the lower band (ldlt_band_solve's layout)
+    const int bw = W.band;
+    if (ldlt_band_ok(n, bw) && c - r <= bw) W.Sb[(size_t)c * ldlt_band_rs(bw) + (r - c + bw + 3)] = sv;
 }
 
 // ---- S8: dense blocked LDLt (no pivoting) of the reduced system + solve, one workgroup -------------
@@ -722,16 +728,18 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
     if (tid == 0) { st->dbg[0] = tprev; st->dbg[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-    const gdouble* S = (const gdouble*)W.S;
-    for (int i0 = tid; i0 < (n + 1) * RS; i0 += 8 * LD_THREADS) {   // eight loads in flight per thread
-        double v[8];
+    {   // the band arrives in its LDS layout (k_schur_reduce wrote it that way): a straight copy, 16 bytes per lane and load
+        typedef __attribute__((address_space(1))) double2_t gdouble2;
+        const gdouble2* src = (const gdouble2*)W.Sb;
+        double2_t* dst = reinterpret_cast<double2_t*>(Ab);
+        const int cnt = ((n + 1) * RS) >> 1;   // RS is even
+        for (int i0 = tid; i0 < cnt; i0 += 9 * LD_THREADS) {
+            double2_t v[9];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * LD_THREADS, r = i / RS, j = i - r * RS, c = r - bw - 3 + j;
-            v[u] = (i < (n + 1) * RS && r < n && j >= 3 && j <= bw + 3 && c >= 0) ? S[(size_t)r * N + c] : 0.0;
+            for (int u = 0; u < 9; ++u) { const int i = i0 + u * LD_THREADS; v[u] = i < cnt ? src[i] : (double2_t){0, 0}; }
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { const int i = i0 + u * LD_THREADS; if (i < cnt) dst[i] = v[u]; }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * LD_THREADS; if (i < (n + 1) * RS) Ab[i] = v[u]; }
     }
     for (int i = tid; i < ldlt_band_ylen(n); i += LD_THREADS) y[i] = i < n ? W.rhs[i] : 0.0;
     __syncthreads();
@@ -1457,6 +1465,8 @@ __global__ __launch_bounds__(256) void k_import(BaWin* wins, const BaIo* io) {
     if (k < W.n_edge) { W.e_active[k] = 1; W.e_out1[k] = 0; W.e_chi2[k] = 0.0; }
     if (k < 3 * W.n_pt) W.pt[k] = I.in_pt[k];
     if (k < (int)(sizeof(BaState) / 8)) reinterpret_cast<unsigned long long*>(W.st)[k] = 0ull;
+    if (ldlt_band_ok(W.nS, W.band))   // the zeros of the band image (pad slots, the part of a row left of column 0, the extra row)
+        for (int i = k; i < (W.nS + 1) * ldlt_band_rs(W.band); i += gridDim.x * 256) W.Sb[i] = 0.0;
     if (k >= W.n_kf) return;
     const double* p = I.in_pose + 12 * (size_t)k;
     double R[9], q[4];

@@ -89,6 +89,8 @@ struct BaWin {
     BA_G double* GB;        // Npad x Kpad : Hpl scattered; row nS holds bl
     BA_G double* part;      // BA_SPLITS x Npad x Npad partial products
     BA_G double* S;         // Npad x Npad reduced system (symmetric, full)
+    BA_G double* Sb;        // (Npad + 1) x 64: the same system as the banded solve's LDS image (rows of ldlt_band_rs(band) doubles; k_schur_reduce
+                            // writes the in-band entries, the zeros around them are laid once per solve by k_import)
     BA_G double* rhs;       // Npad : b_schur in, x_pose out
     BA_G double* x_l;       // n_pt x 3 landmark increments
     BA_G double* chi_part;  // n_part partial robust-cost sums
