@@ -953,34 +953,52 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
         double v;
         { const int d = (4 * S4 - 1 - lane) & 63, c = 4 * S4 - 1 - d; v = y[max(c, 0)]; if (c < 0) v = 0.0; }
         const double2_t* gp = reinterpret_cast<const double2_t*>(fac + 4 * lj);
-        // everything a block needs from LDS is fetched one block ahead: y of the entering columns, the four band rows, G's row
-        auto fetch = [&](int sb, double& ye, double& r0, double& r1, double& r2, double& r3, double2_t& ga, double2_t& gb, bool& enter) {
-            const int k = 4 * sb;
-            const int d = (k - 1 - lane) & 63, c = k - 1 - d;
-            const bool reach = d <= bw - 1 && c >= 0;
-            enter = d >= bw - 4 && reach;
-            const int ra = reach ? k * (RS - 1) + c + bw + 3 : ZA;   // R(k, c); rows k + 1 .. k + 3 follow at RS - 1 each (rows >= n: zeros)
-            ye = y[max(c, 0)];
-            r0 = Ab[ra];
-            r1 = Ab[(reach && k + 1 < n) ? ra + (RS - 1) : ZA];
-            r2 = Ab[(reach && k + 2 < n) ? ra + 2 * (RS - 1) : ZA];
-            r3 = Ab[(reach && k + 3 < n) ? ra + 3 * (RS - 1) : ZA];
-            ga = gp[8 * sb]; gb = gp[8 * sb + 1];
+        // Everything a block needs from LDS is fetched one block ahead (y of the entering columns, the four band rows, G's row),
+        // into two sets of registers used alternately.  The lane's column, its distance to the block and the address of its
+        // entry in the block's first row move by constants from block to block: the column stays (d -= 4) until it becomes
+        // part of the block itself, then the lane takes the column 64 below (d += 60).
+        struct Ops { double ye, r0, r1, r2, r3; double2_t ga, gb; bool enter; };
+        int fd, fc, fra;
+        { const int k = 4 * (S4 - 1); fd = (k - 1 - lane) & 63; fc = k - 1 - fd; fra = k * (RS - 1) + fc + bw + 3; }
+        auto fetch = [&](Ops& O, int sb, bool ragged) {
+            const bool reach = fd <= bw - 1 && fc >= 0;
+            O.enter = fd >= bw - 4 && reach;
+            const int a0 = reach ? fra : ZA, st = reach ? RS - 1 : 0;   // R(k, c); rows k + 1 .. k + 3 follow at RS - 1 each
+            O.ye = y[max(fc, 0)];
+            O.r0 = Ab[a0];
+            if (!ragged) { O.r1 = Ab[a0 + st]; O.r2 = Ab[a0 + 2 * st]; O.r3 = Ab[a0 + 3 * st]; }
+            else {   // the last pivot block of a system whose size is no multiple of four: rows >= n read zeros
+                const int k = 4 * sb;
+                O.r1 = Ab[k + 1 < n ? a0 + st : ZA]; O.r2 = Ab[k + 2 < n ? a0 + 2 * st : ZA]; O.r3 = Ab[k + 3 < n ? a0 + 3 * st : ZA];
+            }
+            O.ga = gp[8 * sb]; O.gb = gp[8 * sb + 1];
         };
-        double ye, r0, r1, r2, r3; double2_t ga, gb; bool enter;
-        fetch(S4 - 1, ye, r0, r1, r2, r3, ga, gb, enter);
-        for (int sb = S4 - 1; sb >= 0; --sb) {
+        auto advance = [&]() {
+            const bool wrap = fd < 4;
+            fd = wrap ? fd + 60 : fd - 4;
+            fc = wrap ? fc - 64 : fc;
+            fra -= 4 * (RS - 1) + (wrap ? 64 : 0);
+        };
+        auto step = [&](const Ops& O, int sb) {
             const int k = 4 * sb;
-            double nye, nr0, nr1, nr2, nr3; double2_t nga, ngb; bool nenter;
-            fetch(max(sb - 1, 0), nye, nr0, nr1, nr2, nr3, nga, ngb, nenter);
             const double v0 = dpp_quad_d<0x00>(v), v1 = dpp_quad_d<0x55>(v), v2 = dpp_quad_d<0xAA>(v), v3 = dpp_quad_d<0xFF>(v);
-            const double x = -((ga.x * v0 + ga.y * v1) + (gb.x * v2 + gb.y * v3));
+            const double x = -((O.ga.x * v0 + O.ga.y * v1) + (O.gb.x * v2 + O.gb.y * v3));
             const int q0 = 4 * (sb & 15);
             const double x0 = readlane_dyn_d(x, q0), x1 = readlane_dyn_d(x, q0 + 1), x2 = readlane_dyn_d(x, q0 + 2), x3 = readlane_dyn_d(x, q0 + 3);
             if ((lane & 60) == q0 && k + lj < n) W.rhs[k + lj] = x;   // the solution leaves from here
-            if (enter) v = ye;
-            v -= (r0 * x0 + r1 * x1) + (r2 * x2 + r3 * x3);
-            ye = nye; r0 = nr0; r1 = nr1; r2 = nr2; r3 = nr3; ga = nga; gb = ngb; enter = nenter;
+            if (O.enter) v = O.ye;
+            v -= (O.r0 * x0 + O.r1 * x1) + (O.r2 * x2 + O.r3 * x3);
+        };
+        Ops A, B;
+        int sb = S4 - 1;
+        fetch(A, sb, true);
+        while (true) {
+            if (sb > 0) { advance(); fetch(B, sb - 1, false); }
+            step(A, sb);
+            if (--sb < 0) break;
+            if (sb > 0) { advance(); fetch(A, sb - 1, false); }
+            step(B, sb);
+            if (--sb < 0) break;
         }
     }
     __syncthreads();
