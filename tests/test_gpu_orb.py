@@ -105,6 +105,26 @@ def test_odd_geometries(w, h, nf, nl, sf):
     _check_frame(ext, orc, synth.synth_frame(w, h, 11), "%dx%d" % (w, h))
 
 
+def test_pyramid_through_the_four_pixel_resize_kernel():
+    """The pyramid levels come from resize_rows8_kernel (eight dst pixels per lane) wherever a level's taps fit its 16-byte
+    windows -- every level at scale factor 1.2 -- and from resize_rows4_kernel otherwise (e.g. scale factor 1.5 above);
+    SLAMIT_RESIZE_NO8=1 (read once, hence the child process) sends every level through the four-pixel kernel: same bytes."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from oracle import bindings as ob\n"
+            "from weiner_slamit_v2_amd import api, synth\n"
+            "for (w, h, nf) in ((640, 480, 1000), (1280, 720, 2000), (317, 251, 500)):\n"
+            "    ext, orc = api.ORBextractor(nf, 1.2, 8, 20, 7), ob.OrbOracle(nf)\n"
+            "    img = synth.synth_frame(w, h, 3)\n"
+            "    kg, dg = ext(img); ko, do = orc.extract(img)\n"
+            "    assert all(np.array_equal(ext.level(0, l), orc.level(l)) for l in range(8)), (w, h)\n"
+            "    assert np.array_equal(dg, do) and len(kg) == len(ko)\n"
+            "print('same bytes')\n" % root)
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, SLAMIT_RESIZE_NO8="1"), cwd=root, timeout=300)
+    assert b"same bytes" in out
+
+
 def test_thresholds_other_than_default():
     ext, orc = api.ORBextractor(800, 1.2, 6, 35, 12), ob.OrbOracle(800, 1.2, 6, 35, 12)
     _check_frame(ext, orc, synth.synth_frame(640, 480, 13), "th35/12")

@@ -25,6 +25,9 @@ bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const s
                         const short* ibeta, std::vector<uint32_t>& col, std::vector<uint32_t>& row);
 void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, int sh, uint8_t* dst, int dw, int dh,
                        size_t dstride, size_t dframe, const uint32_t* d_col, const uint32_t* d_row, int nframes);
+bool orbk_resize_tables8(int dw, int sw, size_t dstride, const int* xofs, const short* ialpha, std::vector<uint32_t>& col);
+void orbk_resize_rows8(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, int sh, uint8_t* dst, int dw, int dh,
+                       size_t dstride, size_t dframe, const uint32_t* d_col8, const uint32_t* d_row, int nframes);
 hipError_t orbk_pyramid_prepare(int smem_bytes);
 void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const PyrBox* boxes, const PyrTabs* tabs,
                   int nregions, const uint8_t* img0, size_t img0_stride, size_t img0_frame, uint8_t* pyr, int bufA_bytes,
@@ -134,6 +137,7 @@ struct slamit_orb {
     short* d_tab_s[ORB_MAX_LEVELS][2];    // ialpha, ibeta
     uint32_t* d_rs_col[ORB_MAX_LEVELS];   // resize_rows4_kernel tables (orbk_resize_tables)
     uint32_t* d_rs_row[ORB_MAX_LEVELS];
+    uint32_t* d_rs_col8[ORB_MAX_LEVELS];  // resize_rows8_kernel column tables; null where the level's geometry does not fit it
     int pyr_mode;                         // 0 per-level rows4 (default), 1 fused segments (SLAMIT_PYR_FUSED)
     PyrBox* d_boxes;                      // fused pyramid: [nregions][nlevels]
     PyrTabs* d_tabs;                      // [nlevels]
@@ -167,7 +171,7 @@ static void orb_free(slamit_orb* h) {
     hipFree(h->d_out_desc); hipFree(h->d_out_n); if (h->h_out) hipHostFree(h->h_out); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
-    for (int l = 0; l < ORB_MAX_LEVELS; ++l) { hipFree(h->d_rs_col[l]); hipFree(h->d_rs_row[l]); }
+    for (int l = 0; l < ORB_MAX_LEVELS; ++l) { hipFree(h->d_rs_col[l]); hipFree(h->d_rs_row[l]); hipFree(h->d_rs_col8[l]); }
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
     if (h->ev_pyr) hipEventDestroy(h->ev_pyr);
     if (h->ev_mid) hipEventDestroy(h->ev_mid);
@@ -350,6 +354,12 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         ALLOC(h->d_rs_col[l], ct.size() * 4); ALLOC(h->d_rs_row[l], rt.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(h->d_rs_col[l], ct.data(), ct.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(h->d_rs_row[l], rt.data(), rt.size() * 4, hipMemcpyHostToDevice);
+        static const bool no_rows8 = getenv("SLAMIT_RESIZE_NO8") && atoi(getenv("SLAMIT_RESIZE_NO8"));   // A/B runs: the four-pixel kernel everywhere
+        std::vector<uint32_t> c8;
+        if (!no_rows8 && orbk_resize_tables8(h->levels[l].w, h->levels[l - 1].w, (size_t)h->levels[l].stride, xo.data(), xa.data(), c8)) {
+            ALLOC(h->d_rs_col8[l], c8.size() * 4);
+            if (e == hipSuccess) e = hipMemcpy(h->d_rs_col8[l], c8.data(), c8.size() * 4, hipMemcpyHostToDevice);
+        }
     }
     // ---- fused pyramid: the levels are built in SEGMENTS (default: 0 -> 1,2 | 2 -> 3,4 | 4 -> 5..): one launch
     // per segment, each workgroup reads its patch of the segment's first level and produces the following levels
@@ -528,8 +538,12 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
             const OrbLevel& S = h->levels[l - 1];
             const OrbLevel& D = h->levels[l];
             const uint8_t* src = l == 1 ? d_gray : h->d_pyr + S.plane_off;
-            orbk_resize_rows4(st, src, l == 1 ? stride : (size_t)S.stride, l == 1 ? frame_stride : h->pyr_frame_total, S.h,
-                              h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride, h->pyr_frame_total, h->d_rs_col[l], h->d_rs_row[l], nframes);
+            if (h->d_rs_col8[l])
+                orbk_resize_rows8(st, src, l == 1 ? stride : (size_t)S.stride, l == 1 ? frame_stride : h->pyr_frame_total, S.h,
+                                  h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride, h->pyr_frame_total, h->d_rs_col8[l], h->d_rs_row[l], nframes);
+            else
+                orbk_resize_rows4(st, src, l == 1 ? stride : (size_t)S.stride, l == 1 ? frame_stride : h->pyr_frame_total, S.h,
+                                  h->d_pyr + D.plane_off, D.w, D.h, (size_t)D.stride, h->pyr_frame_total, h->d_rs_col[l], h->d_rs_row[l], nframes);
             if (early_blur && l == h->blur_split) {
                 // the blur of the big levels 0 .. l (most of its bytes) runs on the side stream beside the rest of the chain:
                 // the small levels are a few microseconds of work behind a kernel boundary each and leave the chip idle

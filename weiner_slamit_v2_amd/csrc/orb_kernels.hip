@@ -151,6 +151,80 @@ __global__ __launch_bounds__(256) void resize_rows4_kernel(
                 ngroups, inv_groups, dh);
 }
 
+// The same pass with EIGHT adjacent dst pixels per lane and row: at the pyramid's scale factors (<= ~1.3) their sixteen taps lie
+// inside one 16-byte source window, so a source row costs ONE 16-byte buffer load per eight pixels instead of one 12-byte
+// load per four, and a dst row one 8-byte store -- the kernel waits on vector-memory ISSUE, not on bytes.  After the
+// per-lane byte shift the taps of pixels 0 .. 3 lie in dwords (a0, a1) and those of pixels 4 .. 7 in (a1, a2): static
+// register pairs (orbk_resize_tables8 checks it and refuses other geometries, which keep the four-pixel kernel).
+// Column group (5 x uint4): byte offset of the window | shift << 16 ; 8 x v_perm selector ; 8 x (ialpha0 | ialpha1 << 16).
+typedef unsigned rs_u4 __attribute__((ext_vector_type(4)));
+template <int RP>
+__device__ __forceinline__ void rs_item8(const int item, const uint8_t* S, const unsigned ss, const unsigned sbytes, uint8_t* D, const unsigned dstride,
+                                         const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, const int ngroups,
+                                         const unsigned inv_groups, const int dh) {
+    const int yq = (int)__umulhi((unsigned)item, inv_groups);
+    const int g = item - yq * ngroups;
+    const uint8_t* ct = reinterpret_cast<const uint8_t*>(coltab) + 80u * (unsigned)g;
+    const uint4 c0 = *reinterpret_cast<const uint4*>(ct), c1 = *reinterpret_cast<const uint4*>(ct + 16u), c2 = *reinterpret_cast<const uint4*>(ct + 32u),
+                c3 = *reinterpret_cast<const uint4*>(ct + 48u);
+    const uint32_t c4x = *reinterpret_cast<const uint32_t*>(ct + 64u);
+    int yrow[2 * RP];
+    uint2 rt[2 * RP];
+    {
+        const uint4* rp4 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(rowtab) + 16u * (unsigned)(RP * yq));
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+            const uint4 v = rp4[r];
+            rt[2 * r] = make_uint2(v.x, v.y); rt[2 * r + 1] = make_uint2(v.z, v.w);
+        }
+#pragma unroll
+        for (int r = 0; r < 2 * RP; ++r) yrow[r] = min(2 * RP * yq + r, dh - 1);
+    }
+    const unsigned b = c0.x & 0xFFFFu, sh = (c0.x >> 16) & 3u;
+    const uint32_t sel[8] = {c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x}, al[8] = {c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, c4x};
+    uint32_t w[4 * RP][4];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(S), 0, sbytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 4 * RP; ++r) {
+        const unsigned srow = (r & 1) ? (rt[r >> 1].x >> 16) : (rt[r >> 1].x & 0xFFFFu);
+        const unsigned ro = __umul24(srow, ss) + b;
+        const rs_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)ro, 0, 0);
+        w[r][0] = v.x; w[r][1] = v.y; w[r][2] = v.z; w[r][3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * RP; ++k) {
+        uint32_t h[2][8];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t* ww = w[2 * k + r];
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(ww[1], ww[0], sh), a1 = __builtin_amdgcn_alignbyte(ww[2], ww[1], sh), a2 = __builtin_amdgcn_alignbyte(ww[3], ww[2], sh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[r][j] = rs_dot2(__builtin_amdgcn_perm(a1, a0, sel[j]), al[j]) >> 4;
+#pragma unroll
+            for (int j = 4; j < 8; ++j) h[r][j] = rs_dot2(__builtin_amdgcn_perm(a2, a1, sel[j]), al[j]) >> 4;
+        }
+        const unsigned b0 = rt[k].y & 0xFFFFu, b1 = rt[k].y >> 16;
+        uint32_t out[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t v = ((__umul24(b0, h[0][j]) >> 16) + (__umul24(b1, h[1][j]) >> 16) + 2u) >> 2;
+            out[j >> 2] |= (v & 0xFFu) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint2*>(D + (__umul24((unsigned)yrow[k], dstride) + 8u * (unsigned)g)) = make_uint2(out[0], out[1]);
+    }
+}
+
+template <int RP>
+__global__ __launch_bounds__(256) void resize_rows8_kernel(
+    const uint8_t* __restrict__ src, size_t sstride, size_t sframe,
+    uint8_t* __restrict__ dst, size_t dstride, size_t dframe,
+    const uint4* __restrict__ coltab, const uint2* __restrict__ rowtab, int ngroups, unsigned inv_groups, int nitems, int dh, unsigned sbytes) {
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= nitems) return;
+    rs_item8<RP>(item, src + (size_t)blockIdx.y * sframe, (unsigned)sstride, sbytes, dst + (size_t)blockIdx.y * dframe, (unsigned)dstride, coltab, rowtab,
+                 ngroups, inv_groups, dh);
+}
+
 // Host: tables of resize_rows4_kernel for one level from the reference-shaped xofs/ialpha/yofs/ibeta tables.
 // Coefficients are non-negative (bilinear) and <= 2048, rows/columns < 65536 (checked by the caller).
 // Returns false when the geometry does not fit the kernel (scale factor > 2.3: taps of one group further than
@@ -190,6 +264,51 @@ bool orbk_resize_tables(int dw, int dh, int sw, int sh, const int* xofs, const s
     for (int y = dh; y < dh + 7; ++y) { row[2 * (size_t)y] = row[2 * (size_t)(dh - 1)]; row[2 * (size_t)y + 1] = row[2 * (size_t)(dh - 1) + 1]; }
     for (int x = 0; x < dw; ++x) if (ialpha[2 * x] < 0 || ialpha[2 * x + 1] < 0) return false;
     return true;
+}
+
+// Column table of resize_rows8_kernel (the row table is orbk_resize_tables'); false when some group's taps do not lie as
+// the kernel assumes -- pixels 0 .. 3 within bytes 0 .. 7 of the window that starts at the group's first left tap, pixels
+// 4 .. 7 within bytes 4 .. 11 -- or the 8-byte stores of the last group would pass the row pitch.
+bool orbk_resize_tables8(int dw, int sw, size_t dstride, const int* xofs, const short* ialpha, std::vector<uint32_t>& col) {
+    const int ng = (dw + 7) / 8;
+    if (sw >= 65536 || (size_t)ng * 8 > dstride) return false;
+    col.assign((size_t)ng * 20, 0u);
+    for (int g = 0; g < ng; ++g) {
+        int L[8], R[8];
+        uint32_t a[8];
+        const int L0 = xofs[8 * g];
+        for (int j = 0; j < 8; ++j) {
+            const int x = 8 * g + j;
+            if (x < dw) {
+                L[j] = xofs[x]; R[j] = std::min(xofs[x] + 1, sw - 1);
+                if (ialpha[2 * x] < 0 || ialpha[2 * x + 1] < 0) return false;
+                a[j] = (uint32_t)(unsigned short)ialpha[2 * x] | ((uint32_t)(unsigned short)ialpha[2 * x + 1] << 16);
+            } else { L[j] = R[j] = L0 + (j >= 4 ? 4 : 0); a[j] = 0; }   // padding pixels of the last group: written as 0
+        }
+        uint32_t* c = &col[(size_t)g * 20];
+        c[0] = (uint32_t)(L0 & ~3) | ((uint32_t)(L0 & 3) << 16);
+        for (int j = 0; j < 8; ++j) {
+            const int lo = j >= 4 ? 4 : 0;   // byte index inside the dword pair the pixel reads
+            const int bl = L[j] - L0 - lo, br = R[j] - L0 - lo;
+            if (bl < 0 || bl > 7 || br < 0 || br > 7) return false;
+            c[1 + j] = (uint32_t)bl | 0x0C00u | ((uint32_t)br << 16) | 0x0C000000u;
+            c[9 + j] = a[j];
+        }
+    }
+    return true;
+}
+
+void orbk_resize_rows8(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, int sh, uint8_t* dst, int dw, int dh,
+                       size_t dstride, size_t dframe, const uint32_t* d_col8, const uint32_t* d_row, int nframes) {
+    static const int rp_env = getenv("SLAMIT_RESIZE8_RP") ? atoi(getenv("SLAMIT_RESIZE8_RP")) : 0;
+    const int rp = rp_env == 1 || rp_env == 2 || rp_env == 4 ? rp_env : 2;
+    const int ng = (dw + 7) / 8, nitems = ng * ((dh + 2 * rp - 1) / (2 * rp));
+    const unsigned inv = (unsigned)((0x100000000ull + (unsigned)ng - 1) / (unsigned)ng);
+    const dim3 grid((nitems + 255) / 256, nframes);
+#define RS_LAUNCH8(RP) hipLaunchKernelGGL(resize_rows8_kernel<RP>, grid, dim3(256), 0, st, src, sstride, sframe, dst, dstride, dframe, \
+                                           reinterpret_cast<const uint4*>(d_col8), reinterpret_cast<const uint2*>(d_row), ng, inv, nitems, dh, (unsigned)(sstride * (size_t)sh))
+    if (rp == 1) RS_LAUNCH8(1); else if (rp == 2) RS_LAUNCH8(2); else RS_LAUNCH8(4);
+#undef RS_LAUNCH8
 }
 
 void orbk_resize_rows4(hipStream_t st, const uint8_t* src, size_t sstride, size_t sframe, int sh, uint8_t* dst, int dw, int dh,
