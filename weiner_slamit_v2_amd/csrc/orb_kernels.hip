@@ -1270,7 +1270,7 @@ static DiscTable make_disc() {
     return t;
 }
 
-#define IC_KP_PER_WAVE 4
+#define IC_KP_PER_WAVE 8
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
@@ -1322,20 +1322,39 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
 #pragma unroll
         for (int j = 0; j < 12; ++j) val[k][j] = center[off[j]];
     }
-    int my10 = 0, my01 = 0;
+    // The 2 x IC_KP_PER_WAVE = 16 moments are summed over the wave TOGETHER (integers: any order is exact): a butterfly over lane
+    // bits 0 .. 3 that halves the number of values at every stage (a lane keeps the value its bit selects and takes the
+    // partner lane's partial of it), so a lane ends with the 16-lane-row partial of moment number lane & 15; the four rows meet
+    // in LDS.  71 vector operations instead of 16 x 12 for sixteen separate wave sums.
+    int V[2 * IC_KP_PER_WAVE];
 #pragma unroll
     for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
         int m10 = 0, m01 = 0;
 #pragma unroll
         for (int j = 0; j < 12; ++j) { m10 += __mul24(wu[j], val[k][j]); m01 += __mul24(wv[j], val[k][j]); }
-        m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);   // DPP row sums + v_readlane (integer: any order is exact)
-        if (lane == k) { my10 = m10; my01 = m01; }
+        V[2 * k] = m10; V[2 * k + 1] = m01;
     }
-    if (lane < IC_KP_PER_WAVE && i0 + lane < count) {
+    {
+        const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { const int a = V[2 * p], b = V[2 * p + 1]; V[p] = (b0 ? b : a) + dpp_i32<0xB1>(b0 ? a : b); }            // partner lane ^ 1
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const int a = V[2 * p], b = V[2 * p + 1]; V[p] = (b1 ? b : a) + dpp_i32<0x4E>(b1 ? a : b); }            // lane ^ 2
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { const int a = V[2 * p], b = V[2 * p + 1]; V[p] = (b2 ? b : a) + dpp_i32<0x1B>(dpp_i32<0x141>(b2 ? a : b)); }   // lane ^ 4: half-row mirror, then quad reverse
+        { const int a = V[0], b = V[1]; V[0] = (b3 ? b : a) + dpp_i32<0x141>(dpp_i32<0x140>(b3 ? a : b)); }                                     // lane ^ 8: row mirror, then half-row mirror
+    }
+    __shared__ int s_rows[4][64];
+    int* sr = s_rows[threadIdx.x >> 6];
+    sr[lane] = V[0];
+    wave_sync_lds();
+    const int tot = (sr[lane & 15] + sr[(lane & 15) + 16]) + (sr[(lane & 15) + 32] + sr[(lane & 15) + 48]);   // moment number lane & 15: m10 of keypoint (lane & 15) >> 1 on even lanes, m01 on odd
+    const int my10 = tot, my01 = dpp_i32<0xB1>(tot);   // (meaningful on the even lanes 0 .. 14: keypoint lane >> 1)
+    if (lane < 2 * IC_KP_PER_WAVE && !(lane & 1) && i0 + (lane >> 1) < count) {
         const float ang = slamit_fast_atan2((float)my01, (float)my10);
         float sn, cs;
         slamit_sincosf(ang * factorPI, &sn, &cs);   // a = cos, b = sin of computeOrbDescriptor, once per keypoint
-        OrbLevelKp* kp = kp0 + i0 + lane;
+        OrbLevelKp* kp = kp0 + i0 + (lane >> 1);
         kp->angle = ang; kp->cs = cs; kp->sn = sn;
     }
 }
