@@ -1397,6 +1397,81 @@ __device__ __forceinline__ uint32_t blur_fetch(const uint8_t* S, unsigned sstrid
     return v;
 }
 
+template <bool INTERIOR>   // INTERIOR: the strip and its halo lie inside the level and the plane is 4-byte aligned -- no reflection, no byte path, no predicates
+__device__ __forceinline__ void blur_strip(uint8_t (*in)[72], uint32_t (*rp)[64], const uint8_t* S, const size_t sstride, const bool aligned,
+                                           uint8_t* D, const unsigned dstride, const int w, const int h, const int bx, const int by0, const int tid) {
+    // in[r][k] holds column bx - 4 + k of row by - 3 + r; a thread stages dwords i0 and i1 of the 22 x 18 of a step
+    const int i0 = tid, i1 = tid + 256;
+    const bool has1 = i1 < 22 * 18;
+    const int r0 = i0 / 18, r1 = i1 / 18;
+    const int g0 = bx - 4 + 4 * (i0 - r0 * 18), g1 = bx - 4 + 4 * (i1 - r1 * 18);
+    const bool whole0 = aligned && g0 >= 0 && g0 + 4 <= w, whole1 = aligned && g1 >= 0 && g1 + 4 <= w;
+    uint32_t* const st0 = reinterpret_cast<uint32_t*>(&in[r0][4 * (i0 - r0 * 18)]);
+    uint32_t* const st1 = reinterpret_cast<uint32_t*>(&in[has1 ? r1 : 0][has1 ? 4 * (i1 - r1 * 18) : 0]);
+    const unsigned ss = (unsigned)sstride;
+    uint32_t v0 = INTERIOR ? *reinterpret_cast<const uint32_t*>(S + ((unsigned)(by0 + r0 - 3) * ss + (unsigned)g0)) : blur_fetch(S, ss, whole0, w, h, g0, by0 + r0 - 3);
+    uint32_t v1 = !has1 ? 0u : INTERIOR ? *reinterpret_cast<const uint32_t*>(S + ((unsigned)(by0 + r1 - 3) * ss + (unsigned)g1)) : blur_fetch(S, ss, whole1, w, h, g1, by0 + r1 - 3);
+    *st0 = v0;
+    if (has1) *st1 = v1;
+    __syncthreads();
+    // taps as dot-product operands: bytes for the row pass, halfword pairs for the column pass (which pair of
+    // rows a tap pair meets depends on the parity of the output row)
+    const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
+    const int cy = tid >> 4, cx4 = (tid & 15) * 4;
+    const bool odd = cy & 1;
+    const uint32_t k0 = odd ? (18u << 16) : (18u | (34u << 16)), k1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16));
+    const uint32_t k2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), k3 = odd ? (34u | (18u << 16)) : 18u;
+#pragma unroll 1
+    for (int s = 0; s < BLUR_STEPS; ++s) {
+        const int by = by0 + 16 * s;
+        const bool more = s + 1 < BLUR_STEPS && (INTERIOR || by + 16 < h);
+        if (more) {
+            if (INTERIOR) {
+                v0 = *reinterpret_cast<const uint32_t*>(S + ((unsigned)(by + 16 + r0 - 3) * ss + (unsigned)g0));
+                if (has1) v1 = *reinterpret_cast<const uint32_t*>(S + ((unsigned)(by + 16 + r1 - 3) * ss + (unsigned)g1));
+            } else {
+                v0 = blur_fetch(S, ss, whole0, w, h, g0, by + 16 + r0 - 3);
+                if (has1) v1 = blur_fetch(S, ss, whole1, w, h, g1, by + 16 + r1 - 3);
+            }
+        }
+        // row pass: thread -> 4 adjacent outputs of TWO rows (2p, 2p+1).  Output o needs the 7 bytes at columns
+        // c+o-3 .. c+o+3 = stream bytes o+1 .. o+7 of three ALIGNED dwords (columns c-4 .. c+7): two v_dot4_u32_u8
+        // on byte quads cut out with v_alignbyte.  (Unaligned LDS reads cost ~30 cycles each on gfx950.)
+        if (tid < 11 * 16) {
+            const int p = tid >> 4, c = (tid & 15) * 4;
+            uint32_t o[2][4];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const uint32_t* pw = reinterpret_cast<const uint32_t*>(&in[2 * p + rr][c]);
+                const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+                o[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TA, 0u, false), false);
+                o[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TA, 0u, false), false);
+                o[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TA, 0u, false), false);
+                o[rr][3] = __builtin_amdgcn_udot4(w2, TB, __builtin_amdgcn_udot4(w1, TA, 0u, false), false);
+            }
+            *reinterpret_cast<uint4*>(&rp[p][c]) = make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16),
+                                                               o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
+        }
+        __syncthreads();
+        if (more) {
+            *st0 = v0;
+            if (has1) *st1 = v1;
+        }
+        if (INTERIOR || (bx + cx4 < w && by + cy < h)) {
+            // output row cy uses rows cy .. cy+6: four row pairs starting at pair cy >> 1
+            const int pb = cy >> 1;
+            const uint4 a0 = *reinterpret_cast<const uint4*>(&rp[pb][cx4]), a1 = *reinterpret_cast<const uint4*>(&rp[pb + 1][cx4]);
+            const uint4 a2 = *reinterpret_cast<const uint4*>(&rp[pb + 2][cx4]), a3 = *reinterpret_cast<const uint4*>(&rp[pb + 3][cx4]);
+#define BLUR_COL(f) min((udot2(a3.f, k3, udot2(a2.f, k2, udot2(a1.f, k1, udot2(a0.f, k0, 1u << 15)))) >> 16), 255u)
+            const uint32_t out = BLUR_COL(x) | (BLUR_COL(y) << 8) | (BLUR_COL(z) << 16) | (BLUR_COL(w) << 24);
+#undef BLUR_COL
+            *reinterpret_cast<uint32_t*>(D + ((unsigned)(by + cy) * dstride + (unsigned)(bx + cx4))) = out;
+        }
+        if (!more) break;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void blur_all_kernel(
     const OrbLevel* __restrict__ levels, const uint4* __restrict__ tiles,
     const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
@@ -1423,71 +1498,10 @@ __global__ __launch_bounds__(256) void blur_all_kernel(
     else { S = pyr + L.plane_off + (size_t)frame * L.plane_bytes; sstride = (size_t)L.stride; }
     const bool aligned = ((((uintptr_t)S) | sstride) & 3) == 0;
     uint8_t* D = blur + L.blur_off + (size_t)frame * L.blur_bytes;
-    // in[r][k] holds column bx - 4 + k of row by - 3 + r; a thread stages dwords i0 and i1 of the 22 x 18 of a step
-    const int i0 = tid, i1 = tid + 256;
-    const bool has1 = i1 < 22 * 18;
-    const int r0 = i0 / 18, r1 = i1 / 18;
-    const int g0 = bx - 4 + 4 * (i0 - r0 * 18), g1 = bx - 4 + 4 * (i1 - r1 * 18);
-    const bool whole0 = aligned && g0 >= 0 && g0 + 4 <= w, whole1 = aligned && g1 >= 0 && g1 + 4 <= w;
-    uint32_t* const st0 = reinterpret_cast<uint32_t*>(&in[r0][4 * (i0 - r0 * 18)]);
-    uint32_t* const st1 = reinterpret_cast<uint32_t*>(&in[has1 ? r1 : 0][has1 ? 4 * (i1 - r1 * 18) : 0]);
-    const unsigned ss = (unsigned)sstride;
-    uint32_t v0 = blur_fetch(S, ss, whole0, w, h, g0, by0 + r0 - 3);
-    uint32_t v1 = has1 ? blur_fetch(S, ss, whole1, w, h, g1, by0 + r1 - 3) : 0;
-    *st0 = v0;
-    if (has1) *st1 = v1;
-    __syncthreads();
-    // taps as dot-product operands: bytes for the row pass, halfword pairs for the column pass (which pair of
-    // rows a tap pair meets depends on the parity of the output row)
-    const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
-    const int cy = tid >> 4, cx4 = (tid & 15) * 4;
-    const bool odd = cy & 1;
-    const uint32_t k0 = odd ? (18u << 16) : (18u | (34u << 16)), k1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16));
-    const uint32_t k2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), k3 = odd ? (34u | (18u << 16)) : 18u;
-#pragma unroll 1
-    for (int s = 0; s < BLUR_STEPS; ++s) {
-        const int by = by0 + 16 * s;
-        const bool more = s + 1 < BLUR_STEPS && by + 16 < h;
-        if (more) {
-            v0 = blur_fetch(S, ss, whole0, w, h, g0, by + 16 + r0 - 3);
-            if (has1) v1 = blur_fetch(S, ss, whole1, w, h, g1, by + 16 + r1 - 3);
-        }
-        // row pass: thread -> 4 adjacent outputs of TWO rows (2p, 2p+1).  Output o needs the 7 bytes at columns
-        // c+o-3 .. c+o+3 = stream bytes o+1 .. o+7 of three ALIGNED dwords (columns c-4 .. c+7): two v_dot4_u32_u8
-        // on byte quads cut out with v_alignbyte.  (Unaligned LDS reads cost ~30 cycles each on gfx950.)
-        if (tid < 11 * 16) {
-            const int p = tid >> 4, c = (tid & 15) * 4;
-            uint32_t o[2][4];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const uint32_t* pw = reinterpret_cast<const uint32_t*>(&in[2 * p + rr][c]);
-                const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-                o[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TA, 0u, false), false);
-                o[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TA, 0u, false), false);
-                o[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TA, 0u, false), false);
-                o[rr][3] = __builtin_amdgcn_udot4(w2, TB, __builtin_amdgcn_udot4(w1, TA, 0u, false), false);
-            }
-            *reinterpret_cast<uint4*>(&rp[p][c]) = make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16),
-                                                               o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
-        }
-        __syncthreads();
-        if (more) {
-            *st0 = v0;
-            if (has1) *st1 = v1;
-        }
-        if (bx + cx4 < w && by + cy < h) {
-            // output row cy uses rows cy .. cy+6: four row pairs starting at pair cy >> 1
-            const int pb = cy >> 1;
-            const uint4 a0 = *reinterpret_cast<const uint4*>(&rp[pb][cx4]), a1 = *reinterpret_cast<const uint4*>(&rp[pb + 1][cx4]);
-            const uint4 a2 = *reinterpret_cast<const uint4*>(&rp[pb + 2][cx4]), a3 = *reinterpret_cast<const uint4*>(&rp[pb + 3][cx4]);
-#define BLUR_COL(f) min((udot2(a3.f, k3, udot2(a2.f, k2, udot2(a1.f, k1, udot2(a0.f, k0, 1u << 15)))) >> 16), 255u)
-            const uint32_t out = BLUR_COL(x) | (BLUR_COL(y) << 8) | (BLUR_COL(z) << 16) | (BLUR_COL(w) << 24);
-#undef BLUR_COL
-            *reinterpret_cast<uint32_t*>(D + (size_t)(by + cy) * L.stride + bx + cx4) = out;
-        }
-        if (!more) break;
-        __syncthreads();
-    }
+    // most strips lie inside their level: they take the copy of the loop without reflection, byte path and predicates
+    const bool interior = aligned && bx >= 4 && bx + 68 <= w && by0 >= 3 && by0 + 16 * BLUR_STEPS + 3 <= h;
+    if (interior) blur_strip<true>(in, rp, S, sstride, aligned, D, (unsigned)L.stride, w, h, bx, by0, tid);
+    else blur_strip<false>(in, rp, S, sstride, aligned, D, (unsigned)L.stride, w, h, bx, by0, tid);
 }
 
 // --------------------------------------------------------------------------------------------
