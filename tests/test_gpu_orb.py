@@ -99,29 +99,33 @@ def test_edge_images():
 
 
 @pytest.mark.parametrize("w,h,nf,nl,sf", [(317, 251, 500, 4, 1.2), (752, 480, 1200, 8, 1.2), (640, 480, 300, 3, 1.5),
-                                          (200, 340, 400, 3, 1.3)])
+                                          (200, 340, 400, 3, 1.3), (534, 402, 600, 8, 1.2), (535, 403, 600, 8, 1.2)])
 def test_odd_geometries(w, h, nf, nl, sf):
     ext, orc = api.ORBextractor(nf, sf, nl, 20, 7), ob.OrbOracle(nf, sf, nl, 20, 7)
     _check_frame(ext, orc, synth.synth_frame(w, h, 11), "%dx%d" % (w, h))
 
 
-def test_pyramid_through_the_four_pixel_resize_kernel():
+def test_pyramid_and_blur_through_their_second_kernels():
     """The pyramid levels come from resize_rows8_kernel (eight dst pixels per lane) wherever a level's taps fit its 16-byte
-    windows -- every level at scale factor 1.2 -- and from resize_rows4_kernel otherwise (e.g. scale factor 1.5 above);
-    SLAMIT_RESIZE_NO8=1 (read once, hence the child process) sends every level through the four-pixel kernel: same bytes."""
+    windows -- every level at scale factor 1.2 -- and from resize_rows4_kernel otherwise (e.g. scale factor 1.5 above); the
+    blurred planes come from blur_stream_kernel (a thread walks a column group down a strip) when the planes are 4-byte
+    aligned and from the tile kernel blur_all_kernel otherwise (the unaligned-view test below).  SLAMIT_RESIZE_NO8=1 and
+    SLAMIT_BLUR_NO_STREAM=1 (read once, hence the child process) send everything through the four-pixel resize and the
+    tile blur: same bytes."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
             "from oracle import bindings as ob\n"
             "from weiner_slamit_v2_amd import api, synth\n"
-            "for (w, h, nf) in ((640, 480, 1000), (1280, 720, 2000), (317, 251, 500)):\n"
+            "for (w, h, nf) in ((640, 480, 1000), (1280, 720, 2000), (317, 251, 500), (533, 401, 600)):\n"
             "    ext, orc = api.ORBextractor(nf, 1.2, 8, 20, 7), ob.OrbOracle(nf)\n"
             "    img = synth.synth_frame(w, h, 3)\n"
             "    kg, dg = ext(img); ko, do = orc.extract(img)\n"
             "    assert all(np.array_equal(ext.level(0, l), orc.level(l)) for l in range(8)), (w, h)\n"
+            "    assert all(np.array_equal(ext.blurred(0, l), orc.blurred(l)) for l in range(8)), (w, h)\n"
             "    assert np.array_equal(dg, do) and len(kg) == len(ko)\n"
             "print('same bytes')\n" % root)
-    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, SLAMIT_RESIZE_NO8="1"), cwd=root, timeout=300)
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, SLAMIT_RESIZE_NO8="1", SLAMIT_BLUR_NO_STREAM="1"), cwd=root, timeout=300)
     assert b"same bytes" in out
 
 

@@ -60,6 +60,10 @@ void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const ui
                    size_t img0_frame, const uint8_t* pyr, OrbLevelKp* lkp, size_t kp_frame_stride,
                    const int* kp_count, int max_kp, int nframes);
 int orbk_blur_tiles(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out);
+void orbk_blur_tiles_split(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& stream, std::vector<uint32_t>& edge,
+                           std::vector<int>& n_stream, std::vector<int>& n_edge);
+void orbk_blur_stream(hipStream_t st, const OrbLevel* levels, const uint32_t* d_tiles, int ntiles, const uint8_t* img0,
+                      size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes, bool edge);
 void orbk_blur(hipStream_t st, const OrbLevel* levels, const uint32_t* d_tiles, int total_tiles, const uint8_t* img0,
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes);
 void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,
@@ -125,6 +129,9 @@ struct slamit_orb {
     uint32_t* d_ws_xy;
     uint16_t* d_ws_node;
     uint32_t* d_blur_tiles;   // blur strip table (orbk_blur_tiles), blur_tiles entries of 4 words
+    uint32_t* d_blur_str; uint32_t* d_blur_edge;   // the same strips split: columns inside the level (blur_stream_kernel) / the rest (orbk_blur_tiles_split)
+    int blur_str_base[ORB_MAX_LEVELS + 1], blur_edge_base[ORB_MAX_LEVELS + 1];   // first entry of a level in each table (last: the totals)
+    bool blur_stream_on;
     uint32_t* d_cells;   // FAST cell table (orbk_fast_cells), fast_cells entries of 8 words
     int fast_cells;
     uint32_t* d_jobs;    // strip FAST job table (orbk_fast_strip_jobs), fast_jobs entries of 8 words; fast_jobs == 0: per-cell kernel only
@@ -167,7 +174,7 @@ static void orb_free(slamit_orb* h) {
     if (!h) return;
     SlamitDeviceGuard guard(h->device);
     hipFree(h->d_levels); hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cand); hipFree(h->d_ws_xy);
-    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_jobs); hipFree(h->d_fb_list); hipFree(h->d_blur_tiles); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
+    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_jobs); hipFree(h->d_fb_list); hipFree(h->d_blur_tiles); hipFree(h->d_blur_str); hipFree(h->d_blur_edge); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
     hipFree(h->d_out_desc); hipFree(h->d_out_n); if (h->h_out) hipHostFree(h->h_out); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
@@ -334,6 +341,16 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         h->blur_tiles = empty ? 0 : orbk_blur_tiles(h->levels.data(), nl, bt);
         ALLOC(h->d_blur_tiles, sizeof(uint32_t) * std::max<size_t>(bt.size(), 4));
         if (e == hipSuccess && !bt.empty()) e = hipMemcpy(h->d_blur_tiles, bt.data(), sizeof(uint32_t) * bt.size(), hipMemcpyHostToDevice);
+        {
+            std::vector<uint32_t> ts, te;
+            std::vector<int> ns, ne;
+            if (!empty) orbk_blur_tiles_split(h->levels.data(), nl, ts, te, ns, ne);
+            for (int l = 0, a = 0, b = 0; l <= nl; ++l) { h->blur_str_base[l] = a; h->blur_edge_base[l] = b; if (l < nl && !empty) { a += ns[l]; b += ne[l]; } }
+            ALLOC(h->d_blur_str, sizeof(uint32_t) * std::max<size_t>(ts.size(), 4)); ALLOC(h->d_blur_edge, sizeof(uint32_t) * std::max<size_t>(te.size(), 4));
+            if (e == hipSuccess && !ts.empty()) e = hipMemcpy(h->d_blur_str, ts.data(), sizeof(uint32_t) * ts.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess && !te.empty()) e = hipMemcpy(h->d_blur_edge, te.data(), sizeof(uint32_t) * te.size(), hipMemcpyHostToDevice);
+            h->blur_stream_on = !empty && !(getenv("SLAMIT_BLUR_NO_STREAM") && atoi(getenv("SLAMIT_BLUR_NO_STREAM")));   // A/B runs: the tile kernel everywhere
+        }
     }
     bool rows4_ok = true;
     for (int l = 1; l < nl && e == hipSuccess && !empty; ++l) {
@@ -528,6 +545,20 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
         HIP_TRY(hipMemsetAsync(fb_count, 0, sizeof(int) * 2, st));
     }
     h->counters_clean = false;
+    // the blur of levels [l0, l1): every strip streams down its columns (blur_stream_kernel; the strips at the left / right edge
+    // in their own launch); when the caller's level-0 plane is not 4-byte aligned everything takes the tile kernel
+    const bool blur_src_aligned = ((((uintptr_t)d_gray) | stride | frame_stride) & 3) == 0;
+    auto launch_blur = [&](hipStream_t bs, int l0, int l1) {
+        if (h->blur_stream_on && blur_src_aligned) {
+            orbk_blur_stream(bs, h->d_levels, h->d_blur_str + 4 * (size_t)h->blur_str_base[l0], h->blur_str_base[l1] - h->blur_str_base[l0], d_gray, stride,
+                             frame_stride, h->d_pyr, h->d_blur, nframes, false);
+            orbk_blur_stream(bs, h->d_levels, h->d_blur_edge + 4 * (size_t)h->blur_edge_base[l0], h->blur_edge_base[l1] - h->blur_edge_base[l0], d_gray, stride,
+                             frame_stride, h->d_pyr, h->d_blur, nframes, true);
+        } else {
+            const int t0 = h->levels[l0].blur_tile_base, t1 = l1 < nl ? h->levels[l1].blur_tile_base : h->blur_tiles;
+            orbk_blur(bs, h->d_levels, h->d_blur_tiles + 4 * (size_t)t0, t1 - t0, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
+        }
+    };
     // K1: pyramid, level l from level l-1
     prof_mark(h, st, ST_RESIZE, true);
     const bool src0_aligned = ((((uintptr_t)d_gray) | stride | frame_stride) & 3) == 0;
@@ -549,8 +580,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
                 // the small levels are a few microseconds of work behind a kernel boundary each and leave the chip idle
                 HIP_TRY(hipEventRecord(h->ev_mid, st));
                 HIP_TRY(hipStreamWaitEvent(h->stream_b, h->ev_mid, 0));
-                orbk_blur(h->stream_b, h->d_levels, h->d_blur_tiles, h->levels[l + 1].blur_tile_base, d_gray, stride, frame_stride, h->d_pyr,
-                          h->d_blur, nframes);
+                launch_blur(h->stream_b, 0, l + 1);
                 early_done = true;
             }
         }
@@ -573,7 +603,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     if (h->overlap && h->prof_on != 1 && getenv("SLAMIT_ORB_FORK_EARLY")) {
         HIP_TRY(hipEventRecord(h->ev_pyr, st));
         HIP_TRY(hipStreamWaitEvent(h->stream_b, h->ev_pyr, 0));
-        orbk_blur(h->stream_b, h->d_levels, h->d_blur_tiles, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
+        launch_blur(h->stream_b, 0, nl);
         HIP_TRY(hipEventRecord(h->ev_blur, h->stream_b));
     }
     // K2: FAST + NMS + per-cell threshold fallback -> candidate lists
@@ -600,9 +630,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     if (side && !fork_early) {
         HIP_TRY(hipEventRecord(h->ev_pyr, st));
         HIP_TRY(hipStreamWaitEvent(h->stream_b, h->ev_pyr, 0));
-        const int t0 = early_done ? h->levels[h->blur_split + 1].blur_tile_base : 0;   // the levels the early launch left
-        orbk_blur(h->stream_b, h->d_levels, h->d_blur_tiles + 4 * (size_t)t0, h->blur_tiles - t0, d_gray, stride, frame_stride, h->d_pyr,
-                  h->d_blur, nframes);
+        launch_blur(h->stream_b, early_done ? h->blur_split + 1 : 0, nl);   // the levels the early launch left
         HIP_TRY(hipEventRecord(h->ev_blur, h->stream_b));
     }
     // K4: octree
@@ -619,7 +647,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
         HIP_TRY(hipStreamWaitEvent(st, h->ev_blur, 0));
     } else {
         prof_mark(h, st, ST_BLUR, true);
-        orbk_blur(st, h->d_levels, h->d_blur_tiles, h->blur_tiles, d_gray, stride, frame_stride, h->d_pyr, h->d_blur, nframes);
+        launch_blur(st, 0, nl);
         prof_mark(h, st, ST_BLUR, false);
     }
     // K7: descriptors + output records

@@ -1391,10 +1391,43 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) { 
 __device__ __forceinline__ uint32_t blur_fetch(const uint8_t* S, unsigned sstride, bool whole, int w, int h, int gx0, int row) {
     const unsigned ro = (unsigned)reflect101(row, h) * sstride;
     if (whole) return *reinterpret_cast<const uint32_t*>(S + (ro + (unsigned)gx0));
+    if (gx0 >= w + 3) return 0u;   // a dword wholly right of the reflected fringe (columns w .. w + 2) feeds no stored output: no byte loads for it
     uint32_t v = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v |= (uint32_t)S[ro + (unsigned)reflect101(gx0 + j, w)] << (8 * j);
     return v;
+}
+
+// The same dword WITHOUT byte loads (4-byte aligned planes): every staged dword, also one that straddles or lies beyond an image
+// edge, is a v_perm of two aligned dwords of the row -- which two and with which selector depends only on the column
+// (REFLECT_101 of columns -4 .. -1 and w .. w + 2; further out nothing is needed), so a thread works it out once and
+// every lane of every wave runs the same three instructions per fetch.  (The byte path made EVERY wave of an edge strip
+// run 4 byte loads + reflections per dword: edge strips cost 2.4 x an inner one.)
+struct BlurCol { unsigned a0, a1, sel; };
+__device__ __forceinline__ BlurCol blur_col(int g, int w, unsigned ss) {
+#define BLUR_SEL(i0, i1, i2, i3) ((unsigned)(i0) | ((unsigned)(i1) << 8) | ((unsigned)(i2) << 16) | ((unsigned)(i3) << 24))
+    BlurCol c;
+    if (g < 0) { c.a0 = 0u; c.a1 = 4u; c.sel = BLUR_SEL(4, 3, 2, 1); }                       // columns -4 .. -1 = 4, 3, 2, 1
+    else if (g + 4 <= w) { c.a0 = c.a1 = (unsigned)g; c.sel = BLUR_SEL(0, 1, 2, 3); }
+    else if (g < w) {                                                                         // q real columns, then w - 2, w - 3, ..
+        const int q = w - g;
+        unsigned idx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) idx[j] = (unsigned)(j < q ? 4 + j : 2 * q + 2 - j);
+        c.a0 = (unsigned)(g - 4); c.a1 = (unsigned)g; c.sel = BLUR_SEL(idx[0], idx[1], idx[2], idx[3]);
+    } else if (g <= w + 2) {                                                                  // columns w + t + j = w - 2 - t - j, needed up to w + 2
+        const int t = g - w, gb = (w - 4) & ~3;
+        unsigned idx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) idx[j] = j <= 2 - t ? (unsigned)(w - 2 - t - j - gb) : 0x0Cu;
+        c.a0 = (unsigned)gb; c.a1 = min((unsigned)gb + 4u, ss - 4u); c.sel = BLUR_SEL(idx[0], idx[1], idx[2], idx[3]);
+    } else { c.a0 = c.a1 = 0u; c.sel = BLUR_SEL(0x0C, 0x0C, 0x0C, 0x0C); }
+#undef BLUR_SEL
+    return c;
+}
+__device__ __forceinline__ uint32_t blur_fetch2(const uint8_t* S, unsigned ss, int h, int row, const BlurCol c) {
+    const unsigned ro = __umul24((unsigned)reflect101(row, h), ss);
+    return __builtin_amdgcn_perm(*reinterpret_cast<const uint32_t*>(S + (ro + c.a1)), *reinterpret_cast<const uint32_t*>(S + (ro + c.a0)), c.sel);
 }
 
 template <bool INTERIOR>   // INTERIOR: the strip and its halo lie inside the level and the plane is 4-byte aligned -- no reflection, no byte path, no predicates
@@ -1409,8 +1442,11 @@ __device__ __forceinline__ void blur_strip(uint8_t (*in)[72], uint32_t (*rp)[64]
     uint32_t* const st0 = reinterpret_cast<uint32_t*>(&in[r0][4 * (i0 - r0 * 18)]);
     uint32_t* const st1 = reinterpret_cast<uint32_t*>(&in[has1 ? r1 : 0][has1 ? 4 * (i1 - r1 * 18) : 0]);
     const unsigned ss = (unsigned)sstride;
-    uint32_t v0 = INTERIOR ? *reinterpret_cast<const uint32_t*>(S + ((unsigned)(by0 + r0 - 3) * ss + (unsigned)g0)) : blur_fetch(S, ss, whole0, w, h, g0, by0 + r0 - 3);
-    uint32_t v1 = !has1 ? 0u : INTERIOR ? *reinterpret_cast<const uint32_t*>(S + ((unsigned)(by0 + r1 - 3) * ss + (unsigned)g1)) : blur_fetch(S, ss, whole1, w, h, g1, by0 + r1 - 3);
+    const BlurCol bc0 = blur_col(g0, w, ss), bc1 = blur_col(g1, w, ss);   // (used by edge strips of aligned planes)
+    uint32_t v0 = INTERIOR ? *reinterpret_cast<const uint32_t*>(S + (__umul24((unsigned)(by0 + r0 - 3), ss) + (unsigned)g0))
+                           : aligned ? blur_fetch2(S, ss, h, by0 + r0 - 3, bc0) : blur_fetch(S, ss, whole0, w, h, g0, by0 + r0 - 3);
+    uint32_t v1 = !has1 ? 0u : INTERIOR ? *reinterpret_cast<const uint32_t*>(S + (__umul24((unsigned)(by0 + r1 - 3), ss) + (unsigned)g1))
+                                        : aligned ? blur_fetch2(S, ss, h, by0 + r1 - 3, bc1) : blur_fetch(S, ss, whole1, w, h, g1, by0 + r1 - 3);
     *st0 = v0;
     if (has1) *st1 = v1;
     __syncthreads();
@@ -1427,11 +1463,16 @@ __device__ __forceinline__ void blur_strip(uint8_t (*in)[72], uint32_t (*rp)[64]
         const bool more = s + 1 < BLUR_STEPS && (INTERIOR || by + 16 < h);
         if (more) {
             if (INTERIOR) {
-                v0 = *reinterpret_cast<const uint32_t*>(S + ((unsigned)(by + 16 + r0 - 3) * ss + (unsigned)g0));
-                if (has1) v1 = *reinterpret_cast<const uint32_t*>(S + ((unsigned)(by + 16 + r1 - 3) * ss + (unsigned)g1));
+                v0 = *reinterpret_cast<const uint32_t*>(S + (__umul24((unsigned)(by + 16 + r0 - 3), ss) + (unsigned)g0));
+                if (has1) v1 = *reinterpret_cast<const uint32_t*>(S + (__umul24((unsigned)(by + 16 + r1 - 3), ss) + (unsigned)g1));
             } else {
-                v0 = blur_fetch(S, ss, whole0, w, h, g0, by + 16 + r0 - 3);
-                if (has1) v1 = blur_fetch(S, ss, whole1, w, h, g1, by + 16 + r1 - 3);
+                if (aligned) {
+                    v0 = blur_fetch2(S, ss, h, by + 16 + r0 - 3, bc0);
+                    if (has1) v1 = blur_fetch2(S, ss, h, by + 16 + r1 - 3, bc1);
+                } else {
+                    v0 = blur_fetch(S, ss, whole0, w, h, g0, by + 16 + r0 - 3);
+                    if (has1) v1 = blur_fetch(S, ss, whole1, w, h, g1, by + 16 + r1 - 3);
+                }
             }
         }
         // row pass: thread -> 4 adjacent outputs of TWO rows (2p, 2p+1).  Output o needs the 7 bytes at columns
@@ -1465,7 +1506,7 @@ __device__ __forceinline__ void blur_strip(uint8_t (*in)[72], uint32_t (*rp)[64]
 #define BLUR_COL(f) min((udot2(a3.f, k3, udot2(a2.f, k2, udot2(a1.f, k1, udot2(a0.f, k0, 1u << 15)))) >> 16), 255u)
             const uint32_t out = BLUR_COL(x) | (BLUR_COL(y) << 8) | (BLUR_COL(z) << 16) | (BLUR_COL(w) << 24);
 #undef BLUR_COL
-            *reinterpret_cast<uint32_t*>(D + ((unsigned)(by + cy) * dstride + (unsigned)(bx + cx4))) = out;
+            *reinterpret_cast<uint32_t*>(D + (__umul24((unsigned)(by + cy), dstride) + (unsigned)(bx + cx4))) = out;
         }
         if (!more) break;
         __syncthreads();
@@ -1502,6 +1543,90 @@ __global__ __launch_bounds__(256) void blur_all_kernel(
     const bool interior = aligned && bx >= 4 && bx + 68 <= w && by0 >= 3 && by0 + 16 * BLUR_STEPS + 3 <= h;
     if (interior) blur_strip<true>(in, rp, S, sstride, aligned, D, (unsigned)L.stride, w, h, bx, by0, tid);
     else blur_strip<false>(in, rp, S, sstride, aligned, D, (unsigned)L.stride, w, h, bx, by0, tid);
+}
+
+// K6, streaming form, for the strips whose COLUMNS lie inside the level (dwords bx - 4 .. bx + 67 inside the row, planes
+// 4-byte aligned: no byte path, no column reflection -- three quarters of the pixels).  One THREAD walks a 4-pixel column
+// group down the strip's 64 rows: per pair of input rows one 12-byte load each, the row pass (14 operations per row, as
+// above), the two rows packed as the halfwords of one dword per column; the last four such pairs are the whole state
+// (16 registers), and every new pair completes TWO output rows (y = 2p - 3 and 2p - 2 for the pair of rows 2p, 2p + 1,
+// with the two tap patterns of v_dot2_u32_u16 above).  No LDS, no barrier, no halo rows staged twice: ~0.2 instructions
+// per pixel and wave against 0.37 (0.66 with the byte path) of the tile form.  Rows reflect by index (REFLECT_101).
+// A workgroup of 256 threads takes 16 strips.  The strips at the left / right image edge take the EDGE instance (their own launch):
+// the same walk with each window dword built from two aligned dwords (blur_col), and no thread for columns past the image.
+template <bool EDGE>   // EDGE: strips that touch the left / right image edge -- each of the three window dwords is a v_perm of two aligned dwords (blur_col)
+__global__ __launch_bounds__(256) void blur_stream_kernel(
+    const OrbLevel* __restrict__ levels, const uint4* __restrict__ tiles,
+    const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
+    const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, unsigned ntiles) {
+    const unsigned tile = blockIdx.x * 16u + (threadIdx.x >> 4);
+    if (tile >= ntiles) return;
+    const int frame = blockIdx.y;
+    const uint4 tt = tiles[tile];
+    const int level = (int)tt.x, by0 = (int)tt.z;
+    const int x0 = (int)tt.y + 4 * (int)(threadIdx.x & 15);
+    const OrbLevel& L = levels[level];
+    const int h = L.h;
+    const uint8_t* S;
+    unsigned ss;
+    if (level == 0) { S = img0 + (size_t)frame * img0_frame; ss = (unsigned)img0_stride; }
+    else { S = pyr + L.plane_off + (size_t)frame * L.plane_bytes; ss = (unsigned)L.stride; }
+    if (EDGE && x0 >= L.w) return;   // (a strip at the right edge is rarely 64 columns wide)
+    BlurCol bc[3];
+    if (EDGE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bc[k] = blur_col(x0 - 4 + 4 * k, L.w, ss);
+    } else S += x0 - 4;
+    uint8_t* D = blur + L.blur_off + (size_t)frame * L.blur_bytes + x0;
+    const unsigned ds = (unsigned)L.stride;
+    const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
+    const uint32_t kA0 = 18u | (34u << 16), kA1 = 49u | (55u << 16), kA2 = 49u | (34u << 16), kA3 = 18u;           // output row 2p - 3
+    const uint32_t kB0 = 18u << 16, kB1 = 34u | (49u << 16), kB2 = 55u | (49u << 16), kB3 = 34u | (18u << 16);     // output row 2p - 2
+    const int ylast = min(by0 + 16 * BLUR_STEPS, h) - 1;
+    const int p0 = (by0 - 3) >> 1, p1 = (ylast + 3) >> 1;   // pairs of rows (2p, 2p + 1); arithmetic shift: by0 - 3 may be negative
+    typedef unsigned blur_u3 __attribute__((ext_vector_type(3)));
+    auto fetch = [&](int yy) -> blur_u3 {
+        int r = yy < 0 ? -yy : yy;
+        r = r >= h ? 2 * h - 2 - r : r;
+        r = min(max(r, 0), h - 1);   // (rows further out are only read for outputs that are not stored)
+        if (EDGE) {
+            const uint8_t* R = S + __umul24((unsigned)r, ss);
+            blur_u3 v;
+            v.x = __builtin_amdgcn_perm(*reinterpret_cast<const uint32_t*>(R + bc[0].a1), *reinterpret_cast<const uint32_t*>(R + bc[0].a0), bc[0].sel);
+            v.y = __builtin_amdgcn_perm(*reinterpret_cast<const uint32_t*>(R + bc[1].a1), *reinterpret_cast<const uint32_t*>(R + bc[1].a0), bc[1].sel);
+            v.z = __builtin_amdgcn_perm(*reinterpret_cast<const uint32_t*>(R + bc[2].a1), *reinterpret_cast<const uint32_t*>(R + bc[2].a0), bc[2].sel);
+            return v;
+        }
+        return *reinterpret_cast<const blur_u3*>(S + __umul24((unsigned)r, ss));   // rows < 2^16, pitch < 2^24: the full-rate multiply
+    };
+    auto rowpass = [&](const blur_u3 v, uint32_t* o) {
+        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(v.z, v.y, 1), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(v.y, v.x, 1), TA, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(v.z, v.y, 2), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(v.y, v.x, 2), TA, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(v.z, v.y, 3), TB, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(v.y, v.x, 3), TA, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(v.z, TB, __builtin_amdgcn_udot4(v.y, TA, 0u, false), false);
+    };
+    uint32_t P0[4] = {0, 0, 0, 0}, P1[4] = {0, 0, 0, 0}, P2[4] = {0, 0, 0, 0}, P3[4];   // the last four row pairs, oldest first
+    // three pairs of rows in flight: a thread's walk is a chain of ~36 dependent steps, and with one pair ahead every step waited for HBM
+    blur_u3 va = fetch(2 * p0), vb = fetch(2 * p0 + 1), va1 = fetch(2 * p0 + 2), vb1 = fetch(2 * p0 + 3), va2 = fetch(2 * p0 + 4), vb2 = fetch(2 * p0 + 5);
+#pragma unroll 4
+    for (int p = p0; p <= p1; ++p) {
+        const blur_u3 ca = va, cb = vb;
+        va = va1; vb = vb1; va1 = va2; vb1 = vb2;
+        va2 = fetch(2 * p + 6); vb2 = fetch(2 * p + 7);   // (rows past the strip's last pair are clamped reads of rows that exist)
+        uint32_t oa[4], ob[4];
+        rowpass(ca, oa); rowpass(cb, ob);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P3[j] = oa[j] | (ob[j] << 16);
+        const int ya = 2 * p - 3, yb = 2 * p - 2;
+#define BLUR_OUT(k0, k1, k2, k3, j) min((udot2(P3[j], k3, udot2(P2[j], k2, udot2(P1[j], k1, udot2(P0[j], k0, 1u << 15)))) >> 16), 255u)
+        if (ya >= by0 && ya <= ylast)
+            *reinterpret_cast<uint32_t*>(D + __umul24((unsigned)ya, ds)) = BLUR_OUT(kA0, kA1, kA2, kA3, 0) | (BLUR_OUT(kA0, kA1, kA2, kA3, 1) << 8) | (BLUR_OUT(kA0, kA1, kA2, kA3, 2) << 16) | (BLUR_OUT(kA0, kA1, kA2, kA3, 3) << 24);
+        if (yb >= by0 && yb <= ylast)
+            *reinterpret_cast<uint32_t*>(D + __umul24((unsigned)yb, ds)) = BLUR_OUT(kB0, kB1, kB2, kB3, 0) | (BLUR_OUT(kB0, kB1, kB2, kB3, 1) << 8) | (BLUR_OUT(kB0, kB1, kB2, kB3, 2) << 16) | (BLUR_OUT(kB0, kB1, kB2, kB3, 3) << 24);
+#undef BLUR_OUT
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { P0[j] = P1[j]; P1[j] = P2[j]; P2[j] = P3[j]; }
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1856,8 +1981,35 @@ int orbk_blur_tiles(const OrbLevel* host_levels, int nlevels, std::vector<uint32
     return (int)(out.size() / 4);
 }
 
+// The same strips as two tables (both level-major): those whose columns lie inside the level (blur_stream_kernel) and the
+// rest (blur_all_kernel); per level the number of entries of each.  The caller uses them when the planes are 4-byte aligned.
+void orbk_blur_tiles_split(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& stream, std::vector<uint32_t>& edge,
+                           std::vector<int>& n_stream, std::vector<int>& n_edge) {
+    stream.clear(); edge.clear(); n_stream.assign(nlevels, 0); n_edge.assign(nlevels, 0);
+    for (int l = 0; l < nlevels; ++l)
+        for (int by = 0; by < host_levels[l].h; by += 16 * BLUR_STEPS)
+            for (int bx = 0; bx < host_levels[l].w; bx += 64) {
+                const uint32_t t[4] = {(uint32_t)l, (uint32_t)bx, (uint32_t)by, 0u};
+                const bool inside = bx >= 4 && bx + 68 <= host_levels[l].w && (host_levels[l].stride & 3) == 0;
+                (inside ? stream : edge).insert((inside ? stream : edge).end(), t, t + 4);
+                ++(inside ? n_stream : n_edge)[l];
+            }
+}
+
+void orbk_blur_stream(hipStream_t st, const OrbLevel* levels, const uint32_t* d_tiles, int ntiles, const uint8_t* img0,
+                      size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes, bool edge) {
+    if (ntiles <= 0) return;
+    if (edge)
+        hipLaunchKernelGGL(blur_stream_kernel<true>, dim3((ntiles + 15) / 16, nframes), dim3(256), 0, st, levels, reinterpret_cast<const uint4*>(d_tiles), img0,
+                           img0_stride, img0_frame, pyr, blur, (unsigned)ntiles);
+    else
+        hipLaunchKernelGGL(blur_stream_kernel<false>, dim3((ntiles + 15) / 16, nframes), dim3(256), 0, st, levels, reinterpret_cast<const uint4*>(d_tiles), img0,
+                           img0_stride, img0_frame, pyr, blur, (unsigned)ntiles);
+}
+
 void orbk_blur(hipStream_t st, const OrbLevel* levels, const uint32_t* d_tiles, int total_tiles, const uint8_t* img0,
                size_t img0_stride, size_t img0_frame, const uint8_t* pyr, uint8_t* blur, int nframes) {
+    if (total_tiles <= 0) return;
     const unsigned total = (unsigned)total_tiles * (unsigned)nframes, grid = ((total + 7u) >> 3) << 3;
     const unsigned inv = (unsigned)((0x100000000ull + (unsigned)total_tiles - 1) / (unsigned)total_tiles);   // exact for logical < 2^32 / tiles
     hipLaunchKernelGGL(blur_all_kernel, dim3(grid), dim3(256), 0, st, levels, reinterpret_cast<const uint4*>(d_tiles), img0,
