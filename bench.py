@@ -243,8 +243,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     # 256 streams per step: per-frame cost keeps falling with the batch (launch floor, ramp and tail of ~14 launches per step, the
-    # octree's one long workgroup per frame, and the side stream's overlap all improve): 64 -> 208k frames/s, 128 -> 236k,
-    # 256 -> 248k, 512 -> 259k on one MI355X; 256 keeps a step at one millisecond
+    # octree's one long workgroup per frame, and the side stream's overlap all improve): 64 -> 218k frames/s, 128 -> 253k,
+    # 256 -> 261k, 512 -> ~270k on one MI355X; 256 keeps a step at one millisecond
     ap.add_argument("--batch", type=int, default=None, help="independent camera streams per GPU and step (default: 256 at VGA, 64 at 720p "
                     "as BASELINE configs[2] words it)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
