@@ -10,15 +10,19 @@
 //   k_prepare          setLambda + Dinv + Hpl, B*Dinv                    G/core/block_solver.hpp:564-589,381-400
 //   k_schur / _reduce  Schur complement  S = Hpp - sum_p B Dinv B^T      G/core/block_solver.hpp:401-439
 //                      as ONE dense split-K product GA * GB^T on v_mfma_f64_16x16x4_f64
-//   k_ldlt_solve       LinearSolverEigen::solve (dense blocked LDLt)     G/solvers/linear_solver_eigen.h:94-124
+//   k_point_pass       k_linearize + k_point_reduce + k_prepare in one launch: every LM trial after a stage's first
+//   k_schur_pose       k_schur with k_pose_reduce's workgroups behind its tiles: the same trials
+//   k_ldlt_solve       LinearSolverEigen::solve                          G/solvers/linear_solver_eigen.h:94-124
+//                      banded systems: block LDLt with 4 x 4 pivots inside LDS, rank-4 updates on v_mfma_f64_16x16x4_f64 with
+//                      the tiles resident in accumulators (ldlt_band_solve); others: dense blocked LDLt through L2
 //   k_backsub_update   landmark back-substitution + oplus + push()       G/core/block_solver.hpp:459-485, sparse_optimizer.cpp:422-435
 //   k_errors           computeActiveErrors + activeRobustChi2            G/core/sparse_optimizer.cpp:61-114
 //   k_decide           gain ratio, lambda update, pop()/discardTop(), stop rules   ...levenberg.cpp:102-161
 //   k_gate / k_final   chi2 gate + depth test between / after the stages  Optimizer.cc:672-743
 //
 // The whole Levenberg-Marquardt control flow lives in a device-resident BaState per window, so
-// an LM trial is a fixed sequence of launches ("slot") with no host round trip; kernels of a
-// finished window exit at once.  blockIdx.y is the window of a batch.
+// an LM trial is a fixed sequence of launches ("slot": eleven for the first trial of a stage, seven afterwards,
+// bak_slot) with no host round trip; kernels of a finished window exit at once.  blockIdx.y is the window of a batch.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
