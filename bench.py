@@ -248,6 +248,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="independent camera streams per GPU and step (default: 256 at VGA, 64 at 720p "
                     "as BASELINE configs[2] words it)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--scene", choices=["rich", "sparse"], default="rich",
+                    help="synthetic frame content (synth.synth_frame): 'rich' is the benchmark's workload (about one pixel in eight is a FAST corner); "
+                         "'sparse' has a few percent of corners and shows how much the FAST pass depends on content (DESIGN.md section 5)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real runs; gloo only to rehearse the multi-rank flow with ranks sharing one GPU")
@@ -297,7 +300,7 @@ def main():
         # each rank owns its own B streams (different seeds per rank); two consecutive frames per stream; 16 distinct
         # frame pairs per rank, each used by B / 16 streams (the kernels are issue bound: content repeats do not help them)
         uniq = min(B, 16)
-        fa = [synth.synth_frame(W, H, 1000 * rank + i) for i in range(uniq)]
+        fa = [synth.synth_frame(W, H, 1000 * rank + i, scene=args.scene) for i in range(uniq)]
         fb = [synth.warp_frame(fa[i], 1000 * rank + i) for i in range(uniq)]
     frames = [np.stack([f[i % uniq] for i in range(B)]) for f in (fa, fb)]
     d_frames = [torch.from_numpy(f).to(dev) for f in frames]
@@ -448,7 +451,7 @@ def main():
             "scaling": "strong" if pipeline else "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" if args.scene == "rich" else "synthetic (scene=%s)" % args.scene,
             "config": {"workload": "BASELINE %s: %dx%d 8-level ORB extract (%d features, FAST 20/7) + "
                                    "brute-force 256-bit Hamming best/second match vs the stream's previous frame; "
                                    "%d independent streams per GPU per step" % (cfg_name, W, H, NFEAT, B) +

@@ -31,14 +31,18 @@ def _value_noise(rs, h, w, cell, amp):
     return amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
 
 
-def synth_frame(width, height, index=0, n_shapes=None, seed=FRAME_SEED):
-    """uint8 (height, width) frame number `index`."""
+def synth_frame(width, height, index=0, n_shapes=None, seed=FRAME_SEED, scene="rich"):
+    """uint8 (height, width) frame number `index`.  scene "rich" (every test, the benchmarks' default): value noise down to
+    4-pixel cells plus 400 hard-edged shapes per VGA frame -- about one pixel in eight is a FAST corner at threshold 20;
+    "sparse": the same construction without the 4-pixel noise level and with 150 shapes -- a few percent of corners, closer
+    to indoor video (bench.py --scene sparse reports how the FAST pass depends on it)."""
     rs = np.random.RandomState((seed + index) & 0x7FFFFFFF)
     img = np.full((height, width), 128.0)
-    for cell, amp in ((64, 64.0), (16, 32.0), (4, 16.0)):
+    sparse = scene == "sparse"
+    for cell, amp in (((64, 64.0), (16, 16.0)) if sparse else ((64, 64.0), (16, 32.0), (4, 16.0))):
         img += _value_noise(rs, height, width, cell, amp)
     if n_shapes is None:
-        n_shapes = int(round(400.0 * (width * height) / (640.0 * 480.0)))
+        n_shapes = int(round((150.0 if sparse else 400.0) * (width * height) / (640.0 * 480.0)))
     yy, xx = np.mgrid[0:height, 0:width]
     for _ in range(n_shapes):
         kind = rs.randint(0, 3)
@@ -62,7 +66,7 @@ def synth_frame(width, height, index=0, n_shapes=None, seed=FRAME_SEED):
             m = (np.abs(lx) * 2 <= sw) & (np.abs(ly) * 2 <= sh)
             sign = np.where((lx >= 0) ^ (ly >= 0), 1.0, -1.0)
             img[y0:y1, x0:x1] += delta * m * sign
-    img += rs.randint(-4, 5, size=(height, width))
+    img += rs.randint(-2, 3, size=(height, width)) if sparse else rs.randint(-4, 5, size=(height, width))
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
