@@ -44,6 +44,9 @@ CONFIGS = {  # name: (width, height, nfeatures, algorithmic FAST bytes per frame
 SCHUR_ALGO_MFLOP = {"window8": 17.9, "dense": 565.0}
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6
+# Integer vector peak of the chip: 1024 SIMDs x 16 lanes per clock x 2.4 GHz (full-rate instructions; the byte instructions
+# FAST lives on -- v_lerp_u8, v_perm, v_pk_* -- run at half of it)
+VALU_PEAK_TLANEOPS = 39.3
 
 
 def _sha16(path):
@@ -74,6 +77,107 @@ def measured_traffic(batch):
         return int(kb * 1024 * batch / doc["frames_per_launch"]), "%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch; kernel source %s)" % (rel, sha)
     except Exception as e:
         return None, "unreadable %s: %r" % (path, e)
+
+
+def measured_valu(batch, fast_avg_ms, pixels_per_frame):
+    """The FAST kernel against the chip's VECTOR-instruction roofline: lane-operations per pyramid pixel from the newest
+    committed SQ counter summary (profiles/rNN_fast_issue.json: SQ_INSTS_VALU per launch of the shipped kernel), priced with
+    THIS run's launch time.  None when the summary was taken on another version of the kernel source."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fast_issue.json")))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        sha = _sha16(os.path.join(ROOT, "weiner_slamit_v2_amd", "csrc", "orb_kernels.hip"))
+        rel = os.path.relpath(files[-1], ROOT)
+        if doc.get("kernel_src_sha16") != sha:
+            return {"lane_ops_per_px": None, "source": "%s was taken on another version of csrc/orb_kernels.hip (%s, now %s)" % (rel, doc.get("kernel_src_sha16"), sha)}
+        k = doc["vga"]
+        valu_per_frame = k["SQ_INSTS_VALU_per_launch"] / k["frames_per_launch"]
+        lane_ops_px = 64.0 * valu_per_frame / pixels_per_frame
+        achieved = 64.0 * valu_per_frame * batch / (fast_avg_ms * 1e-3) / 1e12 if fast_avg_ms > 0 else 0.0
+        out = {"lane_ops_per_px": round(lane_ops_px, 2), "valu_wave_instructions_per_frame": round(valu_per_frame),
+               "achieved_Tlaneops": round(achieved, 2), "peak_Tlaneops": VALU_PEAK_TLANEOPS, "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
+               "source": "%s (rocprofv3 --pmc SQ_INSTS_VALU on the shipped kernel, kernel source %s) x this run's launch time" % (rel, sha)}
+        if "floor" in doc:
+            out["floor_lane_ops_per_px"] = doc["floor"]["lane_ops_per_px"]
+            out["floor_derivation"] = doc["floor"]["derivation"]
+        return out
+    except Exception as e:
+        return {"lane_ops_per_px": None, "source": "unreadable %s: %r" % (files[-1], e)}
+
+
+def host_api_latency(fa, fb):
+    """SURVEY 8(d)'s latency figures through the HOST-POINTER C-ABI (pageable upload + kernels + download, what one Tracking
+    thread sees): one VGA frame, a batch of 64 VGA frames, one 1000 x 1000 best/second match.  Medians, milliseconds."""
+    from weiner_slamit_v2_amd import api
+
+    def med(fn, n):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return round(statistics.median(ts), 4)
+
+    e1 = api.ORBextractor(1000, 1.2, NLEVELS, 20, 7, max_batch=1)
+    e64 = api.ORBextractor(1000, 1.2, NLEVELS, 20, 7, max_batch=64)
+    batch = np.stack([fa[i % len(fa)] for i in range(64)])
+    _, da = e1(fa[0])
+    _, db = e1(fb[0])
+    da, db = np.ascontiguousarray(da[:1000]), np.ascontiguousarray(db[:1000])
+    out = {"extract_1_vga_ms": med(lambda: e1(fa[0]), 20),
+           "extract_batch64_ms": med(lambda: e64.extract_batch(batch), 5),
+           "best2_1000x1000_ms": med(lambda: api.ORBmatcher.best2(db, da), 20),
+           "note": "host-pointer C-ABI incl. upload and download (slamit_orb_extract, slamit_orb_extract_batch, slamit_hamming_best2); medians"}
+    del e1, e64
+    return out
+
+
+def roofline_720p(dev, steps=5):
+    """The FAST pass on the geometry north_star's >= 70 % bar is stated on: 64 frames of 1280x720, 2000 features, per launch
+    (BASELINE configs[2]); `steps` extract + match steps after 2 warm-ups, the launch timed with HIP events like the headline's."""
+    import torch
+    from weiner_slamit_v2_amd import api, synth
+
+    w, h, nfeat, bytes_per_frame, cfg = CONFIGS["720p"]
+    B, uniq = 64, 8
+    fa = [synth.synth_frame(w, h, 7000 + i) for i in range(uniq)]
+    fb = [synth.warp_frame(fa[i], 7000 + i) for i in range(uniq)]
+    d_frames = [torch.from_numpy(np.stack([f[i % uniq] for i in range(B)])).to(dev) for f in (fa, fb)]
+    ext = api.ORBextractor(nfeat, 1.2, NLEVELS, 20, 7, device=dev.index, max_batch=B)
+    ext._bind(w, h, B)
+    cap = ext.max_keypoints
+    d_kps = [torch.zeros((B, cap, 7), dtype=torch.float32, device=dev) for _ in range(2)]
+    d_desc = [torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_n = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_idx, d_best, d_second = (torch.zeros((B, cap), dtype=torch.int32, device=dev) for _ in range(3))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step(k):
+        ext.extract_batch_dev(d_frames[k & 1], d_kps[k & 1], d_desc[k & 1], d_n[k & 1], stream=stream)
+        api.ORBmatcher.best2_batch_dev(d_desc[k & 1], d_n[k & 1], d_desc[(k - 1) & 1], d_n[(k - 1) & 1], d_idx, d_best, d_second,
+                                       cap, device=dev.index, stream=stream)
+    for k in range(2):
+        step(k)
+    torch.cuda.synchronize(dev)
+    ext.profile(2)   # events around every launch of the FAST kernel
+    t0 = time.perf_counter()
+    for k in range(2, 2 + steps):
+        step(k)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    fast_ms, calls = ext.profile(0)["fast"]
+    avg = fast_ms / max(calls, 1)
+    achieved = bytes_per_frame * B / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+    assert (d_n[(steps + 1) & 1].cpu().numpy() >= nfeat).all()
+    return {"workload": "BASELINE %s: 64 frames of 1280x720 per launch, 2000 features" % cfg, "kernel": "fast_cells_kernel", "bound": "hbm",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "avg_launch_ms": round(avg, 5), "launches": calls, "algorithmic_bytes_per_launch": bytes_per_frame * B, "traffic": None,
+            "frames_per_s": round(B * steps / el, 1), "ms_per_step": round(1e3 * el / steps, 4),
+            "note": "events around every launch drain the pipeline: frames_per_s here is a lower bound (bench.py --config 720p times the step)"}
 
 
 def cpu_info():
@@ -195,33 +299,55 @@ def ba_secondary(device, steps, with_cpu=True):
     try:
         from weiner_slamit_v2_amd import api, synth
         out = {"metric": "local-BA LM iterations/sec (50 KF, 2000 pts; schedule 5 robust + 10 plain)", "unit": "iters/s",
-               "dtype": "f64", "note": "end to end through the host-pointer C-ABI (upload + solve + download)"}
+               "dtype": "f64", "note": "end to end through the host-pointer C-ABI (upload + solve + download); value = median of the single-window "
+               "solves; batches hold DIFFERENT windows (seeds 12345 + i)"}
         for name, obs in (("window8", 8), ("dense", None)):
-            prob = synth.synth_ba(50, 2000, obs)
-            ne = len(prob["edge_kf"])
+            # 64 DIFFERENT windows (seeds 12345 + i: same geometry, own noise and outliers), so that the windows of a batch
+            # take different numbers of LM trials and do not run in lock step; the single-window figures use seed 12345
+            probs = [synth.synth_ba(50, 2000, obs, seed=12345 + i) for i in range(64)]
+            prob = probs[0]
+            ne = max(len(q["edge_kf"]) for q in probs)
             opt = api.Optimizer(64, 2048, ne + 64, 8, device)
             opt.LocalBundleAdjustment(prob)  # warm-up
-            reps = max(3, min(steps, 10))
-            t0 = time.perf_counter()
-            its = 0
+            reps = max(5, min(steps, 10))
+            its, ts = 0, []
             for _ in range(reps):
+                t0 = time.perf_counter()
                 r = opt.LocalBundleAdjustment(prob)
-                its += sum(r["stats"]["n_its"])
-            el = time.perf_counter() - t0
-            opt.LocalBundleAdjustmentBatch([prob] * 8)
+                ts.append(time.perf_counter() - t0)
+                its = sum(r["stats"]["n_its"])
+            el = statistics.median(ts)
+            opt.LocalBundleAdjustmentBatch(probs[:8])
             t1 = time.perf_counter()
-            rb = opt.LocalBundleAdjustmentBatch([prob] * 8)
+            rb = opt.LocalBundleAdjustmentBatch(probs[:8])
             elb = time.perf_counter() - t1
-            entry = {"edges": ne, "value": round(its / el, 1), "ms_per_window": round(1e3 * el / reps, 3),
+            entry = {"edges": len(prob["edge_kf"]), "value": round(its / el, 1), "ms_per_window": round(1e3 * el, 3),
+                     "ms_per_window_samples": [round(1e3 * t, 3) for t in ts],
                      "batch8_value": round(sum(sum(x["stats"]["n_its"]) for x in rb) / elb, 1)}
+            # one profiled solve (events between the phases of every LM slot: slower, not part of the timings above)
+            opt.profile(True)
+            opt.LocalBundleAdjustment(prob)
+            pr = opt.profile_read()
+            opt.profile(False)
+            schur_ms = pr["phase_ms"]["schur"] / max(pr["slots"], 1)
+            algo = SCHUR_ALGO_MFLOP[name] * 1e6 / (schur_ms * 1e-3) / 1e12 if schur_ms > 0 else 0.0
+            entry["phases_ms_per_slot"] = {k: round(v / max(pr["slots"], 1), 4) for k, v in pr["phase_ms"].items()}
+            entry["slots"] = pr["slots"]
+            entry["roofline"] = {"kernel": "k_schur_pose + k_schur_reduce (the Schur-complement phase of an LM slot)", "bound": "mfma",
+                                 "achieved": round(algo, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(algo / FP64_MFMA_PEAK_TFLOPS, 5),
+                                 "algorithmic_mflop_per_trial": SCHUR_ALGO_MFLOP[name], "executed_mflop_per_trial": round(pr["schur_exec_mflop"], 1),
+                                 "executed_over_algorithmic": round(pr["schur_exec_mflop"] / SCHUR_ALGO_MFLOP[name], 2),
+                                 "avg_phase_ms": round(schur_ms, 5), "traffic": None,
+                                 "timing": "HIP events around the phase in a separate profiled solve (slamit_ba_profile), one window"}
             opt.close()
             opt = api.Optimizer(64, 2048, ne + 64, 64, device)   # also a batch of 64 windows per GPU
-            opt.LocalBundleAdjustmentBatch([prob] * 64)
+            opt.LocalBundleAdjustmentBatch(probs)
             t1 = time.perf_counter()
-            rb = opt.LocalBundleAdjustmentBatch([prob] * 64)
+            rb = opt.LocalBundleAdjustmentBatch(probs)
             elb = time.perf_counter() - t1
             entry["batch64_value"] = round(sum(sum(x["stats"]["n_its"]) for x in rb) / elb, 1)
-            # Schur product: one dense 2 * Npad^2/2 * Kpad flop MFMA launch per LM trial
+            trials = [sum(sum(x["stats"]["trials"][sg]) for sg in range(2)) for x in rb]
+            entry["batch64_trials_min_max"] = [min(trials), max(trials)]
             if with_cpu:
                 entry["cpu_baseline"] = cpu_baseline_ba(prob)
                 entry["speedup_vs_cpu_1core"] = round(entry["value"] / entry["cpu_baseline"]["value"], 1)
@@ -242,6 +368,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=5, help="the --steps-long timed region is repeated this many times, each bracketed by barrier + "
+                    "synchronize; ms_per_step / value are the MEDIAN region's (SURVEY 8d), every region's figure is in repetitions_ms_per_step")
     # 256 streams per step: per-frame cost keeps falling with the batch (launch floor, ramp and tail of ~14 launches per step, the
     # octree's one long workgroup per frame, and the side stream's overlap all improve): 64 -> 218k frames/s, 128 -> 253k,
     # 256 -> 261k, 512 -> ~270k on one MI355X; 256 keeps a step at one millisecond
@@ -252,6 +380,7 @@ def main():
                     help="synthetic frame content (synth.synth_frame): 'rich' is the benchmark's workload (about one pixel in eight is a FAST corner); "
                          "'sparse' has a few percent of corners and shows how much the FAST pass depends on content (DESIGN.md section 5)")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline_720p and latency blocks (A/B and profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real runs; gloo only to rehearse the multi-rank flow with ranks sharing one GPU")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="vga",
@@ -381,30 +510,39 @@ def main():
         step(k)
     torch.cuda.synchronize(dev)
     ba_its[0] = 0
-    ext.profile(5)   # timed region: events around the dominant kernel (FAST) only, on every 4th step
+    ext.profile(5)   # timed regions: events around the dominant kernel (FAST) only, on every 4th step
     m0 = torch.cuda.Event(enable_timing=True)
     m1 = torch.cuda.Event(enable_timing=True)
     match_ms = 0.0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        step(k)
+    reps = max(1, args.reps if not pipeline else min(args.reps, 3))
+    regions, ba_regions = [], []
     last_slots = None
-    if world > 1 and not pipeline:
-        gather.flush()   # the last step's summary is part of the timed work
-    if pipeline:
-        last_slots = slots.flush()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    ba_its_timed = ba_its[0]
+    k_next = args.warmup
+    for rep in range(reps):   # every region: EXACTLY --steps steps between barrier + synchronize pairs
+        ba_its[0] = 0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(k_next, k_next + args.steps):
+            step(k)
+        k_next += args.steps
+        if world > 1 and not pipeline:
+            gather.flush()   # the last step's summary is part of the timed work
+        if pipeline:
+            last_slots = slots.flush()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        regions.append(shard.max_over_ranks(time.perf_counter() - t0, cdev, world))
+        ba_regions.append(ba_its[0])
+    mid = sorted(range(reps), key=lambda i: regions[i])[reps // 2]   # the median region (same index on every rank: the times are the rank maxima)
+    elapsed = regions[mid]
+    ba_its_timed = ba_regions[mid]
     stages = ext.profile(1)
     # per-stage breakdown: a separate, untimed pass with events around every stage
-    for k in range(args.warmup + args.steps, args.warmup + args.steps + (1 if pipeline else 5)):
+    for k in range(k_next, k_next + (1 if pipeline else 5)):
         step(k)
     if world > 1 and not pipeline:
         gather.flush()
@@ -422,10 +560,8 @@ def main():
     torch.cuda.synchronize(dev)
     match_ms = m0.elapsed_time(m1) / 5
 
-    elapsed = shard.max_over_ranks(elapsed, cdev, world)
-
     # sanity of the timed work: every frame produced its keypoints and matches
-    n_last = d_n[(args.warmup + args.steps - 1) % NBUF].cpu().numpy()
+    n_last = d_n[(k_next - 1) % NBUF].cpu().numpy()
     assert (n_last >= NFEAT).all(), "extractor returned too few keypoints: %s" % n_last[:8]
     if pipeline:   # every stream's slot arrived on this rank, with its keypoints, descriptors and BA poses
         hdr = slots.header(last_slots).cpu().numpy()
@@ -447,6 +583,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "repetitions": reps,
+            "repetitions_ms_per_step": [round(1e3 * t / args.steps, 4) for t in regions],
+            "timing": "median of %d repetitions of the %d-step region, each bracketed by barrier + synchronize (max over ranks)" % (reps, args.steps),
             "higher_is_better": True,
             "scaling": "strong" if pipeline else "weak",
             "vs_baseline": None,
@@ -465,7 +604,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(fast_avg_ms, 5), "launches": fast_calls,
                          "timing": "HIP events on the launch stream around every 4th launch of the timed region (an event pair drains the pipeline for ~20 us)",
-                         "algorithmic_bytes_per_launch": FAST_BYTES_PER_FRAME * B},
+                         "algorithmic_bytes_per_launch": FAST_BYTES_PER_FRAME * B,
+                         "valu": measured_valu(B, fast_avg_ms, FAST_BYTES_PER_FRAME) if args.config == "vga" else None},
             "stage_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in all_stages.items()},
             "match_ms_per_step": round(match_ms, 4),
         }
@@ -477,6 +617,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(fa, fb, NFEAT)
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(fa, fb, NFEAT)
+        if world == 1 and args.config == "vga" and not args.no_extras:
+            # the driver's record also carries: the geometry the >= 70 % bar is stated on, and the host-pointer latencies
+            try:
+                out["roofline_720p"] = roofline_720p(dev)
+            except Exception as e:
+                out["roofline_720p"] = {"error": repr(e)}
+            try:
+                out["latency"] = host_api_latency(fa, fb)
+            except Exception as e:
+                out["latency"] = {"error": repr(e)}
         if not args.no_ba and world == 1 and not pipeline:
             out["secondary"] = ba_secondary(dev.index, args.steps, with_cpu=not args.no_cpu)
         print(json.dumps(out), flush=True)

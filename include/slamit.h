@@ -383,6 +383,23 @@ int slamit_ba_solve(slamit_ba* h, const slamit_ba_problem* prob, const slamit_ba
 int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs,
                           const slamit_ba_opts* opts, slamit_ba_result* results);
 
+/* Per-phase device time of the LM trial slots -- the analogue of g2o's G2OBatchStatistics (Thirdparty/g2o/g2o/core/batch_stats.h:39-77:
+ * timeLinearize + timeQuadraticForm, timeSchurComplement, timeLinearSolver, timeUpdate, timeResiduals), which the reference never
+ * switches on.  After slamit_ba_profile(h, 1) every solve on the handle records HIP events at the phase boundaries of each slot
+ * (an event between two kernels drains the pipeline: such a solve runs slower and is not for timed runs);
+ * slamit_ba_profile_read returns the sums over the slots of the LAST profiled solve (all windows of a batch run a phase in one launch). */
+#define SLAMIT_BA_PHASES 5
+typedef struct slamit_ba_profile_out {
+    double phase_ms[SLAMIT_BA_PHASES]; /* 0 linearise + quadratic form + damping, 1 Schur complement (product + reduction),
+                                          2 reduced solve (LDLt), 3 update (back-substitution + oplus), 4 residuals + LM decision */
+    int32_t slots;                     /* LM trial slots queued */
+    int32_t nwin;
+    double schur_exec_mflop;           /* flops (1e6) the Schur product executes per trial, summed over the windows: its tile granules,
+                                          against the algorithmic count of SURVEY.md 8(d) */
+} slamit_ba_profile_out;
+int slamit_ba_profile(slamit_ba* h, int on);
+int slamit_ba_profile_read(slamit_ba* h, slamit_ba_profile_out* out);
+
 /* ---- Pose-only optimisation (SURVEY.md §8f "next" rank 1) ----------------------------------
  * Optimizer::PoseOptimization (src/Optimizer.cc:239-451): one SE3 pose, n unary reprojection edges
  * (g2o EdgeSE3ProjectXYZOnlyPose, Thirdparty/g2o/g2o/types/types_six_dof_expmap.{h:143-170,cpp:266-288}),

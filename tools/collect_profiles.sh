@@ -8,7 +8,7 @@ export PYTHONPATH=$PWD TMPDIR=/tmp
 TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-B="python3 bench.py --no-ba --no-cpu"
+B="python3 bench.py --no-ba --no-cpu --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 10 > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace720 -- $B --config 720p --steps 6 > $OUT/trace720.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B --steps 3 --warmup 1 > $OUT/fetch.log 2>&1

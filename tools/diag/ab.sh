@@ -3,6 +3,6 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
 for rep in 1 2; do
   for lib in "$@"; do
-    SLAMIT_LIB=$PWD/$lib python3 bench.py --no-ba --no-cpu --steps 40 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', round(d['value']), d['ms_per_step'], d['stage_ms_per_step'], d['match_ms_per_step'])"
+    SLAMIT_LIB=$PWD/$lib python3 bench.py --no-ba --no-cpu --no-extras --steps 40 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', round(d['value']), d['ms_per_step'], d['stage_ms_per_step'], d['match_ms_per_step'])"
   done
 done

@@ -3,7 +3,7 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
 pat=${1:-hamming}; shift
 rm -rf gpurun_out/ktrace
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ktrace -- python3 bench.py --no-cpu --no-ba --steps 6 --warmup 2 "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ktrace -- python3 bench.py --no-cpu --no-ba --no-extras --steps 6 --warmup 2 "$@" > /dev/null 2>&1
 f=$(ls gpurun_out/ktrace/*/*kernel_stats.csv | head -1)
 python3 - "$f" "$pat" <<'PY'
 import csv, sys

@@ -113,6 +113,13 @@ class Camera(C.Structure):
                 ("k2", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("k3", C.c_float)]
 
 
+class BaProfile(C.Structure):
+    _fields_ = [("phase_ms", C.c_double * 5), ("slots", C.c_int32), ("nwin", C.c_int32), ("schur_exec_mflop", C.c_double)]
+
+
+BA_PHASES = ("linearize", "schur", "solve", "update", "residuals")   # slamit_ba_profile_out.phase_ms
+
+
 class PoseProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("pose", C.c_void_p), ("intr", C.c_void_p), ("xw", C.c_void_p),
                 ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p)]
@@ -131,7 +138,7 @@ EXPORTS = [
     "slamit_orb_debug_candidates", "slamit_orb_debug_blurred", "slamit_orb_profile", "slamit_hamming_best2", "slamit_hamming_best2_batch_dev",
     "slamit_hamming_matrix", "slamit_distinctive_batch", "slamit_guided_search", "slamit_guided_search_workspace", "slamit_guided_search_batch_dev", "slamit_bow_search", "slamit_undistort_points", "slamit_frame_finish",
     "slamit_frame_finish_batch_dev", "slamit_ba_create", "slamit_ba_destroy", "slamit_ba_solve",
-    "slamit_ba_solve_batch", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_sim3_optimize", "slamit_sim3_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count", "slamit_set_device", "slamit_release_thread_scratch",
+    "slamit_ba_solve_batch", "slamit_ba_profile", "slamit_ba_profile_read", "slamit_pose_optimize", "slamit_pose_optimize_batch", "slamit_sim3_optimize", "slamit_sim3_optimize_batch", "slamit_last_error", "slamit_version", "slamit_device_count", "slamit_set_device", "slamit_release_thread_scratch",
 ]
 
 
@@ -187,6 +194,9 @@ def lib():
             L.slamit_ba_destroy.restype = None
             L.slamit_ba_solve.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaOpts), C.POINTER(BaResult)]
             L.slamit_ba_solve_batch.argtypes = [vp, i32, C.POINTER(BaProblem), C.POINTER(BaOpts), C.POINTER(BaResult)]
+            if hasattr(L, "slamit_ba_profile"):   # absent from round-2 libraries loaded through SLAMIT_LIB for A/B runs
+                L.slamit_ba_profile.argtypes = [vp, i32]
+                L.slamit_ba_profile_read.argtypes = [vp, C.POINTER(BaProfile)]
         if hasattr(L, "slamit_pose_optimize_batch"):
             L.slamit_pose_optimize_batch.argtypes = [i32, i32, C.POINTER(PoseProblem), C.POINTER(PoseResult)]
             L.slamit_pose_optimize.argtypes = [i32, C.POINTER(PoseProblem), C.POINTER(PoseResult)]
@@ -597,6 +607,18 @@ class Optimizer:
             self.close()
         except Exception:
             pass
+
+    def profile(self, on=True):
+        """Per-phase timing of the following solves (slamit_ba_profile): events between the phases of every LM slot."""
+        _check(lib().slamit_ba_profile(self._h, 1 if on else 0), "slamit_ba_profile")
+
+    def profile_read(self):
+        """Phase sums of the last profiled solve: {"phase_ms": {linearize, schur, solve, update, residuals}, "slots", "nwin",
+        "schur_exec_mflop"} — the analogue of g2o's G2OBatchStatistics."""
+        o = BaProfile()
+        _check(lib().slamit_ba_profile_read(self._h, C.byref(o)), "slamit_ba_profile_read")
+        return {"phase_ms": dict(zip(BA_PHASES, [float(v) for v in o.phase_ms])), "slots": int(o.slots), "nwin": int(o.nwin),
+                "schur_exec_mflop": float(o.schur_exec_mflop)}
 
     @staticmethod
     def _result(n_kf, n_pt, n_e):

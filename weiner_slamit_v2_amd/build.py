@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslamit_hip.so")
-SOURCES = ["slamit_misc.hip", "orb_kernels.hip", "orb_fast_strip.hip", "orb_api.hip", "hamming.hip", "ba_kernels.hip", "ba_api.hip", "pose.hip", "search.hip", "frame.hip", "bow.hip", "sim3.hip"]
+SOURCES = ["slamit_misc.hip", "orb_kernels.hip", "orb_api.hip", "hamming.hip", "ba_kernels.hip", "ba_api.hip", "pose.hip", "search.hip", "frame.hip", "bow.hip", "sim3.hip"]
 # BA is fp64 with a 1e-5 tolerance, not bit-exact: let the compiler fuse multiply-adds there
 # hamming.hip: the i8 MFMA results feed VALU min / median directly, so its accumulators stay in VGPRs (no v_accvgpr moves)
 PER_FILE = {"ba_kernels.hip": ["-ffp-contract=fast"], "pose.hip": ["-ffp-contract=fast"],

@@ -23,7 +23,7 @@ size_t bak_ldlt_smem(int Npad);
 hipError_t bak_prepare(int Npad);
 void bak_import(hipStream_t st, BaWin* wins, const BaIo* io, int max_kf, int max_pt, int max_edge, int Npad, int nwin);
 void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int stage, int max_it, int robust, bool gate);
-void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first);
+void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, hipEvent_t* ev);
 void bak_final(hipStream_t st, BaWin* wins, const BaIo* io, int nwin, int max_kf, int max_pt, int max_edge);
 
 static_assert(BA_MAX_ITS == SLAMIT_BA_MAX_ITS, "stats capacity");
@@ -47,6 +47,10 @@ struct slamit_ba {
     BaIo* d_io;                // max_batch
     uint8_t* h_pin;            // pinned: every window's packed inputs, then outputs, then 2 x max_batch LM states
     size_t pin_bytes;
+    // slamit_ba_profile: six timing events per LM slot of the current solve, and the phase sums of the last profiled one
+    bool prof;
+    std::vector<hipEvent_t> pev;
+    slamit_ba_profile_out prof_last;
 };
 
 namespace {
@@ -159,6 +163,7 @@ void slamit_ba_destroy(slamit_ba* h) {
     hipFree(h->d_slab); hipFree(h->d_wins); hipFree(h->d_states); hipFree(h->d_io);
     if (h->h_pin) hipHostFree(h->h_pin);
     for (int i = 0; i < 2; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->pev) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -207,6 +212,7 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
     std::vector<BaWin> wins(nwin);
     std::vector<BaIo> io(nwin);
     std::vector<std::vector<int32_t> > perm(nwin);   // device point index -> caller's point index
+    std::vector<double> exec_mflop(nwin, 0.0);       // what the Schur product multiplies per trial (slamit_ba_profile_out)
     // per-window preparation (structure, CSR lists, packing into the pinned block) is host work of ~10 ns per edge: windows
     // are independent, so a batch is prepared by a few host threads; the copies are queued afterwards, in order
     auto prepare = [&](int b) {
@@ -270,6 +276,9 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
                 w.tile_alo[t] = lo; w.tile_ahi[t] = hi; w.tile_blo[t] = lo; w.tile_bhi[t] = hi;
                 if (w.nS >= BA_TILE * t && w.nS < BA_TILE * (t + 1)) { w.tile_blo[t] = 0; w.tile_bhi[t] = kmax; }   // row nS of GB = bl of every point
             }
+            for (int I = 0; I < T; ++I)   // the product's granule: 64 x 64 tile pairs (I <= J) over the k range both have non-zeros in
+                for (int J = I; J < T; ++J)
+                    exec_mflop[b] += 2.0 * BA_TILE * BA_TILE * std::max(0, std::min(w.tile_ahi[I], w.tile_bhi[J]) - std::max(w.tile_alo[I], w.tile_blo[J])) * 1e-6;
             // LDLt: row envelope.  first[r] = 6 * fcol[r / 6]; panel i (columns 32 i ..) only touches rows r with first[r] < 32 i + 32
             const int n = w.nS;
             for (int i = 0; i < BA_MAX_PANELS; ++i) { w.panel_hi[i] = (int16_t)std::max(n - 1, 0); w.back_lo[i] = 0; }
@@ -339,6 +348,17 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
     // (Chunks of two throughout queued 20 slots for the 14 trials of a window-8 solve.)
     BaState* hs[2] = {reinterpret_cast<BaState*>(h->h_pin + st_off), reinterpret_cast<BaState*>(h->h_pin + st_off) + nwin};
     bool stopped = opts->stop && *opts->stop;  // :655-657
+    size_t pev_used = 0;   // profiling solves: six events per queued slot
+    auto slot_events = [&]() -> hipEvent_t* {
+        if (!h->prof) return nullptr;
+        while (h->pev.size() < pev_used + 6) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            h->pev.push_back(e);
+        }
+        pev_used += 6;
+        return h->pev.data() + pev_used - 6;
+    };
     for (int stage = 0; stage < 2 && !stopped; ++stage) {
         const int its = stage == 0 ? opts->its_robust : opts->its_final;
         bak_stage_begin(st, h->d_wins, nwin, me, stage, its, stage == 0 ? 1 : 0, stage == 1);
@@ -354,7 +374,7 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
                 const bool was_first = first;
                 first = false;
                 static const bool no_fuse = getenv("SLAMIT_BA_NO_FUSE") && atoi(getenv("SLAMIT_BA_NO_FUSE"));   // A/B runs: every slot as the first
-                for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad, (was_first && sl == 0) || no_fuse);
+                for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad, (was_first && sl == 0) || no_fuse, slot_events());
                 budget -= nslots;
                 HIP_TRY(hipMemcpyAsync(hs[cur], h->d_states, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipEventRecord(h->ev[cur], st));
@@ -376,6 +396,17 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
         HIP_TRY(hipMemcpyAsync(h->h_pin + out_off[b], h->d_slab + (size_t)b * h->win_bytes + dio[b].out_off, dio[b].bytes - dio[b].out_off,
                                hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (h->prof) {
+        slamit_ba_profile_out& O = h->prof_last;
+        memset(&O, 0, sizeof(O));
+        O.nwin = nwin; O.slots = (int32_t)(pev_used / 6);
+        for (size_t s0 = 0; s0 + 6 <= pev_used; s0 += 6)
+            for (int ph = 0; ph < SLAMIT_BA_PHASES; ++ph) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, h->pev[s0 + ph], h->pev[s0 + ph + 1]) == hipSuccess) O.phase_ms[ph] += ms;
+            }
+        for (int b = 0; b < nwin; ++b) O.schur_exec_mflop += exec_mflop[b];
+    }
     for (int b = 0; b < nwin; ++b) {
         const slamit_ba_problem& P = probs[b];
         slamit_ba_result& R = results[b];
@@ -412,6 +443,18 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
 
 int slamit_ba_solve(slamit_ba* h, const slamit_ba_problem* prob, const slamit_ba_opts* opts, slamit_ba_result* res) {
     return slamit_ba_solve_batch(h, 1, prob, opts, res);
+}
+
+int slamit_ba_profile(slamit_ba* h, int on) {
+    if (!h) return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_profile: null handle");
+    h->prof = on != 0;
+    return SLAMIT_OK;
+}
+
+int slamit_ba_profile_read(slamit_ba* h, slamit_ba_profile_out* out) {
+    if (!h || !out) return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_profile_read: bad argument");
+    *out = h->prof_last;
+    return SLAMIT_OK;
 }
 
 }  // extern "C"

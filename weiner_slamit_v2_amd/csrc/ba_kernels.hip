@@ -1527,8 +1527,11 @@ void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int st
 // (`first`: the first slot of a stage, whose lambda comes out of the reductions; every later slot runs them and the
 // damping in one launch, the pose blocks ride with the Schur product, and the iteration bookkeeping is left to k_ldlt_solve: 7 launches
 // instead of 11)
-void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first) {
+// `ev` (profiling solves only, slamit_ba_profile): six events recorded at the phase boundaries of the slot -- before the
+// linearisation, after it, after the Schur complement, after the reduced solve, after the update, after residuals + decision
+void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, hipEvent_t* ev) {
     const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt * BA_PG + 255) / 256, nwin);
+    if (ev) (void)hipEventRecord(ev[0], st);
     if (first) {
         hipLaunchKernelGGL(k_linearize, ge, dim3(256), 0, st, wins);
         hipLaunchKernelGGL(k_point_reduce, gp, dim3(256), 0, st, wins);
@@ -1538,15 +1541,20 @@ void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int
     } else {
         hipLaunchKernelGGL(k_point_pass, gp, dim3(256), 0, st, wins);
     }
+    if (ev) (void)hipEventRecord(ev[1], st);
     const int T = Npad / BA_TILE, ntiles = T * (T + 1) / 2;
     if (first) hipLaunchKernelGGL(k_schur, dim3(ntiles, BA_SPLITS, nwin), dim3(256), 0, st, wins);
     else hipLaunchKernelGGL(k_schur_pose, dim3(ntiles + (max_kf + BA_SPLITS - 1) / BA_SPLITS, BA_SPLITS, nwin), dim3(256), 0, st, wins, ntiles);
     hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins);
+    if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_ldlt_solve, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);
+    if (ev) (void)hipEventRecord(ev[3], st);
     const int nb = (max_pt * BA_PG > max_kf ? max_pt * BA_PG : max_kf);
     hipLaunchKernelGGL(k_backsub_update, dim3((nb + 255) / 256, nwin), dim3(256), 0, st, wins);
+    if (ev) (void)hipEventRecord(ev[4], st);
     hipLaunchKernelGGL(k_errors, ge, dim3(256), 0, st, wins);
     hipLaunchKernelGGL(k_decide, dim3(1, nwin), dim3(256), 0, st, wins);
+    if (ev) (void)hipEventRecord(ev[5], st);
 }
 
 void bak_final(hipStream_t st, BaWin* wins, const BaIo* io, int nwin, int max_kf, int max_pt, int max_edge) {

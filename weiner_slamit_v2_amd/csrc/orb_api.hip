@@ -44,18 +44,7 @@ hipError_t orbk_octree_prepare(int node_cap, int key_cap);
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
                  size_t cand_frame_stride, int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
                  OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int key_cap, int nframes,
-                 int level_override, int* fb_count);
-// FAST at iniThFAST as strip-walking waves (orb_fast_strip.hip) + the per-cell kernel over the cells it left empty
-int orbk_fast_strip_jobs(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out);
-bool orbk_fast_strip_supported(const OrbLevel* host_levels, int nlevels);
-size_t orbk_fast_strip_smem();
-void orbk_fast_strip(hipStream_t st, const OrbLevel* host_levels, int nlevels, const uint32_t* d_jobs, int njobs,
-                     const uint8_t* img0, size_t img0_stride, size_t img0_frame, const uint8_t* pyr,
-                     unsigned long long* cand, size_t cand_frame_stride, int* cand_count, uint32_t* fb_list, int* fb_count,
-                     int th, int nframes);
-void orbk_fast_listed(hipStream_t st, const OrbLevel* host_levels, int nlevels, const uint32_t* d_cells, const uint32_t* d_list,
-                      const int* d_list_count, const uint8_t* img0, size_t img0_stride, size_t img0_frame, const uint8_t* pyr,
-                      unsigned long long* cand, size_t cand_frame_stride, int* cand_count, int th, int max_wcell, int max_hcell);
+                 int level_override);
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0, size_t img0_stride,
                    size_t img0_frame, const uint8_t* pyr, OrbLevelKp* lkp, size_t kp_frame_stride,
                    const int* kp_count, int max_kp, int nframes);
@@ -132,12 +121,9 @@ struct slamit_orb {
     uint32_t* d_blur_str; uint32_t* d_blur_edge;   // the same strips split: columns inside the level (blur_stream_kernel) / the rest (orbk_blur_tiles_split)
     int blur_str_base[ORB_MAX_LEVELS + 1], blur_edge_base[ORB_MAX_LEVELS + 1];   // first entry of a level in each table (last: the totals)
     bool blur_stream_on;
-    uint32_t* d_cells;   // FAST cell table (orbk_fast_cells), fast_cells entries of 8 words
+    uint32_t* d_cells;   // FAST cell table (orbk_fast_cells), fast_cells entries of 4 words
     int fast_cells;
-    uint32_t* d_jobs;    // strip FAST job table (orbk_fast_strip_jobs), fast_jobs entries of 8 words; fast_jobs == 0: per-cell kernel only
-    int fast_jobs;
-    uint32_t* d_fb_list; // cells of the current batch whose iniThFAST pass kept nothing: frame << 20 | cell table index
-    int* d_counts;  // cand_count [max_batch][nlevels][ORB_CC_PAD], then kp_count [max_batch][nlevels], then the d_fb_list length on its own line
+    int* d_counts;  // cand_count [max_batch][nlevels][ORB_CC_PAD], then kp_count [max_batch][nlevels]
     bool counters_clean;   // every cand_count is zero (left so by the last call's octree pass)
     OrbLevelKp* d_lkp;
     int* d_tab_i[ORB_MAX_LEVELS][2];      // xofs, yofs per level (level >= 1)
@@ -174,7 +160,7 @@ static void orb_free(slamit_orb* h) {
     if (!h) return;
     SlamitDeviceGuard guard(h->device);
     hipFree(h->d_levels); hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cand); hipFree(h->d_ws_xy);
-    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_jobs); hipFree(h->d_fb_list); hipFree(h->d_blur_tiles); hipFree(h->d_blur_str); hipFree(h->d_blur_edge); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
+    hipFree(h->d_ws_node); hipFree(h->d_counts); hipFree(h->d_cells); hipFree(h->d_blur_tiles); hipFree(h->d_blur_str); hipFree(h->d_blur_edge); hipFree(h->d_lkp); hipFree(h->d_in); hipFree(h->d_out_kps);
     hipFree(h->d_out_desc); hipFree(h->d_out_n); if (h->h_out) hipHostFree(h->h_out); hipFree(h->d_scratch); hipFree(h->d_boxes); hipFree(h->d_tabs);
     for (int l = 0; l < ORB_MAX_LEVELS; ++l)
         for (int a = 0; a < 2; ++a) { hipFree(h->d_tab_i[l][a]); hipFree(h->d_tab_s[l][a]); }
@@ -328,15 +314,6 @@ int slamit_orb_create(const slamit_orb_params* p, int device, slamit_orb** out) 
         h->fast_cells = empty ? 0 : orbk_fast_cells(h->levels.data(), nl, cells);
         ALLOC(h->d_cells, sizeof(uint32_t) * std::max<size_t>(cells.size(), 8));
         if (e == hipSuccess && !cells.empty()) e = hipMemcpy(h->d_cells, cells.data(), sizeof(uint32_t) * cells.size(), hipMemcpyHostToDevice);
-        // strip FAST (orb_fast_strip.hip) is opt-in, SLAMIT_FAST_STRIP=1: bit-identical, but it issues more instructions
-        // than the per-cell kernel (measured) and is kept for A/B runs only
-        std::vector<uint32_t> jobs;
-        h->fast_jobs = 0;
-        if (!empty && getenv("SLAMIT_FAST_STRIP") && orbk_fast_strip_supported(h->levels.data(), nl) && h->fast_cells < (1 << 20) && p->max_batch < 4096)
-            h->fast_jobs = std::max(orbk_fast_strip_jobs(h->levels.data(), nl, jobs), 0);
-        ALLOC(h->d_jobs, sizeof(uint32_t) * std::max<size_t>(jobs.size(), 8));
-        if (e == hipSuccess && h->fast_jobs > 0) e = hipMemcpy(h->d_jobs, jobs.data(), sizeof(uint32_t) * jobs.size(), hipMemcpyHostToDevice);
-        ALLOC(h->d_fb_list, sizeof(uint32_t) * std::max<size_t>((size_t)h->fast_cells * B, 8));
         std::vector<uint32_t> bt;
         h->blur_tiles = empty ? 0 : orbk_blur_tiles(h->levels.data(), nl, bt);
         ALLOC(h->d_blur_tiles, sizeof(uint32_t) * std::max<size_t>(bt.size(), 4));
@@ -537,13 +514,9 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     if (stride >= ((size_t)1 << 24)) return slamit_fail(SLAMIT_ERR_ARG, "slamit_orb_extract_batch_dev: row pitch of 16 MiB or more");   // kernels address rows with 24-bit multiplies
     int* cand_count = h->d_counts;
     int* kp_count = h->d_counts + (size_t)h->p.max_batch * nl * ORB_CC_PAD;
-    int* fb_count = h->d_counts + (((size_t)h->p.max_batch * nl * (ORB_CC_PAD + 1) + ORB_CC_PAD - 1) / ORB_CC_PAD) * ORB_CC_PAD;
     // the candidate counters are zero between calls: the octree pass consumes and re-zeroes them.  Only a call that
     // follows a failed one (or the first) clears them itself.
-    if (!h->counters_clean) {
-        HIP_TRY(hipMemsetAsync(h->d_counts, 0, sizeof(int) * (size_t)h->p.max_batch * nl * ORB_CC_PAD, st));
-        HIP_TRY(hipMemsetAsync(fb_count, 0, sizeof(int) * 2, st));
-    }
+    if (!h->counters_clean) HIP_TRY(hipMemsetAsync(h->d_counts, 0, sizeof(int) * (size_t)h->p.max_batch * nl * ORB_CC_PAD, st));
     h->counters_clean = false;
     // the blur of levels [l0, l1): every strip streams down its columns (blur_stream_kernel; the strips at the left / right edge
     // in their own launch); when the caller's level-0 plane is not 4-byte aligned everything takes the tile kernel
@@ -608,18 +581,8 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     }
     // K2: FAST + NMS + per-cell threshold fallback -> candidate lists
     prof_mark(h, st, ST_FAST, true);
-    const bool strip = h->fast_jobs > 0 && src0_aligned;
-    if (strip) {
-        // iniThFAST pass by strip-walking waves; the cells it leaves without a corner are listed for the minThFAST retry
-        orbk_fast_strip(st, h->levels.data(), nl, h->d_jobs, h->fast_jobs, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
-                        h->cand_frame_stride, cand_count, h->d_fb_list, fb_count, h->p.ini_th_fast, nframes);
-        if (h->p.min_th_fast < h->p.ini_th_fast)
-            orbk_fast_listed(st, h->levels.data(), nl, h->d_cells, h->d_fb_list, fb_count, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
-                             h->cand_frame_stride, cand_count, h->p.min_th_fast, h->max_wcell, h->max_hcell);
-    } else {
-        orbk_fast(st, h->levels.data(), nl, h->d_cells, h->fast_cells, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
-                  h->cand_frame_stride, cand_count, h->p.ini_th_fast, h->p.min_th_fast, h->max_wcell, h->max_hcell, nframes);
-    }
+    orbk_fast(st, h->levels.data(), nl, h->d_cells, h->fast_cells, d_gray, stride, frame_stride, h->d_pyr, h->d_cand,
+              h->cand_frame_stride, cand_count, h->p.ini_th_fast, h->p.min_th_fast, h->max_wcell, h->max_hcell, nframes);
     prof_mark(h, st, ST_FAST, false);
     // K6: blur every level.  Only the descriptor pass reads it, and it only needs the pyramid: it runs on the side stream
     // beside the octree / orientation launches (latency bound: a few hundred workgroups on 256 CUs) and joins before the
@@ -636,7 +599,7 @@ int slamit_orb_extract_batch_dev(slamit_orb* h, const uint8_t* d_gray, size_t st
     // K4: octree
     prof_mark(h, st, ST_OCTREE, true);
     orbk_octree(st, h->d_levels, nl, h->d_cand, h->cand_frame_stride, cand_count, h->d_ws_xy, h->d_ws_node, h->d_lkp,
-                h->kp_frame_stride, kp_count, h->node_cap, h->oct_key_cap, nframes, -1, strip ? fb_count : nullptr);
+                h->kp_frame_stride, kp_count, h->node_cap, h->oct_key_cap, nframes, -1);
     prof_mark(h, st, ST_OCTREE, false);
     // K5: orientation
     prof_mark(h, st, ST_ANGLE, true);

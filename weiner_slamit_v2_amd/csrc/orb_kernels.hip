@@ -434,77 +434,53 @@ __global__ __launch_bounds__(PYR_THREADS) void pyramid_fused_kernel(
 }
 
 // --------------------------------------------------------------------------------------------
-// K2: FAST-9/16 per cell.  One 256-thread workgroup = one cell of one level of one frame.
+// K2: FAST-9/16 per cell (ORBextractor.cc:805-849; cv::FAST_t<16>, cornerScore<16>, NMS).  ONE WAVEFRONT = one cell
+// of one level of one frame, four cells per workgroup, no workgroup barrier.
 //
-// The cell's window (<= 65x65 bytes) is staged in LDS once; every pixel of the scan area gets its
-// INTRINSIC score S = max over the sixteen 9-arcs of min |v - ring| (same sign) - 1, which is what
-// cornerScore<16> returns for any threshold t <= S, and "corner at t" <=> S >= t.  Sliding
-// 9-window max/min over the ring are built from 3-input max/min (v_max3/v_min3).  NMS compares
-// against the 8 neighbours' scores inside the cell's scan area only (cv::FAST zero-fills outside),
-// then the workgroup decides iniThFAST vs minThFAST and appends its keypoints to the
-// (frame, level) candidate list.  A candidate is one u64: (score << 32) | order, where
-// order = (cell << 12) | (y_local << 6) | x_local is the position in the reference's
-// vToDistributeKeys order (cell row, cell col, y, x); the octree only needs that order to break
-// response ties, so the list itself may be unordered.
+// The cell's window (<= 65x65 bytes) is staged in the wave's LDS slice once.  Per attempt (iniThFAST, then minThFAST
+// if the cell kept nothing, ORBextractor.cc:827-833):
+//   A. compass pre-test, byte-parallel on 4 pixels per lane: a 9-arc of the 16-ring always holds two ADJACENT compass
+//      points, so a corner needs two adjacent ones brighter than v + t, or two darker than v - t;
+//   B. the survivors of a step (256 pixels) are appended to ONE entry stack (tile offset, which polarities passed) in raster
+//      order: a lane counts its pixels, a wave prefix sum (DPP) gives its first slot, four predicated stores write them;
+//   C. whenever 128 entries wait they are scored, TWO per lane on packed 16-bit lanes, with the exact
+//      cornerScore: max over the sixteen 9-arcs of (min over the arc) - centre - 1.  A "darker" candidate is scored on
+//      the complemented bytes (255 - v turns it into a "brighter" one with the same score), so both halves run the same
+//      min / max network; a pixel that passed in both polarities is scored as darker and queued again as brighter;
+//      scores >= t go to a byte tile (stored + 1) and the corner to a list;
+//   D. NMS over the listed corners (strict >, 8 neighbours' stored scores; cv::FAST zero-fills outside the cell's scan
+//      area and below t), kept entries compacted in place.
+// A candidate leaves as one u64: (score << 32) | order, order = (cell << 12) | (y_local << 6) | x_local = its position in
+// the reference's vToDistributeKeys (cell row, cell column, y, x); the octree only needs that order to break response
+// ties, so the list itself is unordered.
+//
+// The kernel is bound by the vector instructions a SIMD issues (rocprofv3 SQ counters): every step
+// is wave-synchronous (no s_barrier), appends use ballot + mbcnt with the running count in a scalar register (no LDS
+// atomics), and a wave needs ~5 KB of LDS for the usual <= 40-pixel cells so 7 waves fit per SIMD.
 // --------------------------------------------------------------------------------------------
 #define SC_COL0 4   // scan pixel x sits at LDS column x + 4 in both the image tile and the score tile
 
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
-__device__ __forceinline__ int imin3(int a, int b, int c) { return min(min(a, b), c); }
 
-template <int PITCH>
-__device__ __forceinline__ int fast_score(const uint8_t* t) {
-    // ring in the order of cv::FAST's 16-pattern: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
-    // (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-    int r[16];
-    r[0] = t[3 * PITCH + 0];   r[1] = t[3 * PITCH + 1];   r[2] = t[2 * PITCH + 2];
-    r[3] = t[1 * PITCH + 3];   r[4] = t[3];               r[5] = t[-1 * PITCH + 3];
-    r[6] = t[-2 * PITCH + 2];  r[7] = t[-3 * PITCH + 1];  r[8] = t[-3 * PITCH + 0];
-    r[9] = t[-3 * PITCH - 1];  r[10] = t[-2 * PITCH - 2]; r[11] = t[-1 * PITCH - 3];
-    r[12] = t[-3];             r[13] = t[1 * PITCH - 3];  r[14] = t[2 * PITCH - 2];
-    r[15] = t[3 * PITCH - 1];
-    const int v = t[0];
-    int hi3[16], lo3[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        hi3[k] = imax3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
-        lo3[k] = imin3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
-    }
-    int h9[16], l9[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        h9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
-        l9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-    }
-    // min over arcs of the arc's max; max over arcs of the arc's min (3-input trees)
-    const int dm = imin3(imin3(imin3(h9[0], h9[1], h9[2]), imin3(h9[3], h9[4], h9[5]), imin3(h9[6], h9[7], h9[8])),
-                         imin3(imin3(h9[9], h9[10], h9[11]), imin3(h9[12], h9[13], h9[14]), h9[15]), 255);
-    const int bm = imax3(imax3(imax3(l9[0], l9[1], l9[2]), imax3(l9[3], l9[4], l9[5]), imax3(l9[6], l9[7], l9[8])),
-                         imax3(imax3(l9[9], l9[10], l9[11]), imax3(l9[12], l9[13], l9[14]), l9[15]), 0);
-    return max(v - dm, bm - v) - 1;
-}
-
-// One WAVEFRONT per cell (4 cells per workgroup): every step is wave-synchronous (no s_barrier), list
-// appends use ballot + popcount with the running count in a wave-uniform register (no LDS atomics),
-// and a wave needs < 5 KB of LDS for the usual <= 40-pixel cells so 8 waves fit per SIMD: on gfx950
-// this kernel is bound by instruction ISSUE (~1 instruction / 4 cycles / SIMD, measured with
-// SQ_ACTIVE_INST_ANY), so occupancy that lets SALU/LDS/VMEM issue beside VALU is what pays.
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-#define FAST_LIST_CAP 640   // two stacks of pre-test survivors (brighter / darker), each < 64 left over + <= 256 of a step
+#define FAST_ENT_CAP 386   // pixel entries (u16): < 128 left over + <= 256 of a pre-test step (a pass pops 128 and re-queues at most as many); the last slot takes the stores of pixels that did not pass
 
-// gfx950's three-input packed f16 min / max: two pixels per lane; the lanes hold the integers 0 .. 255 (f16 denormals) and their negatives
+// LDS bytes of one wave: image tile | score tile | pixel entries (u16) | corner / keypoint list (u16)
+__host__ __device__ inline int fast_tile_bytes(int pitch, int tile_rows) { return (tile_rows * pitch + 16 + 15) & ~15; }
+__host__ __device__ inline int fast_sc_bytes(int pitch, int sc_rows) { return (sc_rows * pitch + 15) & ~15; }
+__host__ __device__ inline int fast_wave_bytes(int pitch, int tile_rows, int sc_rows, int kp_cap) {
+    return (fast_tile_bytes(pitch, tile_rows) + fast_sc_bytes(pitch, sc_rows) + 2 * FAST_ENT_CAP + 2 * kp_cap + 15) & ~15;
+}
+
+// gfx950's three-input packed f16 min / max: two pixels per lane; the lanes hold the integers 0 .. 255 as f16 bit patterns
+// (denormals, kept by the default FP mode) and are only compared
 __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t d;
     asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ uint32_t pk_min3_neghi_f16(uint32_t a, uint32_t b, uint32_t c) {   // high halves enter negated
-    uint32_t d;
-    asm("v_pk_minimum3_f16 %0, %1, %2, %3 neg_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
 __device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
@@ -516,6 +492,27 @@ __device__ __forceinline__ uint32_t pk_max_f16(uint32_t a, uint32_t b) {
     uint32_t d;
     asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
+}
+// v + (this lane's bit of `mask`): one v_addc with the mask as carry-in
+__device__ __forceinline__ unsigned add_flag(unsigned v, unsigned long long mask) {
+    unsigned d;
+    unsigned long long carry;
+    asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(d), "=s"(carry) : "v"(v), "s"(mask));
+    return d;
+}
+
+// exclusive prefix sum of `v` over the wavefront: four DPP row shifts scan each 16-lane row, two row broadcasts carry the row
+// totals on (lane 15 -> rows 1 and 3, lane 31 -> rows 2 and 3); `total` = the sum over all lanes (wave-uniform)
+__device__ __forceinline__ int wave_exclusive_scan(int v, int& total) {
+    int incl = v;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);   // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);   // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);   // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);   // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
+    total = __builtin_amdgcn_readlane(incl, 63);
+    return incl - v;
 }
 
 #ifdef FAST_DIAG   // diagnostic builds only (tools/diag): per-phase wave cycles, one record per wave
@@ -546,23 +543,18 @@ __device__ __forceinline__ void fast_cell_wave(
     unsigned long long* __restrict__ cand, size_t cand_frame_stride,
     int* __restrict__ cand_count, int iniTh, int minTh, int tile_rows, int sc_rows, int kp_cap) {
     FD_DECL;
-    // per-wave LDS carve: image tile | score tile | survivor list | keypoint list
-    const int tile_bytes = (tile_rows * PITCH + 16 + 15) & ~15, sc_bytes = sc_rows * PITCH;
-    const int per_wave = (tile_bytes + sc_bytes + 2 * FAST_LIST_CAP + 2 * kp_cap + 15) & ~15;
-    uint8_t* tile = fsm + wv * per_wave;
-    uint8_t* sc = tile + tile_bytes;
-    unsigned short* s_listB = reinterpret_cast<unsigned short*>(sc + sc_bytes);
-    unsigned short* s_listD = s_listB + FAST_LIST_CAP / 2;
-    unsigned short* s_kp = s_listB + FAST_LIST_CAP;
+    uint8_t* tile = fsm + wv * fast_wave_bytes(PITCH, tile_rows, sc_rows, kp_cap);
+    uint8_t* sc = tile + fast_tile_bytes(PITCH, tile_rows);
+    unsigned short* s_ent = reinterpret_cast<unsigned short*>(sc + fast_sc_bytes(PITCH, sc_rows));
+    unsigned short* s_kp = s_ent + FAST_ENT_CAP;
 
-    // the cell's geometry and every division it needs, precomputed on the host (orbk_fast_cells): two scalar
-    // 16-byte loads instead of ~400 instructions of level search and integer division per wave
-    const uint4 ca = cells[2 * cell], cb = cells[2 * cell + 1];
+    // the cell's geometry and the division it needs, precomputed on the host (orbk_fast_cells): one scalar
+    // 16-byte load instead of ~400 instructions of level search and integer division per wave
+    const uint4 ca = cells[cell];
     const int level = (int)(ca.x & 255u), c = (int)(ca.x >> 8);
     const int iniX = (int)(ca.y & 0xFFFFu), iniY = (int)(ca.y >> 16);
     const int cw = (int)(ca.z & 255u), ch = (int)((ca.z >> 8) & 255u);
-    const int nd = (int)((ca.z >> 16) & 255u), rows_per_it = (int)(ca.z >> 24);
-    const unsigned inv_nd = ca.w, inv_g = cb.x, inv_cw = cb.z;   // (cb.y: magic of sw, unused since entries are y << 6 | x)
+    const unsigned inv_g = ca.w;
     const FastLevel& L = tab.lv[level];
     const int sw = cw - 6, sh = ch - 6;  // scan area = FAST's [3, n-3)
 
@@ -573,191 +565,185 @@ __device__ __forceinline__ void fast_cell_wave(
     src += (size_t)iniY * stride + iniX;
 
     // ---- stage the window: window column j -> LDS column j + 1 (so that scan pixel x is at x + 4) ----
-    // Each lane builds one aligned LDS dword from two aligned global dwords (v_alignbyte).  The window
-    // lies >= 15 px inside the image row, so the 8 bytes around it are always inside the row.
     {
-        const unsigned shift = (unsigned)((uintptr_t)(src - 1) & 3);
-        const uint8_t* abase = src - 1 - shift;            // 4-byte aligned iff the row pitch is
-        const bool aligned = (stride & 3) == 0;
-        const int rsub = (int)(__umul24(lane, inv_nd) >> 20), d = lane - rsub * nd;   // nd dwords per row (LDS cols 0 .. cw)
-        if (aligned) {
-            // all global loads of up to 8 row groups are issued before the first LDS store: one memory
-            // round trip per wave instead of one per row group (rows past the window are clamped, not skipped)
-            const int rs = min(rsub, rows_per_it - 1);
-            const unsigned step = __umul24(rows_per_it, stride);
-            for (int r0 = 0; r0 < ch; r0 += 8 * rows_per_it) {
-                uint32_t lo[8], hi[8];
-                const unsigned last = __umul24(ch - 1, stride) + 4u * d;
-                unsigned off = __umul24(r0 + rs, stride) + 4u * d;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t* g = reinterpret_cast<const uint32_t*>(abase + min(off, last));
-                    lo[k] = g[0]; hi[k] = g[1];
-                    off += step;
-                }
-                uint8_t* t = &tile[(r0 + rsub) * PITCH + 4 * d];
-                int r = r0 + rsub;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (rsub < rows_per_it && r < ch)
-                        *reinterpret_cast<uint32_t*>(t) = __builtin_amdgcn_alignbyte(hi[k], lo[k], shift);
-                    t += rows_per_it * PITCH; r += rows_per_it;
-                }
-            }
-        } else {
-            const int npx = cw * ch;
-            for (int p = lane; p < npx; p += WAVE) {
-                const int r = (int)(__umul24(p, inv_cw) >> 20);
-                const int cc = p - r * cw;
-                tile[r * PITCH + cc + 1] = src[__umul24(r, stride) + cc];
-            }
+        // LDS-DMA: a lane moves 16 bytes of a window row straight into the tile (global_load_lds_dwordx4: LDS address =
+        // wave-uniform base + 16 * lane, so lane -> (row, 16-byte chunk) in tile order; the source address is per lane and
+        // need not be aligned: tools/diag/ubench/glds_unaligned.hip).  No VGPR carries pixels, no v_alignbyte, no LDS store
+        // instruction, and a caller's plane of any pitch and alignment takes the same path.  Only chunks that START inside the
+        // window are fetched: the window ends >= 16 pixels before the end of the image row, so a chunk never leaves the row.
+        static_assert(PITCH % 16 == 0, "a tile row is a whole number of 16-byte DMA chunks");
+        constexpr int CPR = PITCH / 16;
+        const int kact = (cw + 1 + 15) >> 4, nch = ch * CPR;
+        for (int c0 = 0; c0 < nch; c0 += WAVE) {
+            const int ci = c0 + lane;
+            const int r = CPR == 3 ? (int)(__umul24(ci, 171) >> 9) : ci / CPR;   // ci < 256: floor(ci / 3)
+            const int k = ci - r * CPR;
+            if (ci < nch && k < kact)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src - 1 + __umul24(r, stride) + 16 * k),
+                                                 (__attribute__((address_space(3))) void*)(tile + 16 * c0), 16, 0, 0);
         }
     }
     {   // zero the rows of the score tile this cell uses (plus the ring around them), 16 bytes per lane
         const int nz = ((sh + 2) * PITCH + 15) >> 4;
         for (int i = lane; i < nz; i += WAVE) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA's LDS writes are ordered for this wave's reads by its own vmcnt wait
     wave_sync_lds();
     FD_STAMP(0);
 
     const int ngrp = (sw + 3) >> 2;          // groups of 4 scan pixels per row
     const int nitems = ngrp * sh;
-    // pre-test mapping: lane -> (row within a step, column group)
+    // pre-test mapping: lane -> (row within a step, column group).  A lane keeps its column group for the whole cell (rps
+    // rows of ngrp groups per step; the 64 % ngrp lanes left over idle): column, tail mask and LDS address are loop invariants
     const int p_rsub = (int)(__umul24(lane, inv_g) >> 20), p_x0 = (lane - p_rsub * ngrp) * 4;
     const int rps = (int)(__umul24(WAVE, inv_g) >> 20);      // WAVE / ngrp rows per step (ngrp <= 16: cells are <= 64 px wide)
     const bool p_active = p_rsub < rps;
     unsigned p_vmask = 0x80808080u;                          // pixels of the row's last group beyond the scan row (0 .. 3) are masked
     if (p_x0 + 4 - sw > 0) p_vmask >>= 8 * (p_x0 + 4 - sw);
+    const unsigned p_vmask6 = p_vmask >> 1;                  // a lane's flag word, per pixel byte: bit 7 = brighter passed, bit 6 = darker passed
 
-    // Two attempts like the reference: FAST at iniThFAST, and only if the cell stays empty, again at
-    // minThFAST (ORBextractor.cc:827-833).  Per attempt:
-    //  A. compass pre-test, 4 pixels per lane with byte-parallel arithmetic (necessary condition: a
-    //     9-arc of the 16-ring always holds two adjacent compass pixels, so two adjacent ones must
-    //     both be brighter than v+t or both darker than v-t); survivors are compacted into a ring list,
-    //     with the polarity that passed (a pixel that passed both is listed twice),
-    //  B. the exact score of the listed pixels, 128 per pass and TWO per lane on packed 16-bit lanes; stored if >= t,
-    //  C. NMS (strict >, 8 neighbours, zeros outside the scan area / below t) byte-parallel over the score tile.
     int th = iniTh;
     int nkp = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        // For bytes a (ring) and c (centre): a - c > t  <=>  a + (255 - c) >= t + 256.  v_lerp_u8 gives
-        // (a + ~c + r) >> 1 per byte with a 9-bit intermediate; with r = parity of t the test becomes
-        // d >= K on bytes, and a second lerp against 256 - K leaves the answer in each byte's MSB.
+        // For bytes a (ring) and c (centre) let D = (a + ~c + r) >> 1 per byte (v_lerp_u8: 9-bit intermediate), r = parity of
+        // T = t + 256.  a - c > t  <=>  a + (255 - c) >= T  <=>  D >= (T + 1) >> 1: a second lerp against 256 - that constant
+        // leaves the answer in the byte's MSB.  c - a > t  <=>  a + (255 - c) <= 254 - t  ==>  D <= K2 = (254 - t + r) >> 1
+        // (a necessary condition: at most one grey level looser, and the exact score decides): the MSB of a lerp of the SAME D
+        // against 255 - K2 says "D > K2", i.e. NOT darker -- the inversion rides in the truth table of the v_bitop3 that
+        // combines the compass points.
         const int T = th + 256;
         const unsigned rnd = (T & 1) ? 0x01010101u : 0u;
-        const int Kv = (T + 1) >> 1;                       // 129..256
-        const unsigned kc = (unsigned)(256 - Kv) * 0x01010101u;
-        int nB = 0, nD = 0;   // survivor stacks: brighter-than-centre / darker-than-centre candidates, entry = y << 6 | x
+        const unsigned kcB = (unsigned)(256 - ((T + 1) >> 1)) * 0x01010101u;
+        const unsigned kcD = (unsigned)(255 - ((254 - th + (T & 1)) >> 1)) * 0x01010101u;
+        int nE = 0;                // pixel entries waiting
         int ncorner = 0;
         bool corner_overflow = false;
-        // a lane keeps its column group for the whole cell (rps rows of ngrp groups per step; the 64 % ngrp lanes left over
-        // idle): column, tail mask and the LDS address are loop invariants and a step costs one add per lane
-        for (int y0 = 0; y0 < sh; y0 += rps) {
-            const int y = y0 + p_rsub;
-            unsigned pb = 0, pd = 0;
-            const unsigned e0 = (unsigned)((y << 6) | p_x0);
-            if (p_active && y < sh) {
-                const int x0 = p_x0;
-                const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(y + 3) * PITCH + x0 + SC_COL0]);
+
+        // scoring: 128 entries (at the end of a cell: whatever is left) off the top of the entry stack, TWO pixels per lane on
+        // packed 16-bit lanes.  Entry = (y * PITCH + x) << 2 | code, code 1 = darker, 2 = brighter, 3 = both (scored as darker now
+        // and queued again as brighter); lanes without an entry score pixel (0, 0) and do not store.
+        auto score_pass = [&](const int cnt) {
+            wave_sync_lds();
+            FD_STAMP(1);
+#ifdef FAST_DIAG
+            fd_surv += cnt;
+#endif
+            const int base = nE - cnt;
+            const bool vlo = lane < cnt, vhi = lane + 64 < cnt;
+            // lanes beyond the count read whatever the stack holds there and score it (a stale entry addresses LDS, nothing else);
+            // they are kept out of every store below
+            const unsigned elo = s_ent[base + lane], ehi = s_ent[base + 64 + lane];
+            const unsigned long long vmlo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
+            const unsigned long long vmhi = cnt >= 128 ? ~0ull : cnt > 64 ? (1ull << (cnt - 64)) - 1ull : 0ull;
+            // y * PITCH + x: top-left corner of the pixel's 7x7 neighbourhood in the tile, less SC_COL0 - 3
+            const unsigned olo = elo >> 2, ohi = ehi >> 2;
+            const uint8_t* qlo = tile + olo + (SC_COL0 - 3);
+            const uint8_t* qhi = tile + ohi + (SC_COL0 - 3);
+            const uint32_t pm = __umul24(((ehi << 16) | elo) & 0x00010001u, 0xFFu);   // 0xFF in the half of an entry scored as "darker": complements its bytes
+#define PX(dx, dy) ((((uint32_t)qhi[((dy) + 3) * PITCH + (dx) + 3] << 16) | (uint32_t)qlo[((dy) + 3) * PITCH + (dx) + 3]) ^ pm)
+            // ring in the order of cv::FAST's 16-pattern: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+            uint32_t r[16];
+            r[0] = PX(0, 3);    r[1] = PX(1, 3);    r[2] = PX(2, 2);    r[3] = PX(3, 1);
+            r[4] = PX(3, 0);    r[5] = PX(3, -1);   r[6] = PX(2, -2);   r[7] = PX(1, -3);
+            r[8] = PX(0, -3);   r[9] = PX(-1, -3);  r[10] = PX(-2, -2); r[11] = PX(-3, -1);
+            r[12] = PX(-3, 0);  r[13] = PX(-3, 1);  r[14] = PX(-2, 2);  r[15] = PX(-1, 3);
+            const uint32_t ctr = PX(0, 0);
+#undef PX
+            uint32_t lo3[16], l9[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lo3[k] = pk_min3_f16(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) l9[k] = pk_min3_f16(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+            const uint32_t m = pk_max_f16(
+                pk_max3_f16(pk_max3_f16(l9[0], l9[1], l9[2]), pk_max3_f16(l9[3], l9[4], l9[5]), pk_max3_f16(l9[6], l9[7], l9[8])),
+                pk_max3_f16(pk_max3_f16(l9[9], l9[10], l9[11]), pk_max3_f16(l9[12], l9[13], l9[14]), l9[15]));
+            // (best arc minimum) - centre = score + 1 in both halves; <= t means "no corner at t"
+            typedef short fast_s2 __attribute__((ext_vector_type(2)));
+            const fast_s2 dd = __builtin_bit_cast(fast_s2, m) - __builtin_bit_cast(fast_s2, ctr);
+            const int dlo = dd.x, dhi = dd.y;
+            const bool tlo = dlo > th, thi = dhi > th;
+            const bool clo = vlo && tlo, chi = vhi && thi;
+            if (clo) sc[olo + (PITCH + SC_COL0)] = (uint8_t)dlo;   // score tile row y + 1, column x + SC_COL0; holds score + 1
+            if (chi) sc[ohi + (PITCH + SC_COL0)] = (uint8_t)dhi;
+            {   // the corners are also listed (in the keypoint array: NMS compacts it in place), so that NMS visits the
+                // ~12 % of the pixels that are corners instead of all of them; a cell with more corners than the
+                // array holds falls back to the pass over the whole score tile
+                // (the masks of the compares themselves, cut to the lanes that hold an entry: a ballot of `clo` would be rebuilt from a select)
+                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(tlo) & vmlo, m1 = __builtin_amdgcn_ballot_w64(thi) & vmhi;
+                const int n0 = __popcll(m0), add = n0 + __popcll(m1);
+                if (ncorner + add <= kp_cap) {
+                    const unsigned p0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+                    const unsigned p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+                    if (clo) (s_kp + ncorner)[p0] = (unsigned short)elo;
+                    if (chi) (s_kp + ncorner + n0)[p1] = (unsigned short)ehi;
+                } else corner_overflow = true;
+                ncorner += add;
+            }
+            nE = base;
+            {   // both polarities passed the pre-test: back on the stack as "brighter" (the stack's top was just popped: the slots are free)
+                const bool blo = vlo && (elo & 3u) == 3u, bhi = vhi && (ehi & 3u) == 3u;
+                const unsigned long long q0 = __builtin_amdgcn_ballot_w64((elo & 3u) == 3u) & vmlo, q1 = __builtin_amdgcn_ballot_w64((ehi & 3u) == 3u) & vmhi;
+                if ((q0 | q1) != 0ull) {
+                    const int b0 = nE, b1 = nE + __popcll(q0);
+                    nE = b1 + __popcll(q1);
+                    if (blo) s_ent[b0 + __builtin_amdgcn_mbcnt_hi((unsigned)(q0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)q0, 0u))] = (unsigned short)(elo - 1u);
+                    if (bhi) s_ent[b1 + __builtin_amdgcn_mbcnt_hi((unsigned)(q1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)q1, 0u))] = (unsigned short)(ehi - 1u);
+                }
+            }
+            // the counters are wave-uniform; say so (a value merged behind one of the predicated stores above would otherwise count
+            // as divergent and drag the loops that test it into exec-mask form)
+            nE = __builtin_amdgcn_readfirstlane(nE);
+            ncorner = __builtin_amdgcn_readfirstlane(ncorner);
+            FD_STAMP(2);
+        };
+
+        unsigned e_base = (unsigned)(p_rsub * PITCH + p_x0) << 2;                  // entry of the lane's pixel 0, less its code
+        const uint8_t* prow = tile + (p_rsub + 3) * PITCH + p_x0 + SC_COL0;         // the group's centre pixels
+        for (int y0 = 0; y0 < sh; y0 += rps, e_base += (unsigned)(rps * PITCH) << 2, prow += rps * PITCH) {
+            unsigned f6 = 0;     // byte j: which polarities pixel j of the lane's group passed in (1 = darker, 2 = brighter, 3 = both)
+            if (p_active && y0 + p_rsub < sh) {
+                const uint32_t* rowc = reinterpret_cast<const uint32_t*>(prow);
                 const unsigned C = rowc[0], Dm = rowc[-1], Dp = rowc[1];
-                const unsigned N = *reinterpret_cast<const uint32_t*>(&tile[y * PITCH + x0 + SC_COL0]);
-                const unsigned S = *reinterpret_cast<const uint32_t*>(&tile[(y + 6) * PITCH + x0 + SC_COL0]);
+                const unsigned N = *reinterpret_cast<const uint32_t*>(prow - 3 * PITCH);
+                const unsigned S = *reinterpret_cast<const uint32_t*>(prow + 3 * PITCH);
                 const unsigned E = __builtin_amdgcn_alignbyte(Dp, C, 3);   // columns x0+3 .. x0+6
                 const unsigned Wv = __builtin_amdgcn_alignbyte(C, Dm, 1);  // columns x0-3 .. x0
                 const unsigned nC = ~C;
-#define BRIGHT(a) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp((a), nC, rnd), kc, 0u)
-#define DARK(a) __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~(a), rnd), kc, 0u)
-                const unsigned bN = BRIGHT(N), bE = BRIGHT(E), bS = BRIGHT(S), bW = BRIGHT(Wv);
-                const unsigned dN = DARK(N), dE = DARK(E), dS = DARK(S), dW = DARK(Wv);
-#undef BRIGHT
-#undef DARK
-                // two adjacent compass points of one polarity: NE | ES | SW | WN == (N | S) & (E | W); v_bitop3 is full rate
-                pb = __builtin_amdgcn_bitop3_b32(bN | bS, bE, bW, 0xE0) & p_vmask;
-                pd = __builtin_amdgcn_bitop3_b32(dN | dS, dE, dW, 0xE0) & p_vmask;
+                const unsigned DN = __builtin_amdgcn_lerp(N, nC, rnd), DE = __builtin_amdgcn_lerp(E, nC, rnd);
+                const unsigned DS = __builtin_amdgcn_lerp(S, nC, rnd), DW = __builtin_amdgcn_lerp(Wv, nC, rnd);
+                const unsigned bN = __builtin_amdgcn_lerp(DN, kcB, 0u), bE = __builtin_amdgcn_lerp(DE, kcB, 0u);
+                const unsigned bS = __builtin_amdgcn_lerp(DS, kcB, 0u), bW = __builtin_amdgcn_lerp(DW, kcB, 0u);
+                const unsigned gN = __builtin_amdgcn_lerp(DN, kcD, 0u), gE = __builtin_amdgcn_lerp(DE, kcD, 0u);
+                const unsigned gS = __builtin_amdgcn_lerp(DS, kcD, 0u), gW = __builtin_amdgcn_lerp(DW, kcD, 0u);
+                // two adjacent compass points of one polarity: NE | ES | SW | WN == (N | S) & (E | W); v_bitop3 is full rate.
+                // Darker, from the inverted flags g: (~gN | ~gS) & (~gE | ~gW) = ~(gN & gS) & ~(gE & gW)
+                const unsigned pb = __builtin_amdgcn_bitop3_b32(bN | bS, bE, bW, 0xE0);
+                const unsigned pd = __builtin_amdgcn_bitop3_b32(gN & gS, gE, gW, 0x07);
+                // only the MSB of each byte of pb / pd is a flag (the lerps leave anything below it)
+                f6 = (unsigned)__builtin_amdgcn_bitop3_b32(pd >> 1, p_vmask6, pb & p_vmask, 0xEA) >> 6;   // (a & b) | c
             }
-            // compaction: one ballot per pixel slot and polarity; a pixel that passed both tests is on both stacks
+            {   // append in RASTER order (lane = row, column group; a lane's pixels left to right): the lanes of a scoring pass then
+                // gather their rings from neighbouring tile dwords -- appended slot by slot (one ballot per pixel slot, all lanes'
+                // pixel 0 first) the same entries cost 2.4 x the LDS bank conflicts and 9 % of the kernel.  A lane counts its
+                // pixels, a wave prefix sum gives its first slot; a pixel that did not pass writes the stack's spare last slot
+                // (a select costs one vector instruction, an exec-mask region scalar ones and a branch)
+                int total;
+                unsigned pos = (unsigned)(nE + wave_exclusive_scan(__popc((f6 | (f6 >> 1)) & 0x01010101u), total));
+                if (total != 0) {
+                    const unsigned g = f6 + 0x0C080400u;         // byte j: 4 j + code = what pixel j adds to e_base (byte selects: SDWA operands)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool pass = ((pb >> (8 * j)) & 0xFFu) != 0u;   // byte select: one v_cmp_ne_u32_sdwa
-                const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
-                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                // no exec-mask region around the store: lanes that did not pass write the stack's spare last slot (a stack never holds
-                // more than 63 + 256 entries); a select costs one vector instruction, the masked region five scalar ones and a branch
-                s_listB[pass ? (unsigned)nB + pos : (unsigned)(FAST_LIST_CAP / 2 - 1)] = (unsigned short)(e0 + j);
-                nB += __popcll(mk);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool pass = ((pd >> (8 * j)) & 0xFFu) != 0u;
-                const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
-                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                s_listD[pass ? (unsigned)nD + pos : (unsigned)(FAST_LIST_CAP / 2 - 1)] = (unsigned short)(e0 + j);
-                nD += __popcll(mk);
-            }
-            // scoring: 64 + 64 candidates per pass off the tops of the stacks, whenever one of them holds 64 (after the
-            // last step: until both are empty).  TWO pixels per lane on packed 16-bit lanes: the low half holds the ring of
-            // a "brighter" candidate, the high half that of a "darker" one, whose values enter the first stage NEGATED
-            // (neg_hi): min / max then compute  max over the 16 arcs of (min over the arc's 9 pixels)  in the low half and
-            // -(min over arcs of max over arc)  in the high half.  The lanes hold the integers 0 .. 255 as f16 bit
-            // patterns (denormals, kept by the default FP mode) and are only compared.
-            const bool last = y0 + rps >= sh;
-            while (nB >= 64 || nD >= 64 || (last && (nB | nD) != 0)) {
-                wave_sync_lds();
-                FD_STAMP(1);
-                const int tb = min(nB, 64), td = min(nD, 64);
-#ifdef FAST_DIAG
-                fd_surv += tb + td;
-#endif
-                const bool vlo = lane < tb, vhi = lane < td;
-                // lanes without an entry score pixel (0, 0) and do not store
-                const unsigned elo = vlo ? s_listB[nB - tb + lane] : 0u;
-                const unsigned ehi = vhi ? s_listD[nD - td + lane] : 0u;
-                const unsigned ylo = elo >> 6, xlo = elo & 63u, yhi = ehi >> 6, xhi = ehi & 63u;
-                // top-left corner of the 7x7 neighbourhood of scan pixel (x, y): tile row y, column x + SC_COL0 - 3
-                const uint8_t* qlo = tile + (__umul24(ylo, PITCH) + xlo + (SC_COL0 - 3));
-                const uint8_t* qhi = tile + (__umul24(yhi, PITCH) + xhi + (SC_COL0 - 3));
-#define PX(dx, dy) (((uint32_t)qhi[((dy) + 3) * PITCH + (dx) + 3] << 16) | (uint32_t)qlo[((dy) + 3) * PITCH + (dx) + 3])
-                uint32_t r[16];
-                r[0] = PX(0, 3);    r[1] = PX(1, 3);    r[2] = PX(2, 2);    r[3] = PX(3, 1);
-                r[4] = PX(3, 0);    r[5] = PX(3, -1);   r[6] = PX(2, -2);   r[7] = PX(1, -3);
-                r[8] = PX(0, -3);   r[9] = PX(-1, -3);  r[10] = PX(-2, -2); r[11] = PX(-3, -1);
-                r[12] = PX(-3, 0);  r[13] = PX(-3, 1);  r[14] = PX(-2, 2);  r[15] = PX(-1, 3);
-                const uint32_t ctr = PX(0, 0);
-#undef PX
-                uint32_t lo3[16], l9[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) lo3[k] = pk_min3_neghi_f16(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) l9[k] = pk_min3_f16(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-                const uint32_t m = pk_max_f16(
-                    pk_max3_f16(pk_max3_f16(l9[0], l9[1], l9[2]), pk_max3_f16(l9[3], l9[4], l9[5]), pk_max3_f16(l9[6], l9[7], l9[8])),
-                    pk_max3_f16(pk_max3_f16(l9[9], l9[10], l9[11]), pk_max3_f16(l9[12], l9[13], l9[14]), l9[15]));
-                // brighter: (best arc minimum) - centre - 1; darker: centre - (best arc maximum) - 1; < t means "no corner at t"
-                const int slo = (int)(m & 255u) - (int)(ctr & 255u) - 1;
-                const int shi = (int)(ctr >> 16) - (int)((m >> 16) & 255u) - 1;
-                const bool clo = vlo && slo >= th, chi = vhi && shi >= th;
-                if (clo) sc[__umul24(ylo + 1u, PITCH) + xlo + SC_COL0] = (uint8_t)slo;
-                if (chi) sc[__umul24(yhi + 1u, PITCH) + xhi + SC_COL0] = (uint8_t)shi;
-                {   // the corners are also listed (in the keypoint array: NMS compacts it in place), so that NMS visits the
-                    // ~12 % of the pixels that are corners instead of all of them; a cell with more corners than the
-                    // array holds falls back to the pass over the whole score tile
-                    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(clo), m1 = __builtin_amdgcn_ballot_w64(chi);
-                    const int n0 = __popcll(m0), add = n0 + __popcll(m1);
-                    if (ncorner + add <= kp_cap) {
-                        const unsigned p0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
-                        const unsigned p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
-                        if (clo) (s_kp + ncorner)[p0] = (unsigned short)elo;
-                        if (chi) (s_kp + ncorner + n0)[p1] = (unsigned short)ehi;
-                    } else corner_overflow = true;
-                    ncorner += add;
+                    for (int j = 0; j < 4; ++j) {
+                        const bool mine = ((f6 >> (8 * j)) & 0xFFu) != 0u;
+                        s_ent[mine ? pos : (unsigned)(FAST_ENT_CAP - 1)] = (unsigned short)(e_base + ((g >> (8 * j)) & 0xFFu));
+                        pos = add_flag(pos, __builtin_amdgcn_ballot_w64(mine));
+                    }
+                    nE += total;
                 }
-                nB -= tb; nD -= td;
-                wave_sync_lds();
-                FD_STAMP(2);
             }
+            const bool last = y0 + rps >= sh;
+            while (nE >= 128 || (last && nE > 0)) score_pass(min(nE, 128));
         }
-        // NMS byte-parallel over the score tile, 4 pixels per lane: n >= s per byte  <=>  MSB of (n + ~s + 1) >> 1.
-        // A pixel below t holds 0 and is beaten by any neighbour; columns / rows around the scan area hold 0.
+        wave_sync_lds();
         nkp = 0;
         if (!corner_overflow) {
             // NMS over the listed corners: strict > against the 8 neighbours' stored scores (0 below t / outside the scan
@@ -768,7 +754,7 @@ __device__ __forceinline__ void fast_cell_wave(
                 unsigned e = 0;
                 if (i < ncorner) {
                     e = s_kp[i];
-                    const uint8_t* q = &sc[__umul24((e >> 6) + 1u, PITCH) + (e & 63u) + SC_COL0];
+                    const uint8_t* q = &sc[(e >> 2) + (PITCH + SC_COL0)];
                     const int v = q[0];
                     int nb = imax3(q[-PITCH - 1], q[-PITCH], q[-PITCH + 1]);
                     nb = imax3(nb, q[-1], q[1]);
@@ -781,13 +767,15 @@ __device__ __forceinline__ void fast_cell_wave(
                 nkp += __popcll(mk);
             }
         } else
+        // NMS byte-parallel over the whole score tile, 4 pixels per lane: n >= s per byte  <=>  MSB of (n + ~s + 1) >> 1.
+        // A pixel below t holds 0 and is beaten by any neighbour; columns / rows around the scan area hold 0.
         for (int i0 = 0; i0 < nitems; i0 += WAVE) {
             const int it = i0 + lane;
             unsigned keep = 0, e0 = 0;
             if (it < nitems) {
                 const int y = (int)(__umul24(it, inv_g) >> 20);
                 const int x0 = (it - y * ngrp) * 4;
-                e0 = (unsigned)((y << 6) | x0);
+                e0 = (unsigned)(y * PITCH + x0) << 2;
                 const uint32_t* s1 = reinterpret_cast<const uint32_t*>(&sc[(y + 1) * PITCH + x0 + SC_COL0]);
                 const uint32_t* s0 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s1) - PITCH);
                 const uint32_t* s2 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s1) + PITCH);
@@ -802,15 +790,16 @@ __device__ __forceinline__ void fast_cell_wave(
                 const uint32_t g3 = __builtin_amdgcn_lerp(cl, ns, one) | __builtin_amdgcn_lerp(cr, ns, one);
                 keep = ~(g1 | g2 | g3) & 0x80808080u;     // pixels beyond the scan row hold 0 and are never kept
             }
-            // two strict maxima are never adjacent, so a group of 4 keeps at most 2 pixels: two ballots compact them
+            // two strict maxima are never adjacent, so a group of 4 keeps at most 2 pixels: two ballots compact them.
+            // The kept pixel's MSB is bit 8 j + 7: its entry is e0 + 4 j
             const int cnt = __popc(keep);
             const unsigned long long b1 = __ballot(cnt >= 1);
             if (b1) {
                 const unsigned long long b2 = __ballot(cnt >= 2);
                 const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, (unsigned)nkp)) +
                                      __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u));
-                if (cnt >= 1) s_kp[pos] = (unsigned short)(e0 + ((__ffs(keep) - 1) >> 3));
-                if (cnt >= 2) s_kp[pos + 1] = (unsigned short)(e0 + ((31 - __clz(keep)) >> 3));
+                if (cnt >= 1) s_kp[pos] = (unsigned short)(e0 + (((unsigned)(__ffs(keep) - 1) >> 1) & 0xCu));
+                if (cnt >= 2) s_kp[pos + 1] = (unsigned short)(e0 + (((unsigned)(31 - __clz(keep)) >> 1) & 0xCu));
                 nkp += __popcll(b1) + __popcll(b2);
             }
         }
@@ -825,9 +814,9 @@ __device__ __forceinline__ void fast_cell_wave(
     base = __shfl(base, 0, WAVE);
     unsigned long long* out = cand + L.cand_off + (size_t)frame * cand_frame_stride;
     for (int i = lane; i < nkp; i += WAVE) {
-        const int p = s_kp[i];
-        const int y = p >> 6, x = p & 63;
-        const unsigned S = sc[(y + 1) * PITCH + x + SC_COL0];
+        const unsigned off = (unsigned)s_kp[i] >> 2;                  // y * PITCH + x
+        const unsigned y = __umul24(off, (1u << 20) / PITCH + 1u) >> 20, x = off - y * PITCH;   // off < 2^13: the 20-bit reciprocal is exact
+        const unsigned S = sc[off + (PITCH + SC_COL0)] - 1u;          // the tile holds score + 1
         const unsigned order = ((unsigned)c << 12) | ((unsigned)(y + 3) << 6) | (unsigned)(x + 3);
         const int o = base + i;
         if (o < L.cand_cap) out[o] = ((unsigned long long)S << 32) | order;
@@ -850,27 +839,6 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     if (cell >= ncells) return;
     fast_cell_wave<PITCH>(fsm, lane, wv, blockIdx.y, cell, tab, cells, nlevels, img0, img0_stride, img0_frame, pyr, cand,
                           cand_frame_stride, cand_count, iniTh, minTh, tile_rows, sc_rows, kp_cap);
-}
-
-// The minThFAST retry of the cells the strip kernel (orb_fast_strip.hip) left without a corner: a fixed grid of waves
-// walks the list of (frame << 20 | cell) entries; every listed cell is processed at the single threshold `th`.
-template <int PITCH>
-__global__ __launch_bounds__(256) void fast_cells_listed_kernel(
-    const FastTab tab, const uint4* __restrict__ cells, int nlevels, const uint32_t* __restrict__ list, const int* __restrict__ list_count,
-    const uint8_t* __restrict__ img0, unsigned img0_stride, size_t img0_frame,
-    const uint8_t* __restrict__ pyr,
-    unsigned long long* __restrict__ cand, size_t cand_frame_stride,
-    int* __restrict__ cand_count, int th, int tile_rows, int sc_rows, int kp_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = *list_count, nwaves = gridDim.x * 4;
-    for (int i = blockIdx.x * 4 + wv; i < n; i += nwaves) {
-        const uint32_t e = list[i];
-        fast_cell_wave<PITCH>(fsm, lane, wv, (int)(e >> 20), (int)(e & 0xFFFFFu), tab, cells, nlevels, img0, img0_stride, img0_frame, pyr,
-                              cand, cand_frame_stride, cand_count, th, th, tile_rows, sc_rows, kp_cap);
-        wave_sync_lds();   // the next cell reuses this wave's LDS slice
-    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1211,7 +1179,7 @@ __global__ __launch_bounds__(OCT_NT) void octree_kernel(
     int* __restrict__ cand_count,
     uint32_t* __restrict__ ws_xy, uint16_t* __restrict__ ws_node,
     OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, int* __restrict__ kp_count,
-    int node_cap, int key_cap, int level_override /* -1: blockIdx.x */, int* __restrict__ fb_count) {
+    int node_cap, int key_cap, int level_override /* -1: blockIdx.x */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // node arrays | k_xy[key_cap] | k_nd[key_cap]
     __shared__ int wave_tmp[OCT_NT / 64];
     __shared__ int s_vars[4];
@@ -1230,8 +1198,6 @@ __global__ __launch_bounds__(OCT_NT) void octree_kernel(
     // per call) and keep the count in the line's second word for slamit_orb_debug_candidates
     __syncthreads();
     if (threadIdx.x == 0) { cand_count[kidx * ORB_CC_PAD] = 0; cand_count[kidx * ORB_CC_PAD + 1] = n_raw; }
-    // likewise the length of the FAST pass's list of cells for the minThFAST retry (its reader has finished)
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && fb_count) { fb_count[1] = fb_count[0]; fb_count[0] = 0; }
     const unsigned long long* K = cand + L.cand_off + (size_t)frame * cand_frame_stride;
     OrbLevelKp* OUT = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
     if (n_keys == 0) {
@@ -1822,16 +1788,15 @@ void orbk_pyramid(hipStream_t st, const OrbLevel* levels, int nlevels, const Pyr
 
 #ifndef FAST_PS
 #define FAST_PS 48   // tile pitch for cells of <= 37 pixels
-#define FAST_PL 72   // ... up to 59
+#define FAST_PL 80   // ... up to 64 (a multiple of 16: the tile is staged in 16-byte DMA chunks)
 #endif
-static int fast_pitch(int max_wcell) { return max_wcell + 11 <= 48 ? FAST_PS : FAST_PL; }  // LDS columns 0 .. sw + 10 are touched
+static int fast_pitch(int max_wcell) { return max_wcell + 11 <= FAST_PS ? FAST_PS : FAST_PL; }  // LDS columns 0 .. sw + 10 are touched
 
 size_t orbk_fast_smem(int max_wcell, int max_hcell) {
     const int P = fast_pitch(max_wcell);
     const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
     const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
-    const int per_wave = (((tile_rows * P + 16 + 15) & ~15) + sc_rows * P + 2 * FAST_LIST_CAP + 2 * kp_cap + 15) & ~15;
-    return (size_t)4 * per_wave + 16;   // + the score tile's zeroing may round its last 16-byte store up
+    return (size_t)4 * fast_wave_bytes(P, tile_rows, sc_rows, kp_cap);
 }
 
 hipError_t orbk_fast_prepare(int max_wcell, int max_hcell) {
@@ -1839,19 +1804,16 @@ hipError_t orbk_fast_prepare(int max_wcell, int max_hcell) {
     hipError_t e;
     if (fast_pitch(max_wcell) == FAST_PS) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<FAST_PS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_listed_kernel<FAST_PS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_kernel<FAST_PL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_cells_listed_kernel<FAST_PL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     }
     return e;
 }
 
 // Cell table: the non-empty FAST cells of every level in the reference's visiting order (level, row, column;
-// ORBextractor.cc:805-822), 8 words per cell:
-//   0: level | cell index in the level << 8      1: iniX | iniY << 16
-//   2: cw | ch << 8 | nd << 16 | rows_per_it << 24   (window size; dwords per staged row; staged rows per wave pass)
-//   3..6: division magics  floor(2^20 / g) + 1  for g = nd, (sw + 3) / 4, sw, cw
+// ORBextractor.cc:805-822), 4 words per cell:
+//   0: level | cell index in the level << 8      1: iniX | iniY << 16      2: cw | ch << 8 (window size)
+//   3: division magic  floor(2^20 / g) + 1  for g = (sw + 3) / 4, the groups of four scan pixels per row
 int orbk_fast_cells(const OrbLevel* host_levels, int nlevels, std::vector<uint32_t>& out) {
     out.clear();
     auto magic = [](int g) { return (uint32_t)((1u << 20) / (unsigned)std::max(g, 1) + 1u); };
@@ -1864,14 +1826,12 @@ int orbk_fast_cells(const OrbLevel* host_levels, int nlevels, std::vector<uint32
             const int cw = std::min(L.wCell + 6, L.maxBorderX - iniX), ch = std::min(L.hCell + 6, L.maxBorderY - iniY);
             const int sw = cw - 6, sh = ch - 6;
             if (sw <= 0 || sh <= 0) continue;
-            const int nd = (cw + 1 + 3) >> 2, rpi = std::max(64 / nd, 1);
-            const uint32_t w[8] = {(uint32_t)l | ((uint32_t)c << 8), (uint32_t)iniX | ((uint32_t)iniY << 16),
-                                   (uint32_t)cw | ((uint32_t)ch << 8) | ((uint32_t)nd << 16) | ((uint32_t)rpi << 24),
-                                   magic(nd), magic((sw + 3) >> 2), magic(sw), magic(cw), 0u};
-            out.insert(out.end(), w, w + 8);
+            const uint32_t w[4] = {(uint32_t)l | ((uint32_t)c << 8), (uint32_t)iniX | ((uint32_t)iniY << 16),
+                                   (uint32_t)cw | ((uint32_t)ch << 8), magic((sw + 3) >> 2)};
+            out.insert(out.end(), w, w + 4);
         }
     }
-    return (int)(out.size() / 8);
+    return (int)(out.size() / 4);
 }
 
 void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const uint32_t* d_cells, int cells_per_frame,
@@ -1900,29 +1860,6 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
                            sc_rows, kp_cap);
 }
 
-void orbk_fast_listed(hipStream_t st, const OrbLevel* host_levels, int nlevels, const uint32_t* d_cells, const uint32_t* d_list,
-                      const int* d_list_count, const uint8_t* img0, size_t img0_stride, size_t img0_frame, const uint8_t* pyr,
-                      unsigned long long* cand, size_t cand_frame_stride, int* cand_count, int th, int max_wcell, int max_hcell) {
-    const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
-    const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
-    const size_t smem = orbk_fast_smem(max_wcell, max_hcell);
-    FastTab tab = {};
-    for (int l = 0; l < nlevels && l < ORB_MAX_LEVELS; ++l) {
-        const OrbLevel& S = host_levels[l];
-        FastLevel& D = tab.lv[l];
-        D.cell_base = S.cell_base; D.nCols = S.nCols; D.wCell = S.wCell; D.hCell = S.hCell;
-        D.maxBorderX = S.maxBorderX; D.maxBorderY = S.maxBorderY; D.stride = S.stride; D.cand_cap = S.cand_cap;
-        D.plane_off = S.plane_off; D.plane_bytes = S.plane_bytes; D.cand_off = S.cand_off;
-    }
-    const dim3 grid(512);   // 2048 waves walk the list
-    if (fast_pitch(max_wcell) == FAST_PS)
-        hipLaunchKernelGGL(fast_cells_listed_kernel<FAST_PS>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, d_list,
-                           d_list_count, img0, (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, th, tile_rows, sc_rows, kp_cap);
-    else
-        hipLaunchKernelGGL(fast_cells_listed_kernel<FAST_PL>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, d_list,
-                           d_list_count, img0, (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, th, tile_rows, sc_rows, kp_cap);
-}
-
 // candidates kept in LDS: as many as fit beside the node arrays in half a CU's LDS (lists above that use the HBM workspace)
 // LDS budget of one octree workgroup.  Two 78 KB workgroups fill a CU's LDS, which also keeps every other kernel off
 // the chip while the octree pass (a few hundred workgroups, latency bound) runs; images up to about VGA rarely have more
@@ -1948,7 +1885,7 @@ hipError_t orbk_octree_prepare(int node_cap, int key_cap) {
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
                  size_t cand_frame_stride, int* cand_count, uint32_t* ws_xy, uint16_t* ws_node,
                  OrbLevelKp* lkp, size_t kp_frame_stride, int* kp_count, int node_cap, int key_cap, int nframes,
-                 int level_override, int* fb_count) {
+                 int level_override) {
     dim3 grid(nframes, level_override >= 0 ? 1 : nlevels);
     // Workgroups of 512 threads finish a (frame, level) soonest; with a hundred frames or more per call 256-thread workgroups take 10 %
     // longer alone (74 vs 67 us at 128 frames) but leave the side stream's blur more of the chip, and the STEP is 2 % shorter
@@ -1958,11 +1895,11 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
     if (nt == 256)
         hipLaunchKernelGGL(octree_kernel<256>, grid, dim3(256), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
                            cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
-                           key_cap, level_override, fb_count);
+                           key_cap, level_override);
     else
         hipLaunchKernelGGL(octree_kernel<OCT_THREADS>, grid, dim3(OCT_THREADS), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
                            cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
-                           key_cap, level_override, fb_count);
+                           key_cap, level_override);
 }
 
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0,
