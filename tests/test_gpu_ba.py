@@ -83,6 +83,7 @@ def test_banded_windows_in_lds_and_through_the_blocked_path(opt, k, p, o, seed, 
             "r = o.LocalBundleAdjustment(prob)\n"
             "np.savez(sys.argv[1], kf_pose=r['kf_pose'], pt_xyz=r['pt_xyz'], edge_outlier=r['edge_outlier'], n_its=np.array(r['stats']['n_its']))\n"
             % (ROOT, k, p, o, seed, nfix))
+    # the same window through the blocked reduced solve (k_ldlt_blocked: what a window without a narrow envelope takes)
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "r.npz")
         subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, SLAMIT_BA_NO_BAND="1"), cwd=ROOT, timeout=300)
@@ -100,6 +101,16 @@ def test_config4_dense_50kf_2000pt(opt):
     prob = synth.synth_ba(50, 2000, None, seed=12345)
     assert len(prob["edge_kf"]) == 100000
     _close(opt.LocalBundleAdjustment(prob), ob.ba_solve(prob), "dense")
+
+
+def test_batch_mixes_the_two_reduced_solves(opt):
+    """One batch holding banded windows (window-8, window-4) and dense ones of 294 and 306 unknowns (blocked): each kind's
+    kernel is launched once per slot and a window only runs in its own."""
+    probs = [synth.synth_ba(50, 600, 8, seed=21), synth.synth_ba(50, 500, None, seed=22), synth.synth_ba(52, 400, None, seed=23),
+             synth.synth_ba(20, 300, 4, seed=24)]
+    outs = opt.LocalBundleAdjustmentBatch(probs)
+    for i, (p, o) in enumerate(zip(probs, outs)):
+        _close(o, ob.ba_solve(p), "mixed[%d]" % i)
 
 
 def test_batch_of_windows(opt):

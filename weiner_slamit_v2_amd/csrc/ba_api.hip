@@ -23,7 +23,8 @@ size_t bak_ldlt_smem(int Npad);
 hipError_t bak_prepare(int Npad);
 void bak_import(hipStream_t st, BaWin* wins, const BaIo* io, int max_kf, int max_pt, int max_edge, int Npad, int nwin);
 void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int stage, int max_it, int robust, bool gate);
-void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, hipEvent_t* ev);
+void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, unsigned solvers, hipEvent_t* ev);
+int bak_solver_kind(int n, int band);
 void bak_final(hipStream_t st, BaWin* wins, const BaIo* io, int nwin, int max_kf, int max_pt, int max_edge);
 
 static_assert(BA_MAX_ITS == SLAMIT_BA_MAX_ITS, "stats capacity");
@@ -294,8 +295,8 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             }
             int band = 0;   // a window whose keyframes only share points with their neighbours has a narrow band: LDLt inside LDS
             for (int c = 0; c < nfree; ++c) band = std::max(band, 6 * c + 5 - 6 * fcol[c]);
-            static const bool no_band = getenv("SLAMIT_BA_NO_BAND") != nullptr;   // A/B and parity runs: every window through the blocked path
-            w.band = no_band ? std::max(n - 1, 0) : std::min(band, std::max(n - 1, 0));
+            w.band = std::min(band, std::max(n - 1, 0));
+            w.solver = bak_solver_kind(n, w.band);
         }
         // ---- inputs, straight into the pinned block: CSR by point / by keyframe (counting sort, caller order kept
         // inside each list), points in device order ----
@@ -330,8 +331,10 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
             for (std::thread& t : pool) t.join();
         }
     }
+    unsigned solvers = 0;
     for (int b = 0; b < nwin; ++b) {
         Npad = std::max(Npad, wins[b].Npad);
+        solvers |= 1u << wins[b].solver;
         HIP_TRY(hipMemcpyAsync(h->d_slab + (size_t)b * h->win_bytes, h->h_pin + in_off[b], dio[b].in_bytes, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipMemcpyAsync(h->d_wins, wins.data(), sizeof(BaWin) * nwin, hipMemcpyHostToDevice, st));
@@ -374,7 +377,7 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
                 const bool was_first = first;
                 first = false;
                 static const bool no_fuse = getenv("SLAMIT_BA_NO_FUSE") && atoi(getenv("SLAMIT_BA_NO_FUSE"));   // A/B runs: every slot as the first
-                for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad, (was_first && sl == 0) || no_fuse, slot_events());
+                for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad, (was_first && sl == 0) || no_fuse, solvers, slot_events());
                 budget -= nslots;
                 HIP_TRY(hipMemcpyAsync(hs[cur], h->d_states, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipEventRecord(h->ev[cur], st));

@@ -12,7 +12,7 @@
 //                      as ONE dense split-K product GA * GB^T on v_mfma_f64_16x16x4_f64
 //   k_point_pass       k_linearize + k_point_reduce + k_prepare in one launch: every LM trial after a stage's first
 //   k_schur_pose       k_schur with k_pose_reduce's workgroups behind its tiles: the same trials
-//   k_ldlt_solve       LinearSolverEigen::solve                          G/solvers/linear_solver_eigen.h:94-124
+//   k_ldlt_band / k_ldlt_blocked   LinearSolverEigen::solve              G/solvers/linear_solver_eigen.h:94-124
 //                      banded systems: block LDLt with 4 x 4 pivots inside LDS, rank-4 updates on v_mfma_f64_16x16x4_f64 with
 //                      the tiles resident in accumulators (ldlt_band_solve); others: dense blocked LDLt through L2
 //   k_backsub_update   landmark back-substitution + oplus + push()       G/core/block_solver.hpp:459-485, sparse_optimizer.cpp:422-435
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins) {
     W.S[(size_t)c * N + r] = sv;
     // a banded window's solve reads its LDS image instead: entry (row c, column r) of the lower band (ldlt_band_solve's layout)
     const int bw = W.band;
-    if (ldlt_band_ok(n, bw) && c - r <= bw) W.Sb[(size_t)c * ldlt_band_rs(bw) + (r - c + bw + 3)] = sv;
+    if (W.solver == BA_SOLVER_BAND && c - r <= bw) W.Sb[(size_t)c * ldlt_band_rs(bw) + (r - c + bw + 3)] = sv;
 }
 
 // ---- S8: dense blocked LDLt (no pivoting) of the reduced system + solve, one workgroup -------------
@@ -598,20 +598,20 @@ __device__ __forceinline__ void ldlt_rows(double* Wd, const double* Dg, int rows
         double w[LD_NB];
 #pragma unroll
         for (int k = 0; k < LD_NB; ++k) w[k] = wrow[k];
-        // software-pipelined: column k+1 of L11 is read from LDS while the updates with column k run
-        double lc[LD_NB], ln[LD_NB];
+        // software-pipelined: an entry of column k+1 of L11 is requested from LDS into the register its column-k entry has just
+        // left (a second set of 32 registers for the next column made the kernel spill 36 VGPRs)
+        double lc[LD_NB];
 #pragma unroll
         for (int m = 1; m < LD_NB; ++m) lc[m] = Dg[m * LD_P];
 #pragma unroll
         for (int k = 0; k < LD_NB - 1; ++k) {
-#pragma unroll
-            for (int m = k + 2; m < LD_NB; ++m) ln[m] = Dg[m * LD_P + k + 1];
             const double wk = w[k];
 #pragma unroll
-            for (int m = k + 1; m < LD_NB; ++m) w[m] -= wk * lc[m];
+            for (int m = k + 1; m < LD_NB; ++m) {
+                w[m] -= wk * lc[m];
+                if (m >= k + 2) lc[m] = Dg[m * LD_P + k + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);  // keeps the reads of later columns from being hoisted (spills)
-#pragma unroll
-            for (int m = k + 2; m < LD_NB; ++m) lc[m] = ln[m];
         }
 #pragma unroll
         for (int k = 1; k < LD_NB; ++k) wrow[k] = w[k];
@@ -1021,14 +1021,29 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
     if (tid == 0) st->ok2 = 1;
 }
 
-__global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
+// The reduced solve of a window is ONE of two kernels, chosen on the host from the window's size and envelope
+// (BaWin::solver, ba_api.hip); a batch launches the kinds it contains and a workgroup whose window is of the other kind
+// returns at once.  (As one kernel with a run-time branch the register allocation was the union of the paths: 256 VGPRs
+// and 37 spilled; on its own the banded kernel takes 94.)  Each starts with k_iter_begin's bookkeeping for the slots without that launch (bak_slot, first ==
+// false): it is the first single-workgroup kernel behind the last reader of need_linearize (k_pose_reduce).
+__global__ __launch_bounds__(LD_THREADS) void k_ldlt_band(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
     BaState* st = W.st;
-    if (st->done) return;
+    if (W.solver != BA_SOLVER_BAND || st->done) return;
+    if (threadIdx.x == 0 && st->need_linearize) { st->iniChi = st->currentChi; st->qmax = 0; st->need_linearize = 0; }
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    ldlt_band_solve(W, st, sm, &s_fail);
+}
+
+__global__ __launch_bounds__(LD_THREADS) void k_ldlt_blocked(BaWin* wins) {
+    const BaWin& W = wins[blockIdx.y];
+    BaState* st = W.st;
+    if (W.solver != BA_SOLVER_BLOCKED || st->done) return;
     const int n = W.nS, N = W.Npad;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // k_iter_begin's bookkeeping for the slots without that launch (bak_slot, first == false): this is the first
-    // single-workgroup kernel behind the last reader of need_linearize (k_pose_reduce)
     if (tid == 0 && st->need_linearize) { st->iniChi = st->currentChi; st->qmax = 0; st->need_linearize = 0; }
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Dg = sm;                      // LD_NB x LD_P: diagonal block (unit L below, D on the diagonal)
@@ -1037,13 +1052,6 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_solve(BaWin* wins) {
     __shared__ double s_invd[LD_NB], s_corr[LD_NB], s_dval[LD_NB];
     if (tid == 0) s_fail = 0;
     if (n == 0) { if (tid == 0) st->ok2 = 1; return; }
-#ifndef LD_NO_BAND
-    if (ldlt_band_ok(n, W.band)) {   // wave-uniform: the window's structure (host, ba_api.hip)
-        __syncthreads();
-        ldlt_band_solve(W, st, sm, &s_fail);
-        return;
-    }
-#endif
 #ifdef BA_DIAG_STAMPS
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define STAMP(i) do { unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[i] += tn - tprev; tprev = tn; } while (0)
@@ -1487,7 +1495,7 @@ __global__ __launch_bounds__(256) void k_import(BaWin* wins, const BaIo* io) {
     if (k < W.n_edge) { W.e_active[k] = 1; W.e_out1[k] = 0; W.e_chi2[k] = 0.0; }
     if (k < 3 * W.n_pt) W.pt[k] = I.in_pt[k];
     if (k < (int)(sizeof(BaState) / 8)) reinterpret_cast<unsigned long long*>(W.st)[k] = 0ull;
-    if (ldlt_band_ok(W.nS, W.band))   // the zeros of the band image (pad slots, the part of a row left of column 0, the extra row)
+    if (W.solver == BA_SOLVER_BAND)   // the zeros of the band image (pad slots, the part of a row left of column 0, the extra row)
         for (int i = k; i < (W.nS + 1) * ldlt_band_rs(W.band); i += gridDim.x * 256) W.Sb[i] = 0.0;
     if (k >= W.n_kf) return;
     const double* p = I.in_pose + 12 * (size_t)k;
@@ -1505,8 +1513,16 @@ size_t bak_ldlt_smem(int Npad) {   // the blocked path's need, raised to the ban
 }
 
 hipError_t bak_prepare(int Npad) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bak_ldlt_smem(Npad));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bak_ldlt_smem(Npad));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bak_ldlt_smem(Npad));
+    return e;
+}
+
+// the reduced solve a window takes (host): its structure decides
+int bak_solver_kind(int n, int band) {
+    static const bool no_band = getenv("SLAMIT_BA_NO_BAND") != nullptr;   // A/B and parity runs: no window through the banded kernel
+    if (!no_band && ldlt_band_ok(n, band)) return BA_SOLVER_BAND;
+    return BA_SOLVER_BLOCKED;
 }
 
 void bak_import(hipStream_t st, BaWin* wins, const BaIo* io, int max_kf, int max_pt, int max_edge, int Npad, int nwin) {
@@ -1525,11 +1541,11 @@ void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int st
 
 // one LM trial slot for every window of the batch
 // (`first`: the first slot of a stage, whose lambda comes out of the reductions; every later slot runs them and the
-// damping in one launch, the pose blocks ride with the Schur product, and the iteration bookkeeping is left to k_ldlt_solve: 7 launches
+// damping in one launch, the pose blocks ride with the Schur product, and the iteration bookkeeping is left to the reduced solve's kernel: 7 launches
 // instead of 11)
 // `ev` (profiling solves only, slamit_ba_profile): six events recorded at the phase boundaries of the slot -- before the
 // linearisation, after it, after the Schur complement, after the reduced solve, after the update, after residuals + decision
-void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, hipEvent_t* ev) {
+void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, unsigned solvers, hipEvent_t* ev) {
     const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt * BA_PG + 255) / 256, nwin);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (first) {
@@ -1547,7 +1563,9 @@ void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int
     else hipLaunchKernelGGL(k_schur_pose, dim3(ntiles + (max_kf + BA_SPLITS - 1) / BA_SPLITS, BA_SPLITS, nwin), dim3(256), 0, st, wins, ntiles);
     hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins);
     if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_ldlt_solve, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);
+    // `solvers`: bit BA_SOLVER_* set when a window of the batch takes that kernel
+    if (solvers & (1u << BA_SOLVER_BAND)) hipLaunchKernelGGL(k_ldlt_band, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);
+    if (solvers & (1u << BA_SOLVER_BLOCKED)) hipLaunchKernelGGL(k_ldlt_blocked, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);
     if (ev) (void)hipEventRecord(ev[3], st);
     const int nb = (max_pt * BA_PG > max_kf ? max_pt * BA_PG : max_kf);
     hipLaunchKernelGGL(k_backsub_update, dim3((nb + 255) / 256, nwin), dim3(256), 0, st, wins);

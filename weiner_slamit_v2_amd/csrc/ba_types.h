@@ -10,6 +10,8 @@
 #define BA_SPLITS 16        // split-K factor of the Schur GEMM
 #define BA_MAX_TILES 10     // 64-row tiles of the reduced system (slamit_ba_create refuses larger handles)
 #define BA_MAX_PANELS 20    // 32-column LDLt panels
+#define BA_SOLVER_BAND 0      // narrow row envelope: block LDLt inside LDS (k_ldlt_band)
+#define BA_SOLVER_BLOCKED 1   // any other structure: 32-column panels through L2 (k_ldlt_blocked)
 
 // LM control block of one window (device resident; the host only reads it back between chunks
 // of enqueued trial slots).  Mirrors the locals of OptimizationAlgorithmLevenberg::solve
@@ -62,6 +64,7 @@ struct BaWin {
     int16_t panel_hi[BA_MAX_PANELS];   // last matrix row with an entry in the 32 columns of LDLt panel i (>= the panel's last row)
     int16_t back_lo[BA_MAX_PANELS];    // first column any row of panel i's 32 rows reaches (back-substitution)
     int32_t band;      // half bandwidth of the reduced system's row envelope: max over rows r of r - first column of r (nS - 1: full)
+    int32_t solver;    // which reduced solve takes the window (host, from nS and band): BA_SOLVER_*; one launch per kind present in a batch
     // vertices
     BA_G double* pose;      // n_kf x 7: q(x,y,z,w), t
     BA_G double* pose_bak;

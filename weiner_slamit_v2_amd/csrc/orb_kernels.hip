@@ -630,9 +630,9 @@ __device__ __forceinline__ void fast_cell_wave(
 #endif
             const int base = nE - cnt;
             const bool vlo = lane < cnt, vhi = lane + 64 < cnt;
-            // lanes beyond the count read whatever the stack holds there and score it (a stale entry addresses LDS, nothing else);
-            // they are kept out of every store below
-            const unsigned elo = s_ent[base + lane], ehi = s_ent[base + 64 + lane];
+            // lanes beyond the count all re-read the pass's first entry (one address: a broadcast, no bank conflict -- stale slots
+            // would scatter their ring reads over the tile) and are kept out of every store below
+            const unsigned elo = s_ent[base + (vlo ? lane : 0)], ehi = s_ent[base + (vhi ? lane + 64 : 0)];
             const unsigned long long vmlo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
             const unsigned long long vmhi = cnt >= 128 ? ~0ull : cnt > 64 ? (1ull << (cnt - 64)) - 1ull : 0ull;
             // y * PITCH + x: top-left corner of the pixel's 7x7 neighbourhood in the tile, less SC_COL0 - 3
