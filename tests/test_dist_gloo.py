@@ -104,3 +104,31 @@ def test_assignments_cover_every_stream_once():
         assert seen == list(range(8))
         seen = sorted(s for r in range(world) for s in shard.weak_streams(64, world, r))
         assert seen == list(range(64 * world))
+
+
+def test_rt_to_quat_t_round_trip_including_half_turns():
+    """shard.rt_to_quat_t (the BA slot's pose format): quaternion -> R must give the input back for every rotation, the
+    180-degree ones (w = 0, where the off-diagonal differences vanish) included; numpy and torch inputs agree."""
+    import numpy as np
+    import torch
+
+    from weiner_slamit_v2_amd import shard
+
+    def q2R(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    rs = np.random.RandomState(0)
+    qs = rs.randn(64, 4)
+    qs[:16, 3] = 0                                         # half turns about random axes
+    qs[16] = [1 / np.sqrt(2), -1 / np.sqrt(2), 0, 0]       # the axis (1, -1, 0) / sqrt 2 of the review
+    qs /= np.linalg.norm(qs, axis=1)[:, None]
+    R = np.stack([q2R(q) for q in qs])
+    rt = np.concatenate([R.reshape(-1, 9), rs.randn(64, 3)], 1)
+    out = shard.rt_to_quat_t(rt)
+    assert np.allclose((out[:, :4] ** 2).sum(1), 1.0, atol=1e-12) and (out[:, 3] >= 0).all()
+    assert max(np.abs(q2R(o[:4]) - R[i]).max() for i, o in enumerate(out)) < 1e-12
+    assert np.array_equal(out[:, 4:], rt[:, 9:])
+    assert np.allclose(shard.rt_to_quat_t(torch.from_numpy(rt)).numpy(), out, atol=0, rtol=0)

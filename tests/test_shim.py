@@ -164,10 +164,13 @@ def _apply_in_order(n, state, match):
 
 
 def _gemm_row(Rrow, t, X, Y, Z):
-    """One row of cv::Mat x3Dc = Rcw * x3Dw + tcw on CV_32F operands: cv::gemm sums in double and rounds once
-    (the model the shim templates follow, ORBmatcher.cc:1363, 851, 1497)."""
-    f64 = np.float64
-    return (f64(Rrow[0]) * X.astype(f64) + f64(Rrow[1]) * Y.astype(f64) + f64(Rrow[2]) * Z.astype(f64) + f64(t)).astype(np.float32)
+    """One row of cv::Mat x3Dc = Rcw * x3Dw + tcw on CV_32F operands as OpenCV 2.4's cv::gemm evaluates a 3 x 3 by 3 x 1 product
+    without flags (matmul.cpp's small-matrix branch): the dot product in float32, left to right, then one double add of t and a
+    rounding to float32 (ORBmatcher.cc:1363, 851, 1497).  Restated here in numpy, independently of the shim's slamit_gemm_row3;
+    parity unpinned against OpenCV itself (its source is not in the reference tree)."""
+    f32, f64 = np.float32, np.float64
+    t0 = (f32(Rrow[0]) * X.astype(f32) + f32(Rrow[1]) * Y.astype(f32)).astype(f32) + f32(Rrow[2]) * Z.astype(f32)
+    return (t0.astype(f32).astype(f64) + f64(f32(t))).astype(f32)
 
 
 @pytest.mark.gpu

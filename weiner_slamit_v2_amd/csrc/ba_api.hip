@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -169,8 +170,21 @@ void slamit_ba_destroy(slamit_ba* h) {
     delete h;
 }
 
+static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* probs, const slamit_ba_opts* opts, slamit_ba_result* results);
+
 int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs, const slamit_ba_opts* opts,
                           slamit_ba_result* results) {
+    try {
+        return ba_solve_batch_impl(h, nwin, probs, opts, results);
+    } catch (const std::exception& e) {   // (host containers: std::bad_alloc, std::length_error)
+        return slamit_fail(SLAMIT_ERR_DEVICE, e.what());
+    } catch (...) {
+        return slamit_fail(SLAMIT_ERR_DEVICE, "slamit_ba_solve_batch: unexpected exception");
+    }
+}
+
+static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* probs, const slamit_ba_opts* opts,
+                               slamit_ba_result* results) {
     if (!h || !probs || !opts || !results || nwin < 0) return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: bad argument");
     if (nwin > h->max_batch) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_ba_solve_batch: nwin > max_batch");
     if (nwin == 0) return SLAMIT_OK;
@@ -320,16 +334,23 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
         }
     };
     {
+        // nothing thrown in here may cross the C boundary: a worker records a failed preparation (bad_alloc in its vectors), a thread
+        // that cannot be created leaves its share to the threads that exist and to the caller's own
         const int nthreads = std::max(1, std::min(std::min(nwin, 16), (int)std::thread::hardware_concurrency()));
-        if (nthreads <= 1) {
-            for (int b = 0; b < nwin; ++b) prepare(b);
-        } else {
-            std::atomic<int> next(0);
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthreads; ++t)
-                pool.emplace_back([&]() { for (int b = next.fetch_add(1); b < nwin; b = next.fetch_add(1)) prepare(b); });
-            for (std::thread& t : pool) t.join();
-        }
+        std::atomic<int> next(0);
+        std::atomic<bool> failed(false);
+        auto work = [&]() {
+            for (int b = next.fetch_add(1); b < nwin; b = next.fetch_add(1)) {
+                try { prepare(b); } catch (...) { failed = true; }
+            }
+        };
+        std::vector<std::thread> pool;
+        try {
+            for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+        } catch (...) {}
+        work();
+        for (std::thread& t : pool) t.join();
+        if (failed) return slamit_fail(SLAMIT_ERR_DEVICE, "slamit_ba_solve_batch: out of host memory while preparing the windows");
     }
     unsigned solvers = 0;
     for (int b = 0; b < nwin; ++b) {

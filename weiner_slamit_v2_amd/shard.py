@@ -135,18 +135,37 @@ class SlotGather:
 
 
 def rt_to_quat_t(rt):
-    """n x 12 (R row-major | t) -> n x 7 (quaternion x y z w | t), numpy; the BA slot's pose format."""
+    """n x 12 (R row-major | t) -> n x 7 (quaternion x y z w | t); the BA slot's pose format.  numpy array or torch tensor in,
+    the same kind out (a tensor stays on its device: the pipeline packs its slots without a host round trip).  Shepperd's
+    method: the largest of (trace, R00, R11, R22) picks the branch, so rotations by 180 degrees (w = 0) come out right --
+    copysign of a zero difference would not."""
     import numpy as np
 
-    rt = np.asarray(rt, np.float64).reshape(-1, 12)
-    R = rt[:, :9].reshape(-1, 3, 3)
-    q = np.zeros((len(rt), 4))
-    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
-    q[:, 3] = np.sqrt(np.maximum(1.0 + tr, 0.0)) / 2
-    q[:, 0] = np.copysign(np.sqrt(np.maximum(1.0 + R[:, 0, 0] - R[:, 1, 1] - R[:, 2, 2], 0.0)) / 2, R[:, 2, 1] - R[:, 1, 2])
-    q[:, 1] = np.copysign(np.sqrt(np.maximum(1.0 - R[:, 0, 0] + R[:, 1, 1] - R[:, 2, 2], 0.0)) / 2, R[:, 0, 2] - R[:, 2, 0])
-    q[:, 2] = np.copysign(np.sqrt(np.maximum(1.0 - R[:, 0, 0] - R[:, 1, 1] + R[:, 2, 2], 0.0)) / 2, R[:, 1, 0] - R[:, 0, 1])
-    return np.concatenate([q, rt[:, 9:12]], 1)
+    is_t = isinstance(rt, torch.Tensor)
+    X = (rt.to(torch.float64) if is_t else torch.from_numpy(np.ascontiguousarray(np.asarray(rt, np.float64)))).reshape(-1, 12)
+    R = X[:, :9].reshape(-1, 3, 3)
+    r00, r11, r22 = R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]
+    tr = r00 + r11 + r22
+    cand = torch.stack([tr, r00, r11, r22], 1)
+    br = cand.argmax(1)
+    q = torch.zeros((len(X), 4), dtype=torch.float64, device=X.device)
+    # branch 0: w largest
+    s0 = torch.sqrt(torch.clamp(1.0 + tr, min=0.0)) * 2
+    s1 = torch.sqrt(torch.clamp(1.0 + r00 - r11 - r22, min=0.0)) * 2
+    s2 = torch.sqrt(torch.clamp(1.0 - r00 + r11 - r22, min=0.0)) * 2
+    s3 = torch.sqrt(torch.clamp(1.0 - r00 - r11 + r22, min=0.0)) * 2
+    eps = 1e-300
+    qs = [
+        torch.stack([(R[:, 2, 1] - R[:, 1, 2]) / (s0 + eps), (R[:, 0, 2] - R[:, 2, 0]) / (s0 + eps), (R[:, 1, 0] - R[:, 0, 1]) / (s0 + eps), s0 / 4], 1),
+        torch.stack([s1 / 4, (R[:, 0, 1] + R[:, 1, 0]) / (s1 + eps), (R[:, 0, 2] + R[:, 2, 0]) / (s1 + eps), (R[:, 2, 1] - R[:, 1, 2]) / (s1 + eps)], 1),
+        torch.stack([(R[:, 0, 1] + R[:, 1, 0]) / (s2 + eps), s2 / 4, (R[:, 1, 2] + R[:, 2, 1]) / (s2 + eps), (R[:, 0, 2] - R[:, 2, 0]) / (s2 + eps)], 1),
+        torch.stack([(R[:, 0, 2] + R[:, 2, 0]) / (s3 + eps), (R[:, 1, 2] + R[:, 2, 1]) / (s3 + eps), s3 / 4, (R[:, 1, 0] - R[:, 0, 1]) / (s3 + eps)], 1),
+    ]
+    for i in range(4):
+        q = torch.where((br == i)[:, None], qs[i], q)
+    q = torch.where((q[:, 3] < 0)[:, None], -q, q)   # w >= 0, like SE3Quat::normalizeRotation (se3quat.h:276-281)
+    out = torch.cat([q, X[:, 9:12]], 1)
+    return out if is_t else out.numpy()
 
 
 def max_over_ranks(value, device, world):

@@ -214,6 +214,17 @@ int ORBmatcher::SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpM
     return nmatches;
 }
 
+
+// One row of cv::Mat x3Dc = R * x3Dw + t on CV_32F operands as OpenCV 2.4's cv::gemm evaluates it (modules/core/src/matmul.cpp):
+// a 3 x 3 by 3 x 1 product with no transposition flag takes gemm's small-matrix branch -- the dot product in FLOAT, left to
+// right, then (float)((double)t0 * alpha + (double)c * beta) with alpha = beta = 1.  (The transposed product -R.t() * t goes
+// through the generic path, which accumulates in double.)  PARITY UNPINNED: OpenCV's source is not in the reference tree; this
+// follows the published 2.4 code as recalled, and tests/test_shim.py::_gemm_row restates it independently in numpy.
+inline float slamit_gemm_row3(const float r0, const float r1, const float r2, const float X, const float Y, const float Z, const float t) {
+    const float t0 = r0 * X + r1 * Y + r2 * Z;
+    return (float)((double)t0 + (double)t);
+}
+
 template <class FrameT>
 int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono) {
     const int n = (int)CurrentFrame.mvKeysUn.size();
@@ -228,9 +239,9 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame
         tcw[r] = CurrentFrame.mTcw.template at<float>(r, 3); tlw[r] = LastFrame.mTcw.template at<float>(r, 3);
     }
     float twc[3];
-    // cv::Mat products of CV_32F operands sum in double and round once (cv::gemm); so do these
+    // -Rcw.t() * tcw: cv::gemm's generic path (GEMM_1_T) sums in double and rounds once
     for (int r = 0; r < 3; ++r) twc[r] = (float)((double)-Rcw[0][r] * tcw[0] + (double)-Rcw[1][r] * tcw[1] + (double)-Rcw[2][r] * tcw[2]);
-    const float tlc2 = Rlw[2][0] * twc[0] + Rlw[2][1] * twc[1] + Rlw[2][2] * twc[2] + tlw[2];
+    const float tlc2 = slamit_gemm_row3(Rlw[2][0], Rlw[2][1], Rlw[2][2], twc[0], twc[1], twc[2], tlw[2]);   // row 2 of Rlw * twc + tlw (:1346)
     const bool bForward = tlc2 > CurrentFrame.mb && !bMono;
     const bool bBackward = -tlc2 > CurrentFrame.mb && !bMono;
 
@@ -241,9 +252,9 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame
         if (!pMP || LastFrame.mvbOutlier[i]) continue;
         const cv::Mat x3Dw = pMP->GetWorldPos();
         const float X = x3Dw.template at<float>(0, 0), Y = x3Dw.template at<float>(1, 0), Z = x3Dw.template at<float>(2, 0);
-        const float xc = (float)((double)Rcw[0][0] * X + (double)Rcw[0][1] * Y + (double)Rcw[0][2] * Z + (double)tcw[0]);
-        const float yc = (float)((double)Rcw[1][0] * X + (double)Rcw[1][1] * Y + (double)Rcw[1][2] * Z + (double)tcw[1]);
-        const float zc = (float)((double)Rcw[2][0] * X + (double)Rcw[2][1] * Y + (double)Rcw[2][2] * Z + (double)tcw[2]);
+        const float xc = slamit_gemm_row3(Rcw[0][0], Rcw[0][1], Rcw[0][2], X, Y, Z, tcw[0]);
+        const float yc = slamit_gemm_row3(Rcw[1][0], Rcw[1][1], Rcw[1][2], X, Y, Z, tcw[1]);
+        const float zc = slamit_gemm_row3(Rcw[2][0], Rcw[2][1], Rcw[2][2], X, Y, Z, tcw[2]);
         const float invzc = 1.0 / zc;
         if (invzc < 0) continue;
         const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
@@ -312,9 +323,9 @@ int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const S
         if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
         const cv::Mat x3Dw = pMP->GetWorldPos();
         const float X = x3Dw.template at<float>(0, 0), Y = x3Dw.template at<float>(1, 0), Z = x3Dw.template at<float>(2, 0);
-        const float xc = (float)((double)Rcw[0][0] * X + (double)Rcw[0][1] * Y + (double)Rcw[0][2] * Z + (double)tcw[0]);
-        const float yc = (float)((double)Rcw[1][0] * X + (double)Rcw[1][1] * Y + (double)Rcw[1][2] * Z + (double)tcw[1]);
-        const float zc = (float)((double)Rcw[2][0] * X + (double)Rcw[2][1] * Y + (double)Rcw[2][2] * Z + (double)tcw[2]);
+        const float xc = slamit_gemm_row3(Rcw[0][0], Rcw[0][1], Rcw[0][2], X, Y, Z, tcw[0]);
+        const float yc = slamit_gemm_row3(Rcw[1][0], Rcw[1][1], Rcw[1][2], X, Y, Z, tcw[1]);
+        const float zc = slamit_gemm_row3(Rcw[2][0], Rcw[2][1], Rcw[2][2], X, Y, Z, tcw[2]);
         const float invzc = 1.0 / zc;
         const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
         const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
@@ -800,9 +811,9 @@ int ORBmatcher::Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints,
         if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
         const cv::Mat p3Dw = pMP->GetWorldPos();
         const float X = p3Dw.template at<float>(0, 0), Y = p3Dw.template at<float>(1, 0), Z = p3Dw.template at<float>(2, 0);
-        const float xc = (float)((double)R[0][0] * X + (double)R[0][1] * Y + (double)R[0][2] * Z + (double)t[0]);   // cv::gemm: double sum, one rounding
-        const float yc = (float)((double)R[1][0] * X + (double)R[1][1] * Y + (double)R[1][2] * Z + (double)t[1]);   // cv::gemm: double sum, one rounding
-        const float zc = (float)((double)R[2][0] * X + (double)R[2][1] * Y + (double)R[2][2] * Z + (double)t[2]);   // cv::gemm: double sum, one rounding
+        const float xc = slamit_gemm_row3(R[0][0], R[0][1], R[0][2], X, Y, Z, t[0]);
+        const float yc = slamit_gemm_row3(R[1][0], R[1][1], R[1][2], X, Y, Z, t[1]);
+        const float zc = slamit_gemm_row3(R[2][0], R[2][1], R[2][2], X, Y, Z, t[2]);
         if (zc < 0.0f) continue;   // depth must be positive
         const float invz = 1 / zc;
         const float x = xc * invz, y = yc * invz;
