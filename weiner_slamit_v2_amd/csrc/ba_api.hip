@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <thread>
 #include <vector>
@@ -190,6 +191,10 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
     if (nwin == 0) return SLAMIT_OK;
     SLAMIT_USE_DEVICE(h->device);
     hipStream_t st = h->stream;
+    static const bool timing = getenv("SLAMIT_BA_TIMING") != nullptr;   // diagnostic: host phases of the call on stderr
+    const auto tclk = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = tclk();
+    double t_val = 0, t_prep = 0, t_queue = 0, t_loop = 0;
     // ---- validate ----
     int mk = 1, mp = 1, me = 1, Npad = BA_TILE;
     for (int b = 0; b < nwin; ++b) {
@@ -201,11 +206,10 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
             return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: null input array");
         if (!results[b].kf_pose || (P.n_pt && !results[b].pt_xyz))
             return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: null output array");
-        for (int e = 0; e < P.n_edge; ++e)
-            if (P.edge_kf[e] < 0 || P.edge_kf[e] >= P.n_kf || P.edge_pt[e] < 0 || P.edge_pt[e] >= P.n_pt)
-                return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: edge index out of range");
         mk = std::max(mk, P.n_kf); mp = std::max(mp, P.n_pt); me = std::max(me, P.n_edge);
     }
+    // (the edges' indices are checked by the threads that prepare the windows, before anything is packed)
+    t_val = tclk();
     // ---- one pinned block: [inputs of window 0 | inputs of window 1 | ...][outputs ...][2 x nwin LM states] ----
     std::vector<size_t> in_off(nwin), out_off(nwin);
     std::vector<IoLayout> dio(nwin);   // device addresses inside the slabs
@@ -230,8 +234,11 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
     std::vector<double> exec_mflop(nwin, 0.0);       // what the Schur product multiplies per trial (slamit_ba_profile_out)
     // per-window preparation (structure, CSR lists, packing into the pinned block) is host work of ~10 ns per edge: windows
     // are independent, so a batch is prepared by a few host threads; the copies are queued afterwards, in order
+    std::atomic<bool> bad_index(false);
     auto prepare = [&](int b) {
         const slamit_ba_problem& P = probs[b];
+        for (int e = 0; e < P.n_edge; ++e)
+            if (P.edge_kf[e] < 0 || P.edge_kf[e] >= P.n_kf || P.edge_pt[e] < 0 || P.edge_pt[e] >= P.n_pt) { bad_index = true; return; }
         uint8_t* slab = h->d_slab + (size_t)b * h->win_bytes;
         (void)slab;
         BaWin& w = wins[b];
@@ -291,9 +298,6 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
                 w.tile_alo[t] = lo; w.tile_ahi[t] = hi; w.tile_blo[t] = lo; w.tile_bhi[t] = hi;
                 if (w.nS >= BA_TILE * t && w.nS < BA_TILE * (t + 1)) { w.tile_blo[t] = 0; w.tile_bhi[t] = kmax; }   // row nS of GB = bl of every point
             }
-            for (int I = 0; I < T; ++I)   // the product's granule: 64 x 64 tile pairs (I <= J) over the k range both have non-zeros in
-                for (int J = I; J < T; ++J)
-                    exec_mflop[b] += 2.0 * BA_TILE * BA_TILE * std::max(0, std::min(w.tile_ahi[I], w.tile_bhi[J]) - std::max(w.tile_alo[I], w.tile_blo[J])) * 1e-6;
             // LDLt: row envelope.  first[r] = 6 * fcol[r / 6]; panel i (columns 32 i ..) only touches rows r with first[r] < 32 i + 32
             const int n = w.nS;
             for (int i = 0; i < BA_MAX_PANELS; ++i) { w.panel_hi[i] = (int16_t)std::max(n - 1, 0); w.back_lo[i] = 0; }
@@ -311,6 +315,11 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
             for (int c = 0; c < nfree; ++c) band = std::max(band, 6 * c + 5 - 6 * fcol[c]);
             w.band = std::min(band, std::max(n - 1, 0));
             w.solver = bak_solver_kind(n, w.band);
+            for (int I = 0; I < T; ++I)   // the product's granule: 64 x 64 tile pairs (I <= J) over the k range both have non-zeros in,
+                for (int J = I; J < T; ++J) {   // less the tiles a banded window's solver never reads (schur_tile_needed, ba_kernels.hip)
+                    if (w.solver == BA_SOLVER_BAND && BA_TILE * J - (BA_TILE * I + BA_TILE - 1) > w.band && w.nS / BA_TILE != J) continue;
+                    exec_mflop[b] += 2.0 * BA_TILE * BA_TILE * std::max(0, std::min(w.tile_ahi[I], w.tile_bhi[J]) - std::max(w.tile_alo[I], w.tile_blo[J])) * 1e-6;
+                }
         }
         // ---- inputs, straight into the pinned block: CSR by point / by keyframe (counting sort, caller order kept
         // inside each list), points in device order ----
@@ -351,7 +360,9 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         work();
         for (std::thread& t : pool) t.join();
         if (failed) return slamit_fail(SLAMIT_ERR_DEVICE, "slamit_ba_solve_batch: out of host memory while preparing the windows");
+        if (bad_index) return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: edge index out of range");
     }
+    t_prep = tclk();
     unsigned solvers = 0;
     for (int b = 0; b < nwin; ++b) {
         Npad = std::max(Npad, wins[b].Npad);
@@ -370,6 +381,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
     // of a stage is the number of trials the stage cannot do without (one per iteration in the robust stage; three in the
     // final one, whose "no progress three times" rule can end it that early), the chunks after it are single slots.
     // (Chunks of two throughout queued 20 slots for the 14 trials of a window-8 solve.)
+    t_queue = tclk();
     BaState* hs[2] = {reinterpret_cast<BaState*>(h->h_pin + st_off), reinterpret_cast<BaState*>(h->h_pin + st_off) + nwin};
     bool stopped = opts->stop && *opts->stop;  // :655-657
     size_t pev_used = 0;   // profiling solves: six events per queued slot
@@ -414,6 +426,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         }
         HIP_TRY(hipGetLastError());
     }
+    t_loop = tclk();
     // ---- results: one copy per window out of its output section ----
     bak_final(st, h->d_wins, h->d_io, nwin, mk, mp, me);
     for (int b = 0; b < nwin; ++b)
@@ -431,7 +444,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
             }
         for (int b = 0; b < nwin; ++b) O.schur_exec_mflop += exec_mflop[b];
     }
-    for (int b = 0; b < nwin; ++b) {
+    auto unpack = [&](int b) {
         const slamit_ba_problem& P = probs[b];
         slamit_ba_result& R = results[b];
         // the output section as the host sees it: same carve, shifted so that its output part starts at out_off[b]
@@ -454,13 +467,29 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
                     S0.dbg[4] >> 32, S0.dbg[4] & 0xffffffffull, S0.dbg[5] >> 32, S0.dbg[5] & 0xffffffffull, S0.dbg[6] >> 32, S0.dbg[6] & 0xffffffffull, S0.dbg[7]);
         }
         slamit_ba_stats* S = R.stats;
-        if (!S) continue;
+        if (!S) return;
         memset(S, 0, sizeof(*S));
         for (int sg = 0; sg < 2; ++sg) {
             S->n_its[sg] = S0.n_its[sg];
             S->chi2_init[sg] = S0.chi2_init[sg];
             for (int i = 0; i < SLAMIT_BA_MAX_ITS; ++i) { S->chi2[sg][i] = S0.chi2[sg][i]; S->lambda[sg][i] = S0.lam[sg][i]; S->trials[sg][i] = S0.trials[sg][i]; }
         }
+    };
+    {   // the windows' results are unpacked (points back into the caller's order) by the host threads that prepared them
+        const int nthreads = std::max(1, std::min(std::min(nwin, 16), (int)std::thread::hardware_concurrency()));
+        std::atomic<int> next(0);
+        auto work = [&]() { for (int b = next.fetch_add(1); b < nwin; b = next.fetch_add(1)) unpack(b); };
+        std::vector<std::thread> pool;
+        try {
+            for (int t = 1; t < nthreads && nwin >= 4; ++t) pool.emplace_back(work);
+        } catch (...) {}
+        work();
+        for (std::thread& t : pool) t.join();
+    }
+    if (timing) {
+        const double t_out = tclk();
+        fprintf(stderr, "[ba timing] %d windows: validate %.3f | prepare + pack %.3f | queue uploads %.3f | LM loop %.3f | download + unpack %.3f ms\n",
+                nwin, t_val - t_in, t_prep - t_val, t_queue - t_prep, t_loop - t_queue, t_out - t_loop);
     }
     return SLAMIT_OK;
 }

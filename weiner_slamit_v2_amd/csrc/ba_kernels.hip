@@ -367,19 +367,30 @@ __global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
 // MFMA operand pattern lane -> [row = lane&15][k = lane>>4]).
 #define LDS_PITCH 34
 
-__device__ __forceinline__ void schur_body(const BaWin& W, int tile, int s) {
+// does the reduced system need tile pair (I, J), I <= J, of the product?  Not when the two row tiles share no k range (the block
+// is zero: k_schur_reduce writes the zeros itself), and not when the banded solver takes the window and the whole tile lies
+// outside the band (nobody reads it) -- except for the tile column that holds the right-hand side (row nS of GB)
+__device__ __forceinline__ bool schur_tile_needed(const BaWin& W, int I, int J) {
+    if (max(W.tile_alo[I], W.tile_blo[J]) >= min(W.tile_ahi[I], W.tile_bhi[J])) return false;
+    if (W.solver == BA_SOLVER_BAND && BA_TILE * J - (BA_TILE * I + BA_TILE - 1) > W.band && W.nS / BA_TILE != J) return false;
+    return true;
+}
+
+__device__ __forceinline__ void schur_body(const BaWin& W, int tile, int s, int nsplit) {
     if (W.st->done) return;
     const int T = W.Npad / BA_TILE;
     // `tile` enumerates upper-triangular macro tiles
     int I = 0, rem = tile;
     while (I < T && rem >= T - I) { rem -= T - I; ++I; }
     const int J = I + rem;
-    if (I >= T) return;
+    if (I >= T || !schur_tile_needed(W, I, J)) return;
     // Only the k range in which BOTH row tiles have non-zeros is multiplied (points are sorted by their first observing
-    // keyframe, ba_api.hip): its slabs of BA_KC are dealt to the BA_SPLITS splits; a split without a slab stores zeros.
+    // keyframe, ba_api.hip): its slabs of BA_KC are dealt to the launch's nsplit <= BA_SPLITS splits (gridDim.y: sixteen for a single
+    // window, which needs the parallelism; eight for a batch, whose windows already fill the chip -- half of the partial
+    // tiles to write and to sum); a split without a slab stores zeros.
     const int klo = max(W.tile_alo[I], W.tile_blo[J]), khi = min(W.tile_ahi[I], W.tile_bhi[J]);
     const int nslab = khi > klo ? (khi - klo) / BA_KC : 0;
-    const int k0 = klo + (int)((long)nslab * s / BA_SPLITS) * BA_KC, kend = klo + (int)((long)nslab * (s + 1) / BA_SPLITS) * BA_KC;
+    const int k0 = klo + (int)((long)nslab * s / nsplit) * BA_KC, kend = klo + (int)((long)nslab * (s + 1) / nsplit) * BA_KC;
     __shared__ double As[BA_TILE * LDS_PITCH];
     __shared__ double Bs[BA_TILE * LDS_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -438,21 +449,21 @@ __device__ __forceinline__ void schur_body(const BaWin& W, int tile, int s) {
         }
 }
 
-__global__ __launch_bounds__(256) void k_schur(BaWin* wins) { schur_body(wins[blockIdx.z], blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_schur(BaWin* wins) { schur_body(wins[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.y); }
 
 // Both in one launch for the slots after a stage's first (neither needs the other; k_schur_reduce needs both): the pose blocks ride
-// as extra workgroups behind the Schur tiles -- keyframe (x - ntiles) * BA_SPLITS + y.
+// as extra workgroups behind the Schur tiles -- keyframe (x - ntiles) * (splits of the launch) + y.
 __global__ __launch_bounds__(256) void k_schur_pose(BaWin* wins, int ntiles) {
     const BaWin& W = wins[blockIdx.z];
-    if ((int)blockIdx.x < ntiles) schur_body(W, blockIdx.x, blockIdx.y);
-    else pose_reduce_body(W, ((int)blockIdx.x - ntiles) * BA_SPLITS + (int)blockIdx.y);
+    if ((int)blockIdx.x < ntiles) schur_body(W, blockIdx.x, blockIdx.y, gridDim.y);
+    else pose_reduce_body(W, ((int)blockIdx.x - ntiles) * (int)gridDim.y + (int)blockIdx.y);
 }
 
 __host__ __device__ inline int ldlt_band_rs(int bw);
 __host__ __device__ inline bool ldlt_band_ok(int n, int bw);
 
 // ---- S7: S = Hpp + lambda*I - sum_s part[s],  b_s = bp - coeff --------------------------------------
-__global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins) {
+__global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins, int nsplit) {
     const BaWin& W = wins[blockIdx.y];
     BaState* st = W.st;
     if (st->done) return;
@@ -460,8 +471,11 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int r = idx / N, c = idx - r * N;
     if (r >= n || c > n || c < r) return;
+    // a banded window's solver only reads the band (and the right-hand side): the entries beyond are neither summed nor stored
+    if (W.solver == BA_SOLVER_BAND && c - r > W.band && c != n) return;
     double v = 0;
-    for (int s = 0; s < BA_SPLITS; ++s) v += W.part[(size_t)s * N * N + (size_t)r * N + c];
+    if (schur_tile_needed(W, r / BA_TILE, c / BA_TILE))   // (else the product's block is zero and no workgroup wrote its partials)
+        for (int s = 0; s < nsplit; ++s) v += W.part[(size_t)s * N * N + (size_t)r * N + c];
     if (c == n) {
         W.rhs[r] = W.bp[r] - v;  // _bschur = _b - coefficients
         return;
@@ -1546,6 +1560,8 @@ void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int st
 // `ev` (profiling solves only, slamit_ba_profile): six events recorded at the phase boundaries of the slot -- before the
 // linearisation, after it, after the Schur complement, after the reduced solve, after the update, after residuals + decision
 void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, unsigned solvers, hipEvent_t* ev) {
+    static const int nsplit_env = getenv("SLAMIT_BA_NSPLIT") ? atoi(getenv("SLAMIT_BA_NSPLIT")) : 0;   // A/B runs
+    const int nsplit = nsplit_env >= 1 && nsplit_env <= BA_SPLITS ? nsplit_env : nwin >= 16 ? 8 : BA_SPLITS;   // split-K of the Schur product: a batch brings its own parallelism (64 windows: 2 / 4 / 8 / 16 splits -> 47.8k / 49.7k / 52.8k / 50.0k LM it/s)
     const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt * BA_PG + 255) / 256, nwin);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (first) {
@@ -1559,9 +1575,9 @@ void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int
     }
     if (ev) (void)hipEventRecord(ev[1], st);
     const int T = Npad / BA_TILE, ntiles = T * (T + 1) / 2;
-    if (first) hipLaunchKernelGGL(k_schur, dim3(ntiles, BA_SPLITS, nwin), dim3(256), 0, st, wins);
-    else hipLaunchKernelGGL(k_schur_pose, dim3(ntiles + (max_kf + BA_SPLITS - 1) / BA_SPLITS, BA_SPLITS, nwin), dim3(256), 0, st, wins, ntiles);
-    hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins);
+    if (first) hipLaunchKernelGGL(k_schur, dim3(ntiles, nsplit, nwin), dim3(256), 0, st, wins);
+    else hipLaunchKernelGGL(k_schur_pose, dim3(ntiles + (max_kf + nsplit - 1) / nsplit, nsplit, nwin), dim3(256), 0, st, wins, ntiles);
+    hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins, nsplit);
     if (ev) (void)hipEventRecord(ev[2], st);
     // `solvers`: bit BA_SOLVER_* set when a window of the batch takes that kernel
     if (solvers & (1u << BA_SOLVER_BAND)) hipLaunchKernelGGL(k_ldlt_band, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);
