@@ -388,6 +388,10 @@ def main():
                          "pipeline = BASELINE configs[4]: --streams 720p streams dealt over the ranks (stream s on rank s %% N), "
                          "each rank also solving its streams' local-BA windows, results gathered in fixed-capacity slots")
     ap.add_argument("--streams", type=int, default=8, help="pipeline config: total camera streams over all ranks")
+    ap.add_argument("--ba-workers", type=int, default=3, help="pipeline config: local-BA batches in flight per rank (host threads, each with its own "
+                    "BA handle and HIP stream); a step's slot carries the poses of the batch submitted that many steps earlier")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the collectives even on ONE rank (a one-GPU "
+                    "test then drives RCCL: communicator, device-tensor all_gather_into_tensor, async work handles)")
     args = ap.parse_args()
     global W, H, NFEAT, FAST_BYTES_PER_FRAME
     W, H, NFEAT, FAST_BYTES_PER_FRAME, cfg_name = CONFIGS[args.config]
@@ -410,8 +414,16 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
+        if args.force_dist:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            if args.backend == "gloo":
+                dist.init_process_group("gloo", rank=0, world_size=1)
+            else:
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
-    cdev = torch.device("cpu") if (world > 1 and args.backend == "gloo") else dev   # where collective tensors live
+    cdev = torch.device("cpu") if ((world > 1 or args.force_dist) and args.backend == "gloo") else dev   # where collective tensors live
 
     from weiner_slamit_v2_amd import api, shard, synth
 
@@ -446,16 +458,29 @@ def main():
     d_best = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_second = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     gather = shard.SummaryGather(B, 2, cdev, world)  # per-frame (keypoints, matches) to every rank
-    slots = ba_opt = ba_probs = None
+    slots = ba = ba_probs = None
     ba_its = [0]
     if pipeline:
-        # every stream also owns a local-BA window (BASELINE configs[3] geometry, window-8 visibility); the rank's windows are
-        # solved as one batch on the BA handle's own HIP stream, from a host thread, beside the extract + match launches
-        import threading
-        slots = shard.SlotGather(B, cdev, world)
+        # every stream also owns a local-BA window (BASELINE configs[3] geometry, window-8 visibility, its own noise and outliers:
+        # seed 12345 + stream id); the rank's windows of a step are ONE batch, solved by one of --ba-workers host threads on its
+        # own BA handle and HIP stream beside the extract + match launches.  Nothing in a step waits for the batch it submits:
+        # the step's slots take the poses of the batch submitted --ba-workers steps earlier (shard.BaWorkers)
+        slots = shard.SlotGather(B, cdev, world, force_collective=args.force_dist)
         ba_probs = [synth.synth_ba(50, 2000, 8, seed=12345 + sid) for sid in mine]
-        ba_opt = api.Optimizer(64, 2048, max(len(p["edge_kf"]) for p in ba_probs) + 64, B, dev.index)
-        ba_opt.LocalBundleAdjustmentBatch(ba_probs)   # warm-up: pinned block, kernels
+        ba_edges = max(len(p["edge_kf"]) for p in ba_probs) + 64
+        ba = shard.BaWorkers(lambda: api.Optimizer(64, 2048, ba_edges, B, dev.index), args.ba_workers)
+        for j in [ba.submit(ba_probs) for _ in range(ba.n)]:   # warm-up: every worker's handle, pinned block, kernels
+            ba.result(j)
+        # slot packing without per-step tensor construction: pinned staging for what the BA hands back on the host (iterations,
+        # 50 poses per stream), constants on the device
+        NPIN = 4   # a ring: the host runs ahead of the stream, so a staging buffer is reused only after the copy out of it has run
+        pin_its = [torch.zeros(B, dtype=torch.int32).pin_memory() for _ in range(NPIN)]
+        pin_pose = [torch.zeros((B, shard.SLOT_BA_KF, shard.SLOT_BA_DOUBLES), dtype=torch.float64).pin_memory() for _ in range(NPIN)]
+        pin_ev = [torch.cuda.Event() for _ in range(NPIN)]
+        last_ba = {"its": np.zeros(B, np.int32), "pose": np.zeros((B, shard.SLOT_BA_KF, shard.SLOT_BA_DOUBLES))}
+        d_sid = torch.tensor(mine, dtype=torch.int32, device=dev)
+        d_col = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
+        ba_jobs = []
     # ONE non-default stream carries the whole step: extract(k) -> match(k) are ordered by the stream.  (A NULL
     # stream handle would mean "the extractor's own stream" to the C-ABI and un-order the two calls.)
     tstream = torch.cuda.Stream(dev)
@@ -470,6 +495,12 @@ def main():
     ev_x = [torch.cuda.Event() for _ in range(NBUF)]   # extract into buffer i finished
     ev_m = [torch.cuda.Event() for _ in range(NBUF)]   # the match that READ buffer i as "previous frame" finished
 
+    def ba_take(res):
+        """A finished batch becomes what the next slots carry (iterations + poses as quaternion | t); returns its LM iterations."""
+        last_ba["its"] = np.array([sum(r["stats"]["n_its"]) for r in res], np.int32)
+        last_ba["pose"] = shard.rt_to_quat_t(np.concatenate([r["kf_pose"] for r in res])).reshape(B, shard.SLOT_BA_KF, shard.SLOT_BA_DOUBLES)
+        return int(last_ba["its"].sum())
+
     def step(k):
         cur, prv = k % NBUF, (k - 1) % NBUF
         if two_streams:
@@ -483,31 +514,42 @@ def main():
         if two_streams:
             ev_m[prv].record(mstream)
         if pipeline:
-            ba_out = {}
-            th = threading.Thread(target=lambda: ba_out.setdefault("r", ba_opt.LocalBundleAdjustmentBatch(ba_probs)))
-            th.start()                                  # ctypes releases the GIL inside the solve
+            ba_jobs.append(ba.submit(ba_probs))   # this step's windows; never waited for here
         if world > 1 and not pipeline:  # result summary to every rank (the only cross-GPU traffic of the path)
             gather.local[:, 0] = d_n[cur]
             gather.step()
         if pipeline:
-            # fixed-capacity result slots: header, first 2000 keypoints + descriptors, the window's 50 poses
-            th.join()
-            n_kp = torch.clamp(d_n[cur], max=shard.SLOT_KP_CAP)
-            acc = ((d_best <= 50) & (d_best.float() < 0.9 * d_second.float()) & (torch.arange(cap, device=dev)[None, :] < d_n[cur][:, None])).sum(1).to(torch.int32)
-            hdr = torch.stack([n_kp, acc, torch.tensor([sum(r["stats"]["n_its"]) for r in ba_out["r"]], dtype=torch.int32, device=dev),
-                               torch.tensor(mine, dtype=torch.int32, device=dev)], 1)
-            poses = torch.from_numpy(np.stack([shard.rt_to_quat_t(r["kf_pose"]) for r in ba_out["r"]])).to(dev)
-            ba_its[0] += sum(sum(r["stats"]["n_its"]) for r in ba_out["r"])
-            if cdev.type == "cpu":   # gloo rehearsal: the slots live on the host
-                slots.header().copy_(hdr.cpu()); slots.keypoints().copy_(d_kps[cur][:, :shard.SLOT_KP_CAP].cpu())
-                slots.descriptors().copy_(d_desc[cur][:, :shard.SLOT_KP_CAP].cpu()); slots.ba_poses().copy_(poses.cpu())
-            else:
-                slots.header().copy_(hdr); slots.keypoints().copy_(d_kps[cur][:, :shard.SLOT_KP_CAP])
-                slots.descriptors().copy_(d_desc[cur][:, :shard.SLOT_KP_CAP]); slots.ba_poses().copy_(poses)
+            # fixed-capacity result slots: header, first 2000 keypoints + descriptors, and the 50 poses of the BA batch that was
+            # submitted --ba-workers steps ago (the oldest one in flight: usually long done)
+            if len(ba_jobs) > ba.n:
+                ba_its[0] += ba_take(ba.result(ba_jobs.pop(0)))
+            j = k % NPIN
+            pin_ev[j].synchronize()   # (returns at once unless the stream is four steps behind)
+            pin_its[j].numpy()[:] = last_ba["its"]
+            pin_pose[j].numpy()[:] = last_ba["pose"]
+            on_host = cdev.type == "cpu"   # gloo rehearsal: the slots live on the host
+            hdr, kp, ds, bp = slots.header(), slots.keypoints(), slots.descriptors(), slots.ba_poses()
+            n_cur = d_n[cur]
+            acc = ((d_best <= 50) & (d_best.float() < 0.9 * d_second.float()) & (d_col < n_cur[:, None])).sum(1, dtype=torch.int32)
+            if on_host:
+                hdr[:, 0].copy_(torch.clamp(n_cur, max=shard.SLOT_KP_CAP).cpu()); hdr[:, 1].copy_(acc.cpu()); hdr[:, 2].copy_(pin_its[j]); hdr[:, 3].copy_(d_sid.cpu())
+                kp.copy_(d_kps[cur][:, :shard.SLOT_KP_CAP].cpu()); ds.copy_(d_desc[cur][:, :shard.SLOT_KP_CAP].cpu()); bp.copy_(pin_pose[j])
+            else:   # device to device, plus two small pinned-to-device copies on the step's stream
+                hdr[:, 0].copy_(torch.clamp(n_cur, max=shard.SLOT_KP_CAP)); hdr[:, 1].copy_(acc); hdr[:, 2].copy_(pin_its[j], non_blocking=True); hdr[:, 3].copy_(d_sid)
+                kp.copy_(d_kps[cur][:, :shard.SLOT_KP_CAP]); ds.copy_(d_desc[cur][:, :shard.SLOT_KP_CAP]); bp.copy_(pin_pose[j], non_blocking=True)
+                pin_ev[j].record(tstream)
             slots.step()
+
+    def ba_drain():
+        """Waits for every BA batch still in flight (the timed region ends with its work done); returns their LM iterations."""
+        its = 0
+        while pipeline and ba_jobs:
+            its += ba_take(ba.result(ba_jobs.pop(0)))
+        return its
 
     for k in range(args.warmup):
         step(k)
+    ba_drain()
     torch.cuda.synchronize(dev)
     ba_its[0] = 0
     ext.profile(5)   # timed regions: events around the dominant kernel (FAST) only, on every 4th step
@@ -531,6 +573,7 @@ def main():
             gather.flush()   # the last step's summary is part of the timed work
         if pipeline:
             last_slots = slots.flush()
+            ba_its[0] += ba_drain()   # the region's BA batches are part of its work: all of them finish inside it
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -548,6 +591,7 @@ def main():
         gather.flush()
     if pipeline:
         slots.flush()
+        ba_drain()
     torch.cuda.synchronize(dev)
     all_stages = ext.profile(0)
 
@@ -595,9 +639,12 @@ def main():
                                    "brute-force 256-bit Hamming best/second match vs the stream's previous frame; "
                                    "%d independent streams per GPU per step" % (cfg_name, W, H, NFEAT, B) +
                                    ("; every stream also solves one local-BA window (50 KF, 2000 points, window-8) per step on the BA "
-                                    "handle's own HIP stream; every stream's result slot (count + 2000 keypoints + 2000 descriptors + "
-                                    "50 poses, %d B) is all_gathered to every rank, one step late" % shard.SLOT_BYTES if pipeline else ""),
+                                    "handle's own HIP stream (%d batches in flight per rank: a slot's poses come from the batch submitted that many steps "
+                                    "earlier); every stream's result slot (count + 2000 keypoints + 2000 descriptors + "
+                                    "50 poses, %d B) is all_gathered to every rank, one step late" % (args.ba_workers, shard.SLOT_BYTES) if pipeline else ""),
                        "frames_per_step_per_gpu": B, "distinct_frame_pairs_per_gpu": uniq,
+                       "collective": (args.backend if (world > 1 or args.force_dist) else None),
+                       "ba_batches_in_flight": args.ba_workers if pipeline else None,
                        "parallelism": ("stream s on rank s %% %d, results gathered over RCCL" % world) if pipeline else
                                       "streams sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"kernel": "fast_cells_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -630,8 +677,11 @@ def main():
         if not args.no_ba and world == 1 and not pipeline:
             out["secondary"] = ba_secondary(dev.index, args.steps, with_cpu=not args.no_cpu)
         print(json.dumps(out), flush=True)
+    if pipeline:
+        ba.close()
     if world > 1:
         dist.barrier()
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

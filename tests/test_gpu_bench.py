@@ -61,3 +61,14 @@ def test_bench_pipeline_config_single_gpu_and_two_rank_rehearsal():
     d = _line(out)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step_per_gpu"] == 4
     assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01   # 8 streams in all, whatever the rank count
+
+
+def test_bench_pipeline_forced_collective_on_one_gpu():
+    """--force-dist: an initialised nccl (= RCCL) process group of size one, so the pipeline's all_gather_into_tensor of the
+    device-resident slots, its async work handle and the max-over-ranks all_reduce run through RCCL on this one GPU before an
+    8-GPU node sees them.  bench.py's own asserts (8 slots, 2000 keypoints, unit quaternions, BA iterations > 0) still hold."""
+    out = subprocess.check_output([sys.executable, "bench.py", "--config", "pipeline", "--force-dist", "--steps", "6", "--warmup", "2",
+                                   "--reps", "1", "--no-cpu"], cwd=ROOT, stderr=subprocess.STDOUT, timeout=600)
+    d = _line(out)
+    assert d["n_gpus"] == 1 and d["config"]["frames_per_step_per_gpu"] == 8 and d["config"].get("collective") == "nccl"
+    assert d["secondary"]["value"] > 0

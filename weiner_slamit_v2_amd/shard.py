@@ -85,10 +85,13 @@ class SlotGather:
         then     SLOT_BA_KF x 7 float64: the window's optimised keyframe poses (quaternion x y z w, translation)
     No reduction is needed for correctness: streams are independent, the gather only makes every result visible everywhere."""
 
-    def __init__(self, rows, device, world):
+    def __init__(self, rows, device, world, force_collective=False):
         self.world, self.rows = world, rows
+        # force_collective: run the all_gather even on one rank (an initialised process group of size 1): the RCCL path -- communicator,
+        # device-tensor all_gather_into_tensor, async work handle -- is then exercised by a one-GPU test before a node sees it
+        self.collective = world > 1 or force_collective
         self._loc = [torch.zeros((rows, SLOT_BYTES), dtype=torch.uint8, device=device) for _ in range(2)]
-        self._all = [torch.zeros((world * rows, SLOT_BYTES), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else self._loc
+        self._all = [torch.zeros((world * rows, SLOT_BYTES), dtype=torch.uint8, device=device) for _ in range(2)] if self.collective else self._loc
         self._k = 0
         self._pending = None
 
@@ -117,7 +120,7 @@ class SlotGather:
         """Publishes the local slots; returns every rank's slots of the PREVIOUS step (None on the first call)."""
         prev = self.flush()
         cur = self._k & 1
-        if self.world > 1:
+        if self.collective:
             self._pending = (dist.all_gather_into_tensor(self._all[cur], self._loc[cur], async_op=True), self._all[cur])
         else:
             self._pending = (None, self._loc[cur])
@@ -132,6 +135,71 @@ class SlotGather:
             work.wait()
         self._pending = None
         return out
+
+
+class BaWorkers:
+    """The pipeline's local-BA side: `nworkers` host threads, each with its own BA handle (own HIP stream and pinned block), take
+    the rank's per-step window batches in turn.  A solve of eight windows is latency bound (~4 ms of small dependent launches
+    that leave the chip mostly idle), so several batches IN FLIGHT beside the extractor's launches multiply the throughput;
+    submit() never blocks on the solve it queues, result() of a job blocks until that job is done.  A step's slot therefore
+    carries the poses of the batch submitted `nworkers` steps earlier (stated in the bench line)."""
+
+    def __init__(self, make_optimizer, nworkers):
+        import queue
+        import threading
+
+        self.n = max(1, int(nworkers))
+        self._q = [queue.Queue() for _ in range(self.n)]
+        self._done = {}
+        self._cv = threading.Condition()
+        self._submitted = 0
+        self._err = None
+
+        def run(i):
+            try:
+                opt = make_optimizer()
+                while True:
+                    job = self._q[i].get()
+                    if job is None:
+                        break
+                    jid, probs = job
+                    res = opt.LocalBundleAdjustmentBatch(probs)   # ctypes releases the GIL inside the solve
+                    with self._cv:
+                        self._done[jid] = res
+                        self._cv.notify_all()
+                opt.close()
+            except Exception as e:   # surfaced by result()
+                with self._cv:
+                    self._err = e
+                    self._cv.notify_all()
+
+        self._threads = [threading.Thread(target=run, args=(i,), daemon=True) for i in range(self.n)]
+        for t in self._threads:
+            t.start()
+
+    def submit(self, probs):
+        jid = self._submitted
+        self._q[jid % self.n].put((jid, probs))
+        self._submitted += 1
+        return jid
+
+    def ready(self, jid):
+        with self._cv:
+            return jid in self._done
+
+    def result(self, jid, keep=False):
+        with self._cv:
+            while jid not in self._done and self._err is None:
+                self._cv.wait()
+            if self._err is not None:
+                raise self._err
+            return self._done[jid] if keep else self._done.pop(jid)
+
+    def close(self):
+        for q in self._q:
+            q.put(None)
+        for t in self._threads:
+            t.join(30)
 
 
 def rt_to_quat_t(rt):
@@ -170,6 +238,6 @@ def rt_to_quat_t(rt):
 
 def max_over_ranks(value, device, world):
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
