@@ -148,6 +148,22 @@ def test_batch_equals_single_and_oracle():
         assert np.array_equal(ks[i], ks2[i]) and np.array_equal(ds[i], ds2[i])
 
 
+def test_large_batch_launch_shape_is_bit_exact():
+    """From 96 frames per call the octree pass runs 256-thread workgroups with LDS room for 2,048 keys (five per CU), so the long
+    lists of the low levels take the HBM key workspace while the short ones stay in LDS: same keypoints as the oracle, whichever
+    frame of the batch."""
+    kinds = [synth.synth_frame(640, 480, 40), synth.noise_frame(640, 480, 6), synth.synth_frame(640, 480, 41), synth.flat_frame(640, 480)]
+    frames = np.stack([kinds[i % 4] for i in range(96)])
+    ext, orc = api.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=96), ob.OrbOracle(1000)
+    ks, ds = ext.extract_batch(frames)
+    want = [orc.extract(f) for f in kinds]
+    for i in (0, 1, 2, 3, 49, 94, 95):
+        _assert_same(ks[i], ds[i], want[i % 4][0], want[i % 4][1], "batch96[%d]" % i)
+    for i in range(4, 96):
+        assert np.array_equal(ks[i], ks[i % 4]) and np.array_equal(ds[i], ds[i % 4]), i
+    assert len(ext.debug_candidates(0, 0)) > 2048
+
+
 def test_device_buffer_entry_point():
     import torch
 

@@ -7,14 +7,14 @@ import numpy as np
 sys.path.insert(0, ".")
 from weiner_slamit_v2_amd import api, synth  # noqa: E402
 
-B = 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 frames = synth.synth_batch(640, 480, B)
 ext = api.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
 ext.extract_batch(frames)
 ext.extract_batch(frames)
 out = np.zeros(4096 * 8, np.uint64)
 api.lib().slamit_diag_oct(out.ctypes.data_as(C.c_void_p))
-r = out.reshape(-1, 8)[:B * 8].reshape(B, 8, 8)
+r = out.reshape(-1, 8)[:B * 8].reshape(8, B, 8).transpose(1, 0, 2)   # the grid is (frames, levels): workgroup w = level * frames + frame
 t0 = r[:, :, 7].min()
 print("realtime (100 MHz): first start 0, last start %.1f us, last end %.1f us" % ((r[:, :, 7].max() - t0) / 100.0, (r[:, :, 5].max() - t0) / 100.0))
 for lvl in (0, 7):

@@ -1,14 +1,17 @@
-"""Prints start-to-start timeline of the last extract call from a rocprofv3 kernel_trace.csv."""
+"""Prints the kernel timeline (start, end, duration) of one step in the middle of the run from a rocprofv3 kernel_trace.csv."""
 import csv
 import glob
 import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# last occurrence of the first pipeline kernel
-key = sys.argv[2] if len(sys.argv) > 2 else "resize"
-last = max(i for i, r in enumerate(rows) if key in r["Kernel_Name"] and (i == 0 or key not in rows[i - 1]["Kernel_Name"]))
-t0 = int(rows[last]["Start_Timestamp"])
-for r in rows[last - 30:last - 14]:
+key = sys.argv[2] if len(sys.argv) > 2 else "fast_cells"
+idx = [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
+mid = idx[len(idx) // 2]
+nxt = idx[len(idx) // 2 + 1]
+per = nxt - mid
+lo = mid - 8
+t0 = int(rows[lo]["Start_Timestamp"])
+for r in rows[lo:lo + per + 4]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print("%-40s start %8.1f us  dur %7.1f us" % (r["Kernel_Name"][:40], (s - t0) / 1e3, (e - s) / 1e3))
+    print("%-44s start %8.1f  end %8.1f  dur %7.1f us  q%s" % (r["Kernel_Name"].replace("void ", "")[:44], (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "")))

@@ -925,6 +925,12 @@ __host__ __device__ inline size_t orbk_octree_node_bytes(int node_cap) {
 #define OCT_LDS_KEYS_MIN 2048
 #define OCT_LDS_BUDGET (78 * 1024)   // per workgroup, so that two fit a CU
 
+// depth of the path table the full passes are served from: the deepest of 4, 3, 2 whose table (4 + .. + 4^depth ints per root)
+// fits `room` ints; 0 = no table (a sweep over the keys per pass)
+__device__ __forceinline__ int nIniFD(int nIni, int room) {
+    return nIni * 340 <= room ? 4 : nIni * 84 <= room ? 3 : nIni * 20 <= room ? 2 : 0;
+}
+
 // XY / ND: per-candidate position and current node, in LDS when the list fits (LK) and in the HBM workspace otherwise.
 template <int NT, bool LK>
 __device__ __forceinline__ void octree_body(
@@ -945,6 +951,17 @@ __device__ __forceinline__ void octree_body(
     int& s_n = s_vars[0]; int& s_expand = s_vars[1]; int& s_k = s_vars[2]; int& s_flag = s_vars[3];
     const int N = L.quota;
     OD_DECL;
+    // The passes that split EVERY expandable node ("full" passes, ORBextractor.cc:600-686) do not need a sweep over the keys each:
+    // a key's quadrant path down to depth FD follows from its root box alone, so ONE sweep histograms the depth-FD paths, the
+    // shallower populations are sums of four, and a full pass takes its children's populations from the table (node i carries
+    // root | depth | path).  The keys get their node labels once, when the full passes end, through a path -> node table.
+    // The histogram lives in `best` (used after the loop only), the node codes in rankv/sorted (used by "largest first" passes,
+    // i.e. after the full ones).  Depth 4 when the table fits (340 ints per root), else 3, 2 or the sweep per pass.
+    const int two_cap = 2 * cap;
+    const int FD = nIniFD(L.nIni, two_cap);
+    const int HS = ((4 << (2 * FD)) - 4) / 3;          // table ints per root: 4 + 16 + ... + 4^FD
+    int* const hist = reinterpret_cast<int*>(best);
+    int* const ncode0 = rankv;                          // [2 * cap]: two generations, like box0 / cnt0
 
     // ---- roots (ORBextractor.cc:556-598) ----
     const int nIni = L.nIni;
@@ -953,39 +970,84 @@ __device__ __forceinline__ void octree_body(
         box0[tid] = b;
         cnt0[tid] = 0;
     }
+    for (int e = tid; e < nIni * HS; e += NT) hist[e] = 0;
     __syncthreads();
     {
         const int nCols = L.nCols, wCell = L.wCell, hCell = L.hCell;
         const unsigned inv_cols = 0xFFFFFFFFu / (unsigned)nCols + 1u;   // cell / nCols == umulhi(cell, inv) while cell * nCols < 2^32
         const float hX = L.hX;
-        for (int k = tid; k < n_keys; k += NT) {
-            unsigned order = (unsigned)K[k];
+        const int lane = tid & 63;
+        // (every lane stays in the loop: the run lengths below are taken over whole waves; four keys per thread are fetched before
+        // the first is used -- the loop body's LDS atomics keep the compiler from overlapping the trips' global loads itself)
+        for (int kb4 = 0; kb4 < n_keys; kb4 += 4 * NT) {
+            unsigned ord4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ord4[j] = (unsigned)K[min(kb4 + j * NT + tid, n_keys - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+            const int kb = kb4 + j * NT;
+            if (kb >= n_keys) break;
+            const int k = kb + tid;
+            const bool valid = k < n_keys;
+            unsigned order = ord4[j];
             int lx = order & 63, ly = (order >> 6) & 63, cell = order >> 12;
             int ci = (int)__umulhi((unsigned)cell, inv_cols), cj = cell - ci * nCols;
             int x = cj * wCell + lx, y = ci * hCell + ly;
-            XY[k] = (uint32_t)x | ((uint32_t)y << 16);
             int r = (int)((float)x / hX);  // vpIniNodes[kp.pt.x/hX]
             r = min(r, nIni - 1);
-            ND[k] = (uint16_t)r;
-            // every key of a wave falls into one of <= 8 roots: count per root with ballots, one atomic per wave and
-            // root (same-address LDS atomics of 64 lanes would serialise)
-            for (int q = 0; q < nIni; ++q) {
-                const unsigned long long m = __ballot(r == q);
-                if (m && (tid & 63) == (int)__builtin_ctzll(m)) atomicAdd(&cnt0[q], (int)__popcll(m));
+            if (valid) XY[k] = (uint32_t)x | ((uint32_t)y << 16);
+            if (FD) {
+                Box16 b = box0[r];
+                int path = 0;
+                for (int d = 0; d < FD; ++d) {
+                    int mx, my;
+                    const int q = box_quadrant(b, x, y, &mx, &my);
+                    b = child_box(b, q);
+                    path = path * 4 + q;
+                }
+                if (valid) ND[k] = (uint16_t)((r << 8) | path);
+                // the keys come in cell order, so neighbouring lanes mostly share a bin: one atomic per RUN of equal bins
+                const int bin = valid ? r * HS + (HS - (1 << (2 * FD))) + path : -1;
+                const int prev = __shfl_up(bin, 1);
+                const bool head = lane == 0 || bin != prev;
+                const unsigned long long heads = __ballot(head);
+                if (head && bin >= 0) {
+                    const unsigned long long rest = (heads >> lane) >> 1;
+                    atomicAdd(&hist[bin], rest ? (int)__builtin_ctzll(rest) + 1 : 64 - lane);
+                }
+            } else {
+                if (valid) ND[k] = (uint16_t)r;
+                // every key of a wave falls into one of <= 8 roots: count per root with ballots, one atomic per wave and
+                // root (same-address LDS atomics of 64 lanes would serialise)
+                for (int q = 0; q < nIni; ++q) {
+                    const unsigned long long m = __ballot(valid && r == q);
+                    if (m && lane == (int)__builtin_ctzll(m)) atomicAdd(&cnt0[q], (int)__popcll(m));
+                }
+            }
             }
         }
     }
     __syncthreads();
+    for (int d = FD - 1; d >= 1; --d) {   // populations of the shallower paths
+        const int off = ((4 << (2 * d)) - 4) / 3 - (1 << (2 * d)), offc = off + (1 << (2 * d)), per = 1 << (2 * d);
+        for (int e = tid; e < nIni * per; e += NT) {
+            const int r = e >> (2 * d), pth = e & (per - 1);
+            const int* c = &hist[r * HS + offc + 4 * pth];
+            hist[r * HS + off + pth] = (c[0] + c[1]) + (c[2] + c[3]);
+        }
+        __syncthreads();
+    }
     if (tid == 0) {  // erase empty roots, keep order (<= 8 roots)
         int m = 0, dropped = 0;
         for (int i = 0; i < nIni; ++i) {
-            if (cnt0[i] > 0) { scanbuf[i] = m; box0[m] = box0[i]; cnt0[m] = cnt0[i]; ++m; }
+            if (FD) cnt0[i] = (hist[i * HS] + hist[i * HS + 1]) + (hist[i * HS + 2] + hist[i * HS + 3]);
+            if (cnt0[i] > 0) { scanbuf[i] = m; box0[m] = box0[i]; cnt0[m] = cnt0[i]; ncode0[m] = i << 16; ++m; }
             else { scanbuf[i] = -1; dropped = 1; }
         }
         s_n = m; s_flag = dropped;
     }
     __syncthreads();
-    if (s_flag) {
+    if (s_flag && !FD) {
         for (int k = tid; k < n_keys; k += NT) ND[k] = (uint16_t)scanbuf[ND[k]];
         __syncthreads();
     }
@@ -993,12 +1055,45 @@ __device__ __forceinline__ void octree_body(
     int cur = 0;
     int n = s_n;
     bool finish = false, careful = false;
+    bool tabled = FD > 0;     // the keys still carry root | path; node populations come from the table
+    int depth_done = 0;
+    // keys -> nodes once the full passes are over: every node of the list enters its index at its (root, depth, path); a key
+    // looks its path up from the deepest level to the root (the list's nodes are disjoint, so exactly one level answers)
+    auto label_keys = [&]() {
+        for (int e = tid; e < nIni * HS; e += NT) hist[e] = -1;
+        if (tid < ORB_MAX_ROOTS) scanbuf[tid] = -1;
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            const int c = ncode0[cur * cap + i], r = c >> 16, d = (c >> 12) & 15, pth = c & 4095;
+            if (d == 0) scanbuf[r] = i;
+            else hist[r * HS + ((4 << (2 * d)) - 4) / 3 - (1 << (2 * d)) + pth] = i;
+        }
+        __syncthreads();
+        for (int k = tid; k < n_keys; k += NT) {
+            const int lab = ND[k], r = lab >> 8, pth = lab & 255;
+            int node = scanbuf[r];
+            for (int d = 1; d <= FD; ++d) {
+                const int v = hist[r * HS + ((4 << (2 * d)) - 4) / 3 - (1 << (2 * d)) + (pth >> (2 * (FD - d)))];
+                node = v >= 0 ? v : node;
+            }
+            ND[k] = (uint16_t)node;
+        }
+        __syncthreads();
+    };
     OD_STAMP(0);
     while (!finish) {
         const int prevSize = n;
 #ifdef OCT_DIAG
         ++od_pass;
 #endif
+        const bool tpass = tabled && !careful && depth_done < FD;   // a full pass served from the table
+        if (tabled && !tpass) { label_keys(); tabled = false; }
+        if (tpass) {
+            for (int e = tid; e < 4 * n; e += NT) {
+                const int i = e >> 2, c = ncode0[cur * cap + i], r = c >> 16, d = (c >> 12) & 15, pth = c & 4095;
+                childcnt[e] = cnt0[cur * cap + i] > 1 ? hist[r * HS + ((4 << (2 * (d + 1))) - 4) / 3 - (1 << (2 * (d + 1))) + 4 * pth + (e & 3)] : 0;
+            }
+        } else {
         // children populations of every expandable node
         for (int i = tid; i < 4 * n; i += NT) childcnt[i] = 0;
         __syncthreads();
@@ -1011,6 +1106,7 @@ __device__ __forceinline__ void octree_body(
                 atomicAdd(&childcnt[nd * 4 + q], 1);
                 ND[k] = (uint16_t)(nd | ((q + 1) << 12));   // the quadrant rides in the label's top bits until the re-label sweep
             }
+        }
         }
         __syncthreads();
         OD_STAMP(1);
@@ -1104,6 +1200,7 @@ __device__ __forceinline__ void octree_body(
                 if (pos < cap) {
                     box0[nxt * cap + pos] = child_box(box0[cur * cap + i], q);
                     cnt0[nxt * cap + pos] = cc;
+                    if (tpass) { const int c = ncode0[cur * cap + i]; ncode0[nxt * cap + pos] = (c & ~0xFFFF) | ((((c >> 12) & 15) + 1) << 12) | (4 * (c & 4095) + q); }
                 }
                 local_expand += cc > 1;
             }
@@ -1112,12 +1209,16 @@ __device__ __forceinline__ void octree_body(
             bool stays = !careful ? (cnt0[cur * cap + i] <= 1) : !(rankv[i] >= 0 && rankv[i] < kproc);
             if (stays) {
                 int pos = scanbuf[nchildslots + i];
-                if (pos < cap) { box0[nxt * cap + pos] = box0[cur * cap + i]; cnt0[nxt * cap + pos] = cnt0[cur * cap + i]; }
+                if (pos < cap) {
+                    box0[nxt * cap + pos] = box0[cur * cap + i]; cnt0[nxt * cap + pos] = cnt0[cur * cap + i];
+                    if (tpass) ncode0[nxt * cap + pos] = ncode0[cur * cap + i];
+                }
             }
         }
         if (local_expand) atomicAdd(&s_expand, local_expand);
         OD_STAMP(3);
-        // re-label the keys
+        // re-label the keys (not while the table serves the passes: the keys keep root | path)
+        if (!tpass)
         for (int k = tid; k < n_keys; k += NT) {
             const int lab = ND[k];
             const int nd = lab & 4095, q = (lab >> 12) - 1;   // q >= 0 exactly for keys of expandable nodes (cnt > 1)
@@ -1138,8 +1239,10 @@ __device__ __forceinline__ void octree_body(
         __syncthreads();
         if (n >= N || n == prevSize) finish = true;            // ORBextractor.cc:682, 747
         else if (!careful && n + nToExpand * 3 > N) careful = true;  // :686
+        ++depth_done;
         OD_STAMP(4);
     }
+    if (tabled) label_keys();
 
     // ---- best key per node (ORBextractor.cc:755-773): max response, first in input order ----
     for (int i = tid; i < n; i += NT) best[i] = 0ull;
@@ -1237,6 +1340,9 @@ static DiscTable make_disc() {
 }
 
 #define IC_KP_PER_WAVE 8
+#define IC_R 15                   // HALF_PATCH_SIZE
+#define IC_ROWS (2 * IC_R + 1)
+#define IC_PITCH 32               // 31 columns in two 16-byte chunks
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
@@ -1263,7 +1369,31 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
     int stride;
     if (level == 0) { src = img0 + (size_t)frame * img0_frame; stride = (int)img0_stride; }
     else { src = pyr + L.plane_off + (size_t)frame * L.plane_bytes; stride = L.stride; }
-    // this lane's 12 disc pixels (749 = 11 * 64 + 45): offsets and weights live in registers
+    // The wave's keypoints at once.  A keypoint's 31 x 31 window is STAGED in LDS with one 16-byte load per lane (31 rows x two
+    // chunks = 62 lanes; the loads start at the window's own first column, whatever its alignment), then the lane's 12 disc pixels
+    // are LDS byte reads at constant offsets.  Fetching the 749 disc bytes straight from the plane took 12 byte-gather
+    // instructions per keypoint, each a 64-address trip through the texture addresser: that unit, not memory, bound the pass
+    // (3.07 M gathers per 256 frames x 16 cycles over 256 CUs = 80 of its 90 us).  The atan2 / sincos tail (~150 instructions)
+    // runs ONCE with keypoint k on lane k instead of once per keypoint on lane 0.
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][IC_KP_PER_WAVE][IC_ROWS * IC_PITCH];
+    const int wvi = threadIdx.x >> 6;
+    OrbLevelKp* kp0 = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
+    typedef unsigned ic_u4 __attribute__((ext_vector_type(4), aligned(1)));
+    {
+        const int lr = min(lane >> 1, IC_ROWS - 1), lc = lane & 1;
+        const unsigned loff = __umul24((unsigned)lr, (unsigned)stride) + 16u * (unsigned)lc;
+        ic_u4 ld[IC_KP_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
+            const int i = min(i0 + k, count - 1);
+            const uint8_t* corner = src + (__umul24((unsigned)(kp0[i].y - IC_R), (unsigned)stride) + (unsigned)(kp0[i].x - IC_R));
+            ld[k] = *reinterpret_cast<const ic_u4*>(corner + loff);
+        }
+#pragma unroll
+        for (int k = 0; k < IC_KP_PER_WAVE; ++k)
+            if (lane < 2 * IC_ROWS) *reinterpret_cast<uint4*>(&s_win[wvi][k][lr * IC_PITCH + 16 * lc]) = make_uint4(ld[k].x, ld[k].y, ld[k].z, ld[k].w);
+    }
+    // this lane's 12 disc pixels (749 = 11 * 64 + 45): window offsets and weights live in registers
     int off[12], wu[12], wv[12];
     {
         const uint4 t0 = *reinterpret_cast<const uint4*>(&c_disc.uv[lane][0]);
@@ -1273,21 +1403,16 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
         for (int j = 0; j < 12; ++j) {
             const uint32_t pr = tw[j >> 1] >> (16 * (j & 1));
             const int u = (int)(signed char)(pr & 0xFFu), v = (int)(signed char)((pr >> 8) & 0xFFu);
-            off[j] = __mul24(v, stride) + u; wu[j] = u; wv[j] = v;   // |v| <= 15, pitch < 2^23: full-rate 24-bit multiply
+            off[j] = (v + IC_R) * IC_PITCH + (u + IC_R); wu[j] = u; wv[j] = v;
         }
     }
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    // all the wave's keypoints at once: their 12 x IC_KP_PER_WAVE byte loads are in flight together, and the
-    // atan2 / sincos tail (~150 instructions) runs ONCE with keypoint k on lane k instead of once per keypoint on lane 0
-    OrbLevelKp* kp0 = lkp + L.kp_off + (size_t)frame * kp_frame_stride;
+    wave_sync_lds();
     int val[IC_KP_PER_WAVE][12];
 #pragma unroll
-    for (int k = 0; k < IC_KP_PER_WAVE; ++k) {
-        const int i = min(i0 + k, count - 1);
-        const uint8_t* center = src + (__umul24((unsigned)kp0[i].y, (unsigned)stride) + (unsigned)kp0[i].x);
+    for (int k = 0; k < IC_KP_PER_WAVE; ++k)
 #pragma unroll
-        for (int j = 0; j < 12; ++j) val[k][j] = center[off[j]];
-    }
+        for (int j = 0; j < 12; ++j) val[k][j] = s_win[wvi][k][off[j]];
     // The 2 x IC_KP_PER_WAVE = 16 moments are summed over the wave TOGETHER (integers: any order is exact): a butterfly over lane
     // bits 0 .. 3 that halves the number of values at every stage (a lane keeps the value its bit selects and takes the
     // partner lane's partial of it), so a lane ends with the 16-lane-row partial of moment number lane & 15; the four rows meet
@@ -1868,6 +1993,7 @@ int orbk_octree_key_cap(int node_cap, int width, int height) {
     long budget = (long)width * height <= 640L * 480L * 3 / 2 ? 48L * 1024 : (long)OCT_LDS_BUDGET;
     if (getenv("SLAMIT_OCT_LDS_KB")) budget = 1024L * atol(getenv("SLAMIT_OCT_LDS_KB"));
     const long room = budget - (long)orbk_octree_node_bytes(node_cap);
+    if (getenv("SLAMIT_OCT_KEYS")) return atoi(getenv("SLAMIT_OCT_KEYS")) & ~7;
     return (int)std::min<long>(OCT_LDS_KEYS_MAX, std::max<long>(OCT_LDS_KEYS_MIN, room / 6)) & ~7;
 }
 size_t orbk_octree_smem(int node_cap, int key_cap) { return orbk_octree_node_bytes(node_cap) + (size_t)key_cap * 6; }
@@ -1892,6 +2018,12 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
     // (0.551 vs 0.562 ms); at 64 frames they cost 5 %.
     static const int nt_env = getenv("SLAMIT_OCT_THREADS") ? atoi(getenv("SLAMIT_OCT_THREADS")) : 0;
     const int nt = nt_env == 256 || nt_env == 512 ? nt_env : (nframes >= 96 ? 256 : OCT_THREADS);
+    // A big batch is bound by how many of its (frame, level) workgroups a CU holds at once, and that by their LDS: with the
+    // handle's full key arrays (48 KB) three fit, with room for 2,048 keys five do, and the lists above that go through the HBM
+    // workspace (L2 resident) at little cost: 0.116 -> 0.092 ms per 256 VGA frames.  (1,536 keys = six per CU: the pass alone
+    // 0.088 ms, but the step 2 % LONGER -- the side stream's blur finds less of the chip.)  A few frames keep the big arrays.
+    static const bool keys_env = getenv("SLAMIT_OCT_KEYS") || getenv("SLAMIT_OCT_LDS_KB");
+    if (nframes >= 96 && !keys_env) key_cap = std::min(key_cap, 2048);
     if (nt == 256)
         hipLaunchKernelGGL(octree_kernel<256>, grid, dim3(256), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
                            cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
