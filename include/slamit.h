@@ -338,6 +338,12 @@ typedef struct slamit_ba_problem {
     const int32_t* edge_pt; /* n_edge */
     const double* edge_uv;  /* n_edge x 2 */
     const double* edge_inv_sigma2; /* n_edge */
+    /* Stereo observations (EdgeStereoSE3ProjectXYZ, Thirdparty/g2o/g2o/types/types_six_dof_expmap.h:112-141; built by
+       src/Optimizer.cc:621-650).  Both NULL: every edge is monocular.  Otherwise edge_ur[e] is the keypoint's column in
+       the right image (KeyFrame::mvuRight), negative for a monocular edge (the test at src/Optimizer.cc:596), and
+       kf_bf[k] is keyframe k's baseline x fx (KeyFrame::mbf). */
+    const double* edge_ur;  /* n_edge, nullable */
+    const double* kf_bf;    /* n_kf, nullable (required when edge_ur is given) */
 } slamit_ba_problem;
 
 typedef struct slamit_ba_opts {
@@ -346,6 +352,8 @@ typedef struct slamit_ba_opts {
     double huber_delta;     /* (double)(float)sqrt(5.991)  src/Optimizer.cc:569 */
     double chi2_gate;       /* 5.991 src/Optimizer.cc:680,723 */
     const volatile uint8_t* stop; /* nullable; polled like SparseOptimizer::terminate() */
+    double huber_delta_stereo; /* (double)(float)sqrt(7.815)  src/Optimizer.cc:570; <= 0: that default */
+    double chi2_gate_stereo;   /* 7.815 src/Optimizer.cc:696,740; <= 0: that default */
 } slamit_ba_opts;
 
 #define SLAMIT_BA_MAX_ITS 32

@@ -129,8 +129,10 @@ void pose_oplus(Pose& T, const double* u) {
 struct Edge {
     int kf, pt;
     double u, v, w;
+    double ur;       // right-image column of a stereo observation (EdgeStereoSE3ProjectXYZ); unused for a monocular edge
+    bool stereo;
     bool active, robust;
-    double err[2];
+    double err[3];   // err[2] = 0 for a monocular edge
     double chi2;
 };
 
@@ -141,6 +143,8 @@ struct Problem {
     std::vector<double> intr, pts;
     std::vector<Edge> edges;
     double delta, gate;
+    double delta_s, gate_s;        // stereo edges: S/Optimizer.cc:570 (thHuberStereo), :696 / :740 (7.815)
+    std::vector<double> bf;        // per keyframe: KeyFrame::mbf (S/Optimizer.cc:641)
     const volatile uint8_t* stop;
     // index mapping of the current stage
     std::vector<int> pose_col;  // -1 = fixed, else block index among free poses
@@ -152,7 +156,8 @@ inline bool stopped(const Problem& pb) { return pb.stop && *pb.stop; }
 // computeActiveErrors + activeRobustChi2
 double compute_errors(Problem& pb) {
     double total = 0;
-    const double dsqr = pb.delta * pb.delta;
+    // RobustKernelHuber keeps delta^2 in a FLOAT member (G/core/robust_kernel_impl.h:84, set by setDelta :64-68)
+    const double dsqr = (double)(float)(pb.delta * pb.delta);
     for (int e = 0; e < pb.E; ++e) {
         Edge& ed = pb.edges[e];
         if (!ed.active) continue;
@@ -161,12 +166,27 @@ double compute_errors(Problem& pb) {
         quat_rot(T.q, &pb.pts[3 * ed.pt], Xc);
         for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
         const double* in = &pb.intr[4 * ed.kf];
-        ed.err[0] = ed.u - (Xc[0] / Xc[2] * in[0] + in[2]);  // project2d then *fx + cx
-        ed.err[1] = ed.v - (Xc[1] / Xc[2] * in[1] + in[3]);
-        ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1];
+        double delta = pb.delta, dq = dsqr;
+        if (!ed.stereo) {
+            ed.err[0] = ed.u - (Xc[0] / Xc[2] * in[0] + in[2]);  // project2d then *fx + cx
+            ed.err[1] = ed.v - (Xc[1] / Xc[2] * in[1] + in[3]);
+            ed.err[2] = 0.0;
+            ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1];
+        } else {
+            // EdgeStereoSE3ProjectXYZ::cam_project (G/types/types_six_dof_expmap.cpp:150-157): the inverse depth is a FLOAT
+            // (1.0f / z rounded to float), bf arrives through a `const float&`, and bf * invz is a float product
+            const float invz = (float)(1.0 / Xc[2]);
+            const double r0 = Xc[0] * (double)invz * in[0] + in[2];
+            const double r1 = Xc[1] * (double)invz * in[1] + in[3];
+            const float bfz = (float)pb.bf[ed.kf] * invz;
+            const double r2 = r0 - (double)bfz;
+            ed.err[0] = ed.u - r0; ed.err[1] = ed.v - r1; ed.err[2] = ed.ur - r2;
+            ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1] + ed.err[2] * ed.w * ed.err[2];
+            delta = pb.delta_s; dq = (double)(float)(delta * delta);
+        }
         if (ed.robust) {
-            if (ed.chi2 <= dsqr) total += ed.chi2;
-            else total += 2 * sqrt(ed.chi2) * pb.delta - dsqr;
+            if (ed.chi2 <= dq) total += ed.chi2;
+            else total += 2 * sqrt(ed.chi2) * delta - dq;
         } else total += ed.chi2;
     }
     return total;
@@ -181,7 +201,7 @@ void build_system(Problem& pb, System& S) {
     S.np = pb.nfree; S.nl = pb.P;
     S.Hpp.assign((size_t)S.np * 36, 0.0); S.Hll.assign((size_t)pb.P * 9, 0.0); S.Hpl.assign((size_t)pb.E * 18, 0.0);
     S.bp.assign((size_t)S.np * 6, 0.0); S.bl.assign((size_t)pb.P * 3, 0.0);
-    const double dsqr = pb.delta * pb.delta;
+    const double dsqr = (double)(float)(pb.delta * pb.delta);   // (a float in the reference, see compute_errors)
     for (int e = 0; e < pb.E; ++e) {
         const Edge& ed = pb.edges[e];
         if (!ed.active) continue;
@@ -193,26 +213,45 @@ void build_system(Problem& pb, System& S) {
         for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
         quat_to_R(T.q, R);
         const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
-        // _jacobianOplusXi = -1/z * tmp * R
-        double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
-        double A[6];
-        for (int r = 0; r < 2; ++r)
-            for (int c = 0; c < 3; ++c)
-                A[3 * r + c] = -1. / z * (tmp[3 * r] * R[c] + tmp[3 * r + 1] * R[3 + c] + tmp[3 * r + 2] * R[6 + c]);
-        double B[12];
-        B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx;
-        B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
-        B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy;
-        B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+        double A[9], B[18];   // rows 0, 1 (and 2 for a stereo edge; zero otherwise)
+        for (int i = 6; i < 9; ++i) A[i] = 0.0;
+        for (int i = 12; i < 18; ++i) B[i] = 0.0;
+        double delta = pb.delta, dq = dsqr;
+        if (!ed.stereo) {
+            // _jacobianOplusXi = -1/z * tmp * R
+            double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+            for (int r = 0; r < 2; ++r)
+                for (int c = 0; c < 3; ++c)
+                    A[3 * r + c] = -1. / z * (tmp[3 * r] * R[c] + tmp[3 * r + 1] * R[3 + c] + tmp[3 * r + 2] * R[6 + c]);
+            B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx;
+            B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+            B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy;
+            B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+        } else {
+            // EdgeStereoSE3ProjectXYZ::linearizeOplus (G/types/types_six_dof_expmap.cpp:188-234), its expressions as written
+            const double bf = pb.bf[ed.kf];
+            for (int c = 0; c < 3; ++c) {
+                A[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+                A[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+                A[6 + c] = A[c] - bf * R[6 + c] / z_2;
+            }
+            B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx;
+            B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+            B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy;
+            B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+            B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2];
+            B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2;
+            delta = pb.delta_s; dq = (double)(float)(delta * delta);
+        }
         double rho1 = 1.0;
-        if (ed.robust && ed.chi2 > dsqr) rho1 = pb.delta / sqrt(ed.chi2);
+        if (ed.robust && ed.chi2 > dq) rho1 = delta / sqrt(ed.chi2);
         const double wO = rho1 * ed.w;                       // weightedOmega = rho[1] * information
-        const double r0 = -ed.w * ed.err[0] * rho1, r1 = -ed.w * ed.err[1] * rho1;  // omega_r
+        const double r0 = -ed.w * ed.err[0] * rho1, r1 = -ed.w * ed.err[1] * rho1, r2 = -ed.w * ed.err[2] * rho1;  // omega_r
         double* bl = &S.bl[3 * ed.pt];
         double* Hl = &S.Hll[9 * ed.pt];
         for (int i = 0; i < 3; ++i) {
-            bl[i] += A[i] * r0 + A[3 + i] * r1;
-            for (int j = 0; j < 3; ++j) Hl[3 * i + j] += (A[i] * A[j] + A[3 + i] * A[3 + j]) * wO;
+            bl[i] += A[i] * r0 + A[3 + i] * r1 + A[6 + i] * r2;
+            for (int j = 0; j < 3; ++j) Hl[3 * i + j] += (A[i] * A[j] + A[3 + i] * A[3 + j] + A[6 + i] * A[6 + j]) * wO;
         }
         const int col = pb.pose_col[ed.kf];
         if (col >= 0) {
@@ -220,9 +259,9 @@ void build_system(Problem& pb, System& S) {
             double* Hp = &S.Hpp[36 * col];
             double* Hx = &S.Hpl[18 * (size_t)e];
             for (int i = 0; i < 6; ++i) {
-                bq[i] += B[i] * r0 + B[6 + i] * r1;
-                for (int j = 0; j < 6; ++j) Hp[6 * i + j] += (B[i] * B[j] + B[6 + i] * B[6 + j]) * wO;
-                for (int j = 0; j < 3; ++j) Hx[3 * i + j] += (B[i] * A[j] + B[6 + i] * A[3 + j]) * wO;
+                bq[i] += B[i] * r0 + B[6 + i] * r1 + B[12 + i] * r2;
+                for (int j = 0; j < 6; ++j) Hp[6 * i + j] += (B[i] * B[j] + B[6 + i] * B[6 + j] + B[12 + i] * B[12 + j]) * wO;
+                for (int j = 0; j < 3; ++j) Hx[3 * i + j] += (B[i] * A[j] + B[6 + i] * A[3 + j] + B[12 + i] * A[6 + j]) * wO;
             }
         }
     }
@@ -401,6 +440,10 @@ extern "C" int ba_oracle_solve(const slamit_ba_problem* in, const slamit_ba_opts
     Problem pb;
     pb.K = in->n_kf; pb.P = in->n_pt; pb.E = in->n_edge;
     pb.delta = op->huber_delta; pb.gate = op->chi2_gate; pb.stop = op->stop;
+    pb.delta_s = op->huber_delta_stereo > 0 ? op->huber_delta_stereo : (double)(float)sqrt(7.815);
+    pb.gate_s = op->chi2_gate_stereo > 0 ? op->chi2_gate_stereo : 7.815;
+    if (in->edge_ur && !in->kf_bf) return -1;
+    if (in->kf_bf) pb.bf.assign(in->kf_bf, in->kf_bf + pb.K);
     pb.poses.resize(pb.K);
     pb.fixed.assign(in->kf_fixed, in->kf_fixed + pb.K);
     pb.intr.assign(in->kf_intr, in->kf_intr + 4 * (size_t)pb.K);
@@ -417,8 +460,10 @@ extern "C" int ba_oracle_solve(const slamit_ba_problem* in, const slamit_ba_opts
         if (ed.kf < 0 || ed.kf >= pb.K || ed.pt < 0 || ed.pt >= pb.P) return -1;
         ed.u = in->edge_uv[2 * (size_t)e]; ed.v = in->edge_uv[2 * (size_t)e + 1];
         ed.w = in->edge_inv_sigma2[e];
+        ed.stereo = in->edge_ur && !(in->edge_ur[e] < 0);   // S/Optimizer.cc:596: mvuRight < 0 is a monocular observation
+        ed.ur = ed.stereo ? in->edge_ur[e] : -1.0;
         ed.active = true; ed.robust = true;
-        ed.err[0] = ed.err[1] = 0; ed.chi2 = 0;
+        ed.err[0] = ed.err[1] = ed.err[2] = 0; ed.chi2 = 0;
     }
     slamit_ba_stats* st = res->stats;
     if (st) memset(st, 0, sizeof(*st));
@@ -430,7 +475,7 @@ extern "C" int ba_oracle_solve(const slamit_ba_problem* in, const slamit_ba_opts
                 const Pose& T = pb.poses[ed.kf];
                 double Xc[3];
                 quat_rot(T.q, &pb.pts[3 * ed.pt], Xc);
-                bool out = ed.chi2 > pb.gate || !(Xc[2] + T.t[2] > 0.0);
+                bool out = ed.chi2 > (ed.stereo ? pb.gate_s : pb.gate) || !(Xc[2] + T.t[2] > 0.0);
                 if (out) ed.active = false;   // setLevel(1)
                 ed.robust = false;            // setRobustKernel(0)
                 if (res->edge_stage1_outlier) res->edge_stage1_outlier[e] = out;
@@ -452,7 +497,7 @@ extern "C" int ba_oracle_solve(const slamit_ba_problem* in, const slamit_ba_opts
         double Xc[3];
         quat_rot(T.q, &pb.pts[3 * ed.pt], Xc);
         if (res->edge_chi2) res->edge_chi2[e] = ed.chi2;
-        if (res->edge_outlier) res->edge_outlier[e] = ed.chi2 > pb.gate || !(Xc[2] + T.t[2] > 0.0);
+        if (res->edge_outlier) res->edge_outlier[e] = ed.chi2 > (ed.stereo ? pb.gate_s : pb.gate) || !(Xc[2] + T.t[2] > 0.0);
     }
     for (int k = 0; k < pb.K; ++k) {
         double R[9];
@@ -478,7 +523,7 @@ struct PEdge { double X[3], u, v, w; bool active, robust; double err[2], chi2; }
 
 double pose_errors(const Pose& T, const double* in, std::vector<PEdge>& E, double delta) {
     double total = 0;
-    const double dsqr = delta * delta;
+    const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float (G/core/robust_kernel_impl.h:84)
     for (size_t e = 0; e < E.size(); ++e) {
         PEdge& ed = E[e];
         if (!ed.active) continue;
@@ -498,7 +543,7 @@ int pose_optimize_round(Pose& T, const double* in, std::vector<PEdge>& E, double
     bool any = false;
     for (size_t e = 0; e < E.size(); ++e) any |= E[e].active;
     if (!any) return 0;
-    const double dsqr = delta * delta;
+    const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float (G/core/robust_kernel_impl.h:84)
     double lambda = -1, ni = 2;
     int nBad = 0, done = 0;
     bool ok = true;
@@ -717,7 +762,7 @@ inline double huber_rho(double chi2, double delta, double dsqr) { return chi2 > 
 
 double sim3_errors(const Sim3& S, const double* in1, const double* in2, std::vector<SPair>& E, double delta) {
     const Sim3 Sinv = sim3_inverse(S);
-    const double dsqr = delta * delta;
+    const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float (G/core/robust_kernel_impl.h:84)
     double total = 0;
     for (size_t k = 0; k < E.size(); ++k) {
         SPair& P = E[k];
@@ -742,7 +787,7 @@ int sim3_optimize_stage(Sim3& S, const double* in1, const double* in2, std::vect
     bool any = false;
     for (size_t k = 0; k < E.size(); ++k) any |= E[k].active;
     if (!any) return 0;
-    const double dsqr = delta * delta;
+    const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float (G/core/robust_kernel_impl.h:84)
     double lambda = -1, ni = 2;
     int nBad = 0, done = 0;
     bool ok = true;

@@ -70,6 +70,9 @@ extern "C" int ba_ref_solve(const slamit_ba_problem* pb, const slamit_ba_opts* o
     }
     const int maxKFid = K - 1;
     std::vector<g2o::EdgeSE3ProjectXYZ*> edges(E, (g2o::EdgeSE3ProjectXYZ*)0);
+    std::vector<g2o::EdgeStereoSE3ProjectXYZ*> sedges(E, (g2o::EdgeStereoSE3ProjectXYZ*)0);   // stereo observations (S/Optimizer.cc:621-650)
+    const double delta_s = op->huber_delta_stereo > 0 ? op->huber_delta_stereo : (double)(float)sqrt(7.815);
+    const double gate_s = op->chi2_gate_stereo > 0 ? op->chi2_gate_stereo : 7.815;
     for (int p = 0; p < P; ++p) {
         g2o::VertexSBAPointXYZ* v = new g2o::VertexSBAPointXYZ();
         v->setEstimate(Eigen::Vector3d(pb->pt_xyz[3 * p], pb->pt_xyz[3 * p + 1], pb->pt_xyz[3 * p + 2]));
@@ -79,6 +82,25 @@ extern "C" int ba_ref_solve(const slamit_ba_problem* pb, const slamit_ba_opts* o
     }
     for (int e = 0; e < E; ++e) {
         const int id = pb->edge_pt[e] + maxKFid + 1, kf = pb->edge_kf[e];
+        if (pb->edge_ur && !(pb->edge_ur[e] < 0)) {
+            Eigen::Matrix<double, 3, 1> obs;
+            obs << pb->edge_uv[2 * e], pb->edge_uv[2 * e + 1], pb->edge_ur[e];
+            g2o::EdgeStereoSE3ProjectXYZ* ed = new g2o::EdgeStereoSE3ProjectXYZ();
+            ed->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(id)));
+            ed->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(kf)));
+            ed->setMeasurement(obs);
+            Eigen::Matrix3d Info = Eigen::Matrix3d::Identity() * pb->edge_inv_sigma2[e];
+            ed->setInformation(Info);
+            g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber;
+            ed->setRobustKernel(rk);
+            rk->setDelta(delta_s);
+            ed->fx = pb->kf_intr[4 * kf]; ed->fy = pb->kf_intr[4 * kf + 1];
+            ed->cx = pb->kf_intr[4 * kf + 2]; ed->cy = pb->kf_intr[4 * kf + 3];
+            ed->bf = pb->kf_bf[kf];
+            optimizer.addEdge(ed);
+            sedges[e] = ed;
+            continue;
+        }
         Eigen::Matrix<double, 2, 1> obs;
         obs << pb->edge_uv[2 * e], pb->edge_uv[2 * e + 1];
         g2o::EdgeSE3ProjectXYZ* ed = new g2o::EdgeSE3ProjectXYZ();
@@ -107,6 +129,14 @@ extern "C" int ba_ref_solve(const slamit_ba_problem* pb, const slamit_ba_opts* o
         if (op->stop && *op->stop) break;  // S/Optimizer.cc:655-657, 664-666
         if (stage == 1) {
             for (int e = 0; e < E; ++e) {
+                if (sedges[e]) {   // S/Optimizer.cc:689-703
+                    g2o::EdgeStereoSE3ProjectXYZ* ed = sedges[e];
+                    bool out = ed->chi2() > gate_s || !ed->isDepthPositive();
+                    if (out) ed->setLevel(1);
+                    if (res->edge_stage1_outlier) res->edge_stage1_outlier[e] = out;
+                    ed->setRobustKernel(0);
+                    continue;
+                }
                 g2o::EdgeSE3ProjectXYZ* ed = edges[e];
                 bool out = ed->chi2() > op->chi2_gate || !ed->isDepthPositive();
                 if (out) ed->setLevel(1);
@@ -135,6 +165,12 @@ extern "C" int ba_ref_solve(const slamit_ba_problem* pb, const slamit_ba_opts* o
     }
 
     for (int e = 0; e < E; ++e) {
+        if (sedges[e]) {   // S/Optimizer.cc:731-745
+            g2o::EdgeStereoSE3ProjectXYZ* ed = sedges[e];
+            if (res->edge_chi2) res->edge_chi2[e] = ed->chi2();
+            if (res->edge_outlier) res->edge_outlier[e] = ed->chi2() > gate_s || !ed->isDepthPositive();
+            continue;
+        }
         g2o::EdgeSE3ProjectXYZ* ed = edges[e];
         if (res->edge_chi2) res->edge_chi2[e] = ed->chi2();
         if (res->edge_outlier) res->edge_outlier[e] = ed->chi2() > op->chi2_gate || !ed->isDepthPositive();

@@ -377,12 +377,12 @@ class _BaProblem(C.Structure):
     _fields_ = [("n_kf", C.c_int32), ("n_pt", C.c_int32), ("n_edge", C.c_int32),
                 ("kf_pose", C.c_void_p), ("kf_fixed", C.c_void_p), ("kf_intr", C.c_void_p),
                 ("pt_xyz", C.c_void_p), ("edge_kf", C.c_void_p), ("edge_pt", C.c_void_p),
-                ("edge_uv", C.c_void_p), ("edge_inv_sigma2", C.c_void_p)]
+                ("edge_uv", C.c_void_p), ("edge_inv_sigma2", C.c_void_p), ("edge_ur", C.c_void_p), ("kf_bf", C.c_void_p)]
 
 
 class _BaOpts(C.Structure):
     _fields_ = [("its_robust", C.c_int32), ("its_final", C.c_int32), ("huber_delta", C.c_double),
-                ("chi2_gate", C.c_double), ("stop", C.c_void_p)]
+                ("chi2_gate", C.c_double), ("stop", C.c_void_p), ("huber_delta_stereo", C.c_double), ("chi2_gate_stereo", C.c_double)]
 
 
 class _BaStats(C.Structure):
@@ -425,9 +425,14 @@ def _ba_call(which, prob, its_robust, its_final, huber_delta, chi2_gate, stop):
                   ("edge_kf", np.int32), ("edge_pt", np.int32), ("edge_uv", np.float64), ("edge_inv_sigma2", np.float64)):
         keep[k] = np.ascontiguousarray(prob[k], dtype=dt)
     nk, npt, ne = len(keep["kf_fixed"]), len(keep["pt_xyz"]), len(keep["edge_kf"])
+    stereo = prob.get("edge_ur") is not None
+    if stereo:
+        keep["edge_ur"] = np.ascontiguousarray(prob["edge_ur"], dtype=np.float64)
+        keep["kf_bf"] = np.ascontiguousarray(prob["kf_bf"], dtype=np.float64)
     p = _BaProblem(nk, npt, ne, *[keep[k].ctypes.data for k in (
-        "kf_pose", "kf_fixed", "kf_intr", "pt_xyz", "edge_kf", "edge_pt", "edge_uv", "edge_inv_sigma2")])
-    o = _BaOpts(its_robust, its_final, huber_delta, chi2_gate, stop.ctypes.data if stop is not None else None)
+        "kf_pose", "kf_fixed", "kf_intr", "pt_xyz", "edge_kf", "edge_pt", "edge_uv", "edge_inv_sigma2")],
+        keep["edge_ur"].ctypes.data if stereo else None, keep["kf_bf"].ctypes.data if stereo else None)
+    o = _BaOpts(its_robust, its_final, huber_delta, chi2_gate, stop.ctypes.data if stop is not None else None, 0.0, 0.0)
     out = {"kf_pose": np.zeros((nk, 12)), "pt_xyz": np.zeros((npt, 3)), "edge_chi2": np.zeros(ne),
            "edge_outlier": np.zeros(ne, np.uint8), "edge_stage1_outlier": np.zeros(ne, np.uint8)}
     st = _BaStats()

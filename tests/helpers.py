@@ -23,6 +23,9 @@ def load_ba_golden(path):
     prob["kf_fixed"] = z["kf_fixed"].astype(np.uint8)
     prob["edge_kf"] = z["edge_kf"].astype(np.int32)
     prob["edge_pt"] = z["edge_pt"].astype(np.int32)
+    if "edge_ur" in z.files:   # a window with stereo observations
+        prob["edge_ur"] = z["edge_ur"].astype(np.float64)
+        prob["kf_bf"] = z["kf_bf"].astype(np.float64)
     n = [int(v) for v in z["ref_n_its"]]
     ref = {"kf_pose": z["ref_kf_pose"], "pt_xyz": z["ref_pt_xyz"], "edge_chi2": z["ref_edge_chi2"],
            "edge_outlier": z["ref_edge_outlier"], "edge_stage1_outlier": z["ref_edge_stage1_outlier"],

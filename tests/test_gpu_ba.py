@@ -21,26 +21,38 @@ POSE_RTOL = 1e-5
 GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ba_*.npz")))
 
 
-def _close(res, ref, tag, counts=True):
+def _close(res, ref, tag, counts=True, prob=None):
+    # Stereo edges project with a FLOAT inverse depth (cam_project, types_six_dof_expmap.cpp:150-157): a last-bit difference in a
+    # point's depth can move that float by one ulp and the residual by ~2e-5 px, so the error function itself is not continuous at
+    # the 1e-13 level the two implementations agree to; a window that MIXES monocular and stereo observations then amplifies such
+    # noise by ~5x per LM iteration (the reference's g2o against the CPU restatement does the same, tests/test_oracle_ba.py).
+    # Bounds: states to POSE_RTOL (3 x POSE_RTOL on mixed windows), per-edge chi2 to what those allow; LM path and flags exact.
+    stereo = prob is not None and prob.get("edge_ur") is not None
+    mixed = stereo and (prob["edge_ur"] < 0).any()
+    state_tol = 3 * POSE_RTOL if mixed else POSE_RTOL
     scale = max(np.abs(ref["kf_pose"]).max(), 1.0)
     err = np.abs(res["kf_pose"] - ref["kf_pose"]).max() / scale
-    assert err <= POSE_RTOL, "%s pose rel err %g" % (tag, err)
+    assert err <= state_tol, "%s pose rel err %g" % (tag, err)
     perr = np.abs(res["pt_xyz"] - ref["pt_xyz"]).max() / max(np.abs(ref["pt_xyz"]).max(), 1.0)
-    assert perr <= POSE_RTOL, "%s point rel err %g" % (tag, perr)
+    assert perr <= state_tol, "%s point rel err %g" % (tag, perr)
     for key in ("edge_stage1_outlier", "edge_outlier"):
         diff = res[key] != ref[key]
-        near = np.abs(ref["edge_chi2"] - 5.991) <= 1e-6 * 5.991
+        gate = np.where(prob["edge_ur"] >= 0, 7.815, 5.991) if prob is not None and prob.get("edge_ur") is not None else 5.991   # Optimizer.cc:680, :696
+        near = np.abs(ref["edge_chi2"] - gate) <= 1e-6 * gate
         assert not (diff & ~near).any(), "%s %s differs on %d edges away from the gate" % (tag, key, int((diff & ~near).sum()))
-    assert np.allclose(res["edge_chi2"], ref["edge_chi2"], rtol=1e-5, atol=1e-7), tag
+    chi_tol = 3e-3 if mixed else 1e-4 if stereo else None
+    assert np.allclose(res["edge_chi2"], ref["edge_chi2"], rtol=chi_tol or 1e-5, atol=chi_tol or 1e-7), tag
     if counts:
         s, r = res["stats"], ref["stats"]
         assert s["n_its"] == r["n_its"], "%s iterations %s vs %s" % (tag, s["n_its"], r["n_its"])
         assert s["trials"] == r["trials"], tag
         for st in range(2):
-            assert np.allclose(s["chi2"][st], r["chi2"][st], rtol=1e-6, atol=1e-9), tag
+            assert np.allclose(s["chi2"][st], r["chi2"][st], rtol=1e-5 if stereo else 1e-6, atol=1e-9), tag
             # lambda's update factor 1-(2*rho-1)^3 takes rho from a cancelling difference of two
             # large costs, so it amplifies summation-order noise: control state, looser bound
-            assert np.allclose(s["lambda"][st], r["lambda"][st], rtol=1e-3), tag
+            # (with stereo edges the cost near convergence carries the float-projection noise described above, and rho is that noise
+            #  divided by a vanishing predicted decrease: lambda only has to stay within an update factor there)
+            assert np.allclose(s["lambda"][st], r["lambda"][st], rtol=0.7 if stereo else 1e-3), tag
         for st in range(2):  # the start cost is only evaluated for a stage that iterates
             if r["n_its"][st] > 0:
                 assert np.isclose(s["chi2_init"][st], r["chi2_init"][st], rtol=1e-8), tag
@@ -55,13 +67,34 @@ def opt():
 def test_vs_reference_g2o_golden(opt, path):
     prob, ref = load_ba_golden(path)
     sched = ref.get("schedule", (5, 10, api.HUBER_MONO))   # the global-BA fixtures carry (nIterations, 0, sqrt(5.99))
-    _close(opt.LocalBundleAdjustment(prob, *sched), ref, os.path.basename(path))
+    _close(opt.LocalBundleAdjustment(prob, *sched), ref, os.path.basename(path), prob=prob)
 
 
 @pytest.mark.parametrize("k,p,o,seed,nfix", [(6, 80, 3, 31, 1), (20, 400, 6, 32, 2), (33, 700, None, 33, 1)])
 def test_vs_oracle_fresh(opt, k, p, o, seed, nfix):
     prob = synth.synth_ba(k, p, o, seed=seed, n_fixed=nfix)
     _close(opt.LocalBundleAdjustment(prob), ob.ba_solve(prob), "fresh%d" % seed)
+
+
+@pytest.mark.parametrize("k,p,o,seed,nfix,sf", [(9, 150, 4, 61, 1, 1.0), (24, 600, 7, 62, 2, 0.4), (40, 1500, None, 63, 1, 0.7), (50, 2000, 8, 64, 1, 0.9)])
+def test_stereo_windows_vs_oracle_fresh(opt, k, p, o, seed, nfix, sf):
+    """Windows with stereo observations (EdgeStereoSE3ProjectXYZ, Optimizer.cc:621-650; types_six_dof_expmap.cpp:150-157, 188-234):
+    three residual rows, the float inverse depth of cam_project, Huber width sqrt(7.815) and gate 7.815 on the stereo edges, the
+    monocular edges of the same window on theirs; the banded and the blocked reduced solve, and a batch that mixes both kinds of window."""
+    prob = synth.synth_ba(k, p, o, seed=seed, n_fixed=nfix, stereo_frac=sf)
+    assert (prob["edge_ur"] >= 0).any() and ((prob["edge_ur"] < 0).any() or sf == 1.0)
+    _close(opt.LocalBundleAdjustment(prob), ob.ba_solve(prob), "stereo%d" % seed, prob=prob)
+
+
+def test_batch_mixes_monocular_and_stereo_windows(opt):
+    probs = [synth.synth_ba(12, 300, 4, seed=71), synth.synth_ba(12, 300, 4, seed=72, stereo_frac=0.6), synth.synth_ba(20, 500, None, seed=73, stereo_frac=1.0),
+             synth.synth_ba(30, 800, 6, seed=74)]
+    res = opt.LocalBundleAdjustmentBatch(probs)
+    for i, (pr, r) in enumerate(zip(probs, res)):
+        _close(r, ob.ba_solve(pr), "mixbatch%d" % i, prob=pr)
+    with pytest.raises(api.SlamitError):   # stereo observations need the keyframes' bf
+        bad = dict(probs[1]); bad.pop("kf_bf"); bad["kf_bf"] = None
+        api._ba_problem(bad)
 
 
 @pytest.mark.parametrize("k,p,o,seed,nfix", [(50, 2000, 8, 12345, 2), (50, 1200, 3, 41, 1), (50, 1500, 10, 42, 3), (12, 300, 4, 43, 1),

@@ -99,9 +99,12 @@ def test_shim_orbmatcher(tmp_path):
 
 
 @pytest.mark.gpu
-def test_shim_optimizer_local_ba(tmp_path):
+@pytest.mark.parametrize("name", ["fixed3", "stereo_mixed"])
+def test_shim_optimizer_local_ba(tmp_path, name):
+    """LocalMapping.cc:84's call against mock KeyFrame / MapPoint / Map types; "stereo_mixed": keyframes with mvuRight >= 0 on half
+    of their keypoints and an mbf (the EdgeStereoSE3ProjectXYZ edges of Optimizer.cc:621-650), against the reference-g2o golden."""
     _build()
-    prob, ref = load_ba_golden(os.path.join(ROOT, "tests", "golden", "ba_fixed3.npz"))
+    prob, ref = load_ba_golden(os.path.join(ROOT, "tests", "golden", "ba_%s.npz" % name))
     K, P, E = len(prob["kf_fixed"]), len(prob["pt_xyz"]), len(prob["edge_kf"])
     blob = struct.pack("<iii", K, P, E)
     blob += prob["kf_pose"].astype(np.float32).tobytes()
@@ -110,6 +113,8 @@ def test_shim_optimizer_local_ba(tmp_path):
     blob += prob["pt_xyz"].astype(np.float32).tobytes()
     blob += prob["edge_kf"].astype(np.int32).tobytes() + prob["edge_pt"].astype(np.int32).tobytes()
     blob += prob["edge_uv"].astype(np.float32).tobytes() + prob["edge_inv_sigma2"].astype(np.float32).tobytes()
+    if "edge_ur" in prob:
+        blob += prob["kf_bf"][:1].astype(np.float32).tobytes() + prob["edge_ur"].astype(np.float32).tobytes()
     pin, pout = tmp_path / "p.bin", tmp_path / "o.bin"
     open(pin, "wb").write(blob)
     subprocess.check_call([EXE, "ba", str(pin), str(pout)])

@@ -28,14 +28,19 @@ CASES = {
     # sqrt(5.99), keyframe 0 fixed -- the same solve with schedule (nIterations, 0)
     "global_init": (2, 150, None, 21, 1, 1.0),   # Tracking::CreateInitialMapMonocular: 2 keyframes, GlobalBundleAdjustemnt(mpMap, 20)
     "global_map": (14, 500, 5, 22, 1, 4.0),      # a small map, 10 iterations
+    # windows with stereo observations (EdgeStereoSE3ProjectXYZ, Optimizer.cc:621-650): a 7th field = the fraction of stereo edges
+    "stereo_all": (10, 200, 4, 51, 1, 1.0, 1.0),        # every observation stereo (an RGB-D session)
+    "stereo_mixed": (20, 600, 6, 52, 2, 1.0, 0.5),      # half of the observations without a right-image match
+    "stereo_rough": (8, 150, 4, 56, 1, 80.0, 0.6),      # very large initial error: a rejected LM trial, most edges gated out
+    "stereo_window8": (50, 2000, 8, 54, 1, 1.0, 0.8),   # BASELINE config 4 geometry with 80 % stereo observations
 }
 # name -> (its_robust, its_final, huber_delta); everything else uses the local-BA schedule of Optimizer.cc:507-743
 SCHEDULE = {"global_init": (20, 0, float(np.float32(np.sqrt(5.99)))), "global_map": (10, 0, float(np.float32(np.sqrt(5.99))))}
 
 
 def make(name):
-    k, p, o, seed, nfix, rough = CASES[name]
-    prob = synth.synth_ba(k, p, o, seed=seed, n_fixed=nfix)
+    k, p, o, seed, nfix, rough = CASES[name][:6]
+    prob = synth.synth_ba(k, p, o, seed=seed, n_fixed=nfix, stereo_frac=CASES[name][6] if len(CASES[name]) > 6 else 0.0)
     if rough != 1.0:
         rs = np.random.RandomState(seed + 99)
         prob["pt_xyz"] = (prob["pt_xyz"] + rs.normal(0, 0.02 * rough, prob["pt_xyz"].shape)).astype(np.float32).astype(np.float64)
@@ -52,7 +57,10 @@ def make(name):
 def main():
     assert ob.ba_ref_available(), "build oracle/_ref first: make -C oracle -f Makefile.ref"
     out_dir = os.path.join(ROOT, "tests", "golden")
+    only = sys.argv[1:]   # optional: the case names to (re)generate; default all
     for name in CASES:
+        if only and not any(name.startswith(o) for o in only):
+            continue
         prob = make(name)
         sched = SCHEDULE.get(name)
         ref = ob.ba_ref_solve(prob, *sched) if sched else ob.ba_ref_solve(prob)
@@ -63,6 +71,7 @@ def main():
             kf_pose=prob["kf_pose"].astype(np.float32), kf_fixed=prob["kf_fixed"], kf_intr=prob["kf_intr"].astype(np.float32),
             pt_xyz=prob["pt_xyz"].astype(np.float32), edge_kf=prob["edge_kf"].astype(np.int16), edge_pt=prob["edge_pt"].astype(np.int16),
             edge_uv=prob["edge_uv"].astype(np.float32), edge_inv_sigma2=prob["edge_inv_sigma2"].astype(np.float32),
+            **({"edge_ur": prob["edge_ur"].astype(np.float32), "kf_bf": prob["kf_bf"].astype(np.float32)} if "edge_ur" in prob else {}),
             ref_kf_pose=ref["kf_pose"], ref_pt_xyz=ref["pt_xyz"], ref_edge_chi2=ref["edge_chi2"],
             ref_edge_outlier=ref["edge_outlier"], ref_edge_stage1_outlier=ref["edge_stage1_outlier"],
             ref_n_its=np.array(st["n_its"]), ref_chi2=pad(st["chi2"]), ref_lambda=pad(st["lambda"]),

@@ -36,12 +36,14 @@ class BaProblem(C.Structure):
     _fields_ = [("n_kf", C.c_int32), ("n_pt", C.c_int32), ("n_edge", C.c_int32),
                 ("kf_pose", C.c_void_p), ("kf_fixed", C.c_void_p), ("kf_intr", C.c_void_p),
                 ("pt_xyz", C.c_void_p), ("edge_kf", C.c_void_p), ("edge_pt", C.c_void_p),
-                ("edge_uv", C.c_void_p), ("edge_inv_sigma2", C.c_void_p)]
+                ("edge_uv", C.c_void_p), ("edge_inv_sigma2", C.c_void_p),
+                ("edge_ur", C.c_void_p), ("kf_bf", C.c_void_p)]   # stereo observations: both NULL for a monocular window
 
 
 class BaOpts(C.Structure):
     _fields_ = [("its_robust", C.c_int32), ("its_final", C.c_int32), ("huber_delta", C.c_double),
-                ("chi2_gate", C.c_double), ("stop", C.c_void_p)]
+                ("chi2_gate", C.c_double), ("stop", C.c_void_p),
+                ("huber_delta_stereo", C.c_double), ("chi2_gate_stereo", C.c_double)]   # 0: the reference's sqrt(7.815) / 7.815
 
 
 class BaStats(C.Structure):
@@ -579,13 +581,21 @@ def _ba_problem(arrs):
     for k, dt in (("kf_pose", np.float64), ("kf_fixed", np.uint8), ("kf_intr", np.float64), ("pt_xyz", np.float64),
                   ("edge_kf", np.int32), ("edge_pt", np.int32), ("edge_uv", np.float64), ("edge_inv_sigma2", np.float64)):
         keep[k] = np.ascontiguousarray(arrs[k], dtype=dt)
+    stereo = arrs.get("edge_ur") is not None
+    if stereo:   # right-image columns (negative: a monocular edge) and the keyframes' baseline x fx
+        keep["edge_ur"] = np.ascontiguousarray(arrs["edge_ur"], dtype=np.float64)
+        keep["kf_bf"] = np.ascontiguousarray(arrs["kf_bf"], dtype=np.float64)
+        if len(keep["edge_ur"]) != len(keep["edge_kf"]) or len(keep["kf_bf"]) != len(keep["kf_fixed"]):
+            raise SlamitError("edge_ur / kf_bf do not match the window's edges / keyframes")
     p = BaProblem(len(keep["kf_fixed"]), len(keep["pt_xyz"]), len(keep["edge_kf"]),
                   *[keep[k].ctypes.data for k in ("kf_pose", "kf_fixed", "kf_intr", "pt_xyz", "edge_kf", "edge_pt",
-                                                   "edge_uv", "edge_inv_sigma2")])
+                                                   "edge_uv", "edge_inv_sigma2")],
+                  keep["edge_ur"].ctypes.data if stereo else None, keep["kf_bf"].ctypes.data if stereo else None)
     return p, keep
 
 
 HUBER_MONO = float(np.float32(np.sqrt(5.991)))  # Optimizer.cc:569 stores sqrt(5.991) in a float
+HUBER_STEREO = float(np.float32(np.sqrt(7.815)))  # Optimizer.cc:570
 
 
 class Optimizer:
@@ -637,9 +647,10 @@ class Optimizer:
                 "trials": [list(st.trials[s])[:n[s]] for s in range(2)], "chi2_init": list(st.chi2_init)}
 
     def LocalBundleAdjustment(self, problem, its_robust=5, its_final=10, huber_delta=HUBER_MONO, chi2_gate=5.991,
-                              stop=None):
+                              stop=None, huber_delta_stereo=HUBER_STEREO, chi2_gate_stereo=7.815):
         p, keep = _ba_problem(problem)
-        o = BaOpts(its_robust, its_final, huber_delta, chi2_gate, stop.ctypes.data if stop is not None else None)
+        o = BaOpts(its_robust, its_final, huber_delta, chi2_gate, stop.ctypes.data if stop is not None else None,
+                   huber_delta_stereo, chi2_gate_stereo)
         r, out, st = self._result(p.n_kf, p.n_pt, p.n_edge)
         _check(lib().slamit_ba_solve(self._h, C.byref(p), C.byref(o), C.byref(r)), "slamit_ba_solve")
         out["stats"] = self._stats(st)
@@ -701,7 +712,7 @@ class Optimizer:
         return res[0] if single else res
 
     def LocalBundleAdjustmentBatch(self, problems, its_robust=5, its_final=10, huber_delta=HUBER_MONO,
-                                   chi2_gate=5.991):
+                                   chi2_gate=5.991, huber_delta_stereo=HUBER_STEREO, chi2_gate_stereo=7.815):
         n = len(problems)
         P = (BaProblem * n)()
         R = (BaResult * n)()
@@ -712,7 +723,7 @@ class Optimizer:
             R[i], out, st = self._result(P[i].n_kf, P[i].n_pt, P[i].n_edge)
             outs.append(out)
             sts.append(st)
-        o = BaOpts(its_robust, its_final, huber_delta, chi2_gate, None)
+        o = BaOpts(its_robust, its_final, huber_delta, chi2_gate, None, huber_delta_stereo, chi2_gate_stereo)
         _check(lib().slamit_ba_solve_batch(self._h, n, P, C.byref(o), R), "slamit_ba_solve_batch")
         for out, st in zip(outs, sts):
             out["stats"] = self._stats(st)

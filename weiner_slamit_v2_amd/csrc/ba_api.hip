@@ -76,6 +76,7 @@ struct Carver {
 struct IoLayout {
     // inputs
     double* in_pose; double* intr; int32_t* pose_col; double* in_pt; int32_t* e_kf; int32_t* e_pt; double* e_uv; double* e_w;
+    double* e_ur; double* bf;   // stereo windows only (slamit_ba_problem::edge_ur / kf_bf)
     int32_t* pt_edges; int32_t* kf_edges; int32_t* pt_ptr; int32_t* kf_ptr;
     size_t in_bytes;
     // outputs
@@ -84,15 +85,17 @@ struct IoLayout {
     size_t bytes;
 };
 
-IoLayout carve_io(uint8_t* base, int n_kf, int n_pt, int n_edge) {
+IoLayout carve_io(uint8_t* base, int n_kf, int n_pt, int n_edge, bool stereo) {
     Carver c{base, 0};
     IoLayout L;
+    L.e_ur = nullptr; L.bf = nullptr;
     L.in_pose = c.take<double>(12 * (size_t)n_kf); L.intr = c.take<double>(4 * (size_t)n_kf); L.pose_col = c.take<int32_t>(n_kf);
     L.in_pt = c.take<double>(3 * (size_t)std::max(n_pt, 1));
     L.e_kf = c.take<int32_t>(std::max(n_edge, 1)); L.e_pt = c.take<int32_t>(std::max(n_edge, 1));
     L.e_uv = c.take<double>(2 * (size_t)std::max(n_edge, 1)); L.e_w = c.take<double>(std::max(n_edge, 1));
     L.pt_edges = c.take<int32_t>(std::max(n_edge, 1)); L.kf_edges = c.take<int32_t>(std::max(n_edge, 1));
     L.pt_ptr = c.take<int32_t>((size_t)n_pt + 1); L.kf_ptr = c.take<int32_t>((size_t)n_kf + 1);
+    if (stereo) { L.e_ur = c.take<double>(std::max(n_edge, 1)); L.bf = c.take<double>(n_kf); }
     L.in_bytes = rup(c.off, 256);
     c.off = L.in_bytes;
     L.out_off = c.off;
@@ -109,7 +112,7 @@ size_t carve_work(uint8_t* base, BaWin& w, int max_kf, int max_pt, int max_edge,
     w.pose = c.take<double>(7 * (size_t)max_kf); w.pose_bak = c.take<double>(7 * (size_t)max_kf);
     w.pt = c.take<double>(3 * (size_t)max_pt); w.pt_bak = c.take<double>(3 * (size_t)max_pt);
     w.e_active = c.take<uint8_t>(max_edge); w.e_out1 = c.take<uint8_t>(max_edge);
-    w.e_chi2 = c.take<double>(max_edge); w.e_jac = c.take<double>(21 * (size_t)max_edge);
+    w.e_chi2 = c.take<double>(max_edge); w.e_jac = c.take<double>(BA_JAC_STEREO * (size_t)max_edge);
     w.Hll = c.take<double>(6 * (size_t)max_pt); w.bl = c.take<double>(3 * (size_t)max_pt);
     w.Dinv = c.take<double>(6 * (size_t)max_pt);
     w.Hpp = c.take<double>(36 * (size_t)max_kf); w.bp = c.take<double>(6 * (size_t)max_kf + 8);
@@ -142,7 +145,7 @@ int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int de
     }
     {
         BaWin probe;
-        h->io_cap = carve_io(nullptr, max_kf, max_pt, max_edge).bytes;
+        h->io_cap = carve_io(nullptr, max_kf, max_pt, max_edge, true).bytes;
         h->win_bytes = h->io_cap + carve_work(nullptr, probe, max_kf, max_pt, max_edge, h->Npad_max, h->Kpad_max, h->n_part);
     }
     hipError_t e = hipMalloc((void**)&h->d_slab, h->win_bytes * (size_t)max_batch);
@@ -204,6 +207,8 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         if (!P.kf_pose || !P.kf_fixed || !P.kf_intr || (P.n_pt && !P.pt_xyz) ||
             (P.n_edge && (!P.edge_kf || !P.edge_pt || !P.edge_uv || !P.edge_inv_sigma2)))
             return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: null input array");
+        if (P.edge_ur && !P.kf_bf)
+            return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: stereo observations (edge_ur) without the keyframes' bf (kf_bf)");
         if (!results[b].kf_pose || (P.n_pt && !results[b].pt_xyz))
             return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: null output array");
         mk = std::max(mk, P.n_kf); mp = std::max(mp, P.n_pt); me = std::max(me, P.n_edge);
@@ -215,7 +220,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
     std::vector<IoLayout> dio(nwin);   // device addresses inside the slabs
     size_t pin_need = 0;
     for (int b = 0; b < nwin; ++b) {
-        dio[b] = carve_io(h->d_slab + (size_t)b * h->win_bytes, probs[b].n_kf, probs[b].n_pt, probs[b].n_edge);
+        dio[b] = carve_io(h->d_slab + (size_t)b * h->win_bytes, probs[b].n_kf, probs[b].n_pt, probs[b].n_edge, probs[b].edge_ur != nullptr);
         in_off[b] = pin_need; pin_need += dio[b].in_bytes;
     }
     for (int b = 0; b < nwin; ++b) { out_off[b] = pin_need; pin_need += dio[b].bytes - dio[b].out_off; }
@@ -245,7 +250,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         memset(&w, 0, sizeof(w));
         carve_work(slab + h->io_cap, w, h->max_kf, h->max_pt, h->max_edge, h->Npad_max, h->Kpad_max, h->n_part);
         const IoLayout& D = dio[b];
-        const IoLayout H = carve_io(h->h_pin + in_off[b], P.n_kf, P.n_pt, P.n_edge);   // the same packing in the pinned block
+        const IoLayout H = carve_io(h->h_pin + in_off[b], P.n_kf, P.n_pt, P.n_edge, P.edge_ur != nullptr);   // the same packing in the pinned block
         w.intr = D.intr; w.pose_col = D.pose_col; w.e_kf = D.e_kf; w.e_pt = D.e_pt; w.e_uv = D.e_uv; w.e_w = D.e_w;
         w.pt_edges = D.pt_edges; w.kf_edges = D.kf_edges; w.pt_ptr = D.pt_ptr; w.kf_ptr = D.kf_ptr;
         io[b].in_pose = D.in_pose; io[b].in_pt = D.in_pt; io[b].out_pose = D.out_pose; io[b].out_pt = D.out_pt;
@@ -259,6 +264,11 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         w.Kpad = (int)rup((size_t)std::max(3 * P.n_pt, 1), (size_t)BA_KC * BA_SPLITS);
         w.n_part = h->n_part;
         w.huber_delta = opts->huber_delta; w.chi2_gate = opts->chi2_gate;
+        // stereo observations (EdgeStereoSE3ProjectXYZ): three residual rows per edge in this window, own Huber width and gate
+        w.huber_delta_s = opts->huber_delta_stereo > 0 ? opts->huber_delta_stereo : (double)(float)sqrt(7.815);   // Optimizer.cc:570
+        w.chi2_gate_s = opts->chi2_gate_stereo > 0 ? opts->chi2_gate_stereo : 7.815;                           // Optimizer.cc:696, 740
+        w.nrow = P.edge_ur ? 3 : 2;
+        w.e_ur = D.e_ur; w.bf = D.bf;
         w.st = h->d_states + b;
         // ---- structure of the window (g2o's BlockSolver / SimplicialLDLT exploit the same sparsity on the CPU,
         // block_solver.hpp:381-432, linear_solver_eigen.h:94-124) ----
@@ -330,7 +340,9 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
             memcpy(H.e_kf, P.edge_kf, sizeof(int32_t) * (size_t)P.n_edge);
             memcpy(H.e_uv, P.edge_uv, sizeof(double) * 2 * (size_t)P.n_edge);
             memcpy(H.e_w, P.edge_inv_sigma2, sizeof(double) * (size_t)P.n_edge);
+            if (P.edge_ur) memcpy(H.e_ur, P.edge_ur, sizeof(double) * (size_t)P.n_edge);
         }
+        if (P.edge_ur) memcpy(H.bf, P.kf_bf, sizeof(double) * (size_t)P.n_kf);
         int32_t* pptr = H.pt_ptr; int32_t* kptr = H.kf_ptr;
         for (int p2 = 0; p2 <= P.n_pt; ++p2) pptr[p2] = 0;
         for (int k = 0; k <= P.n_kf; ++k) kptr[k] = 0;
@@ -448,7 +460,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         const slamit_ba_problem& P = probs[b];
         slamit_ba_result& R = results[b];
         // the output section as the host sees it: same carve, shifted so that its output part starts at out_off[b]
-        const IoLayout H = carve_io(h->h_pin + out_off[b] - dio[b].out_off, P.n_kf, P.n_pt, P.n_edge);
+        const IoLayout H = carve_io(h->h_pin + out_off[b] - dio[b].out_off, P.n_kf, P.n_pt, P.n_edge, P.edge_ur != nullptr);
         memcpy(R.kf_pose, H.out_pose, sizeof(double) * 12 * (size_t)P.n_kf);
         for (int p2 = 0; p2 < P.n_pt; ++p2)   // points back in the caller's order
             for (int j = 0; j < 3; ++j) R.pt_xyz[3 * (size_t)perm[b][p2] + j] = H.out_pt[3 * (size_t)p2 + j];

@@ -70,6 +70,109 @@ __device__ __forceinline__ EdgeGeom edge_eval(const BaWin& W, int e) {
     return g;
 }
 
+// RobustKernelHuber keeps delta^2 in a FLOAT member (g2o/core/robust_kernel_impl.h:84, written by setDelta, robust_kernel_impl.cpp:64-68):
+// the inlier test and the constant of rho(e) = 2 delta sqrt(e) - delta^2 use the rounded value
+__device__ __forceinline__ double huber_dsqr(double delta) { return (double)(float)(delta * delta); }
+
+// ---- windows with stereo observations (EdgeStereoSE3ProjectXYZ, g2o/types/types_six_dof_expmap.h:112-141): three residual rows
+// per edge record (BA_JAC_STEREO doubles: A 3x3 | B 3x6 | wO | r0 r1 r2); a monocular edge of such a window keeps its own
+// expressions and a zero third row.  The monocular code above and below is untouched: a window takes one path or the other.
+struct EdgeGeom3 { double err0, err1, err2, chi2, x, y, z; bool stereo; };
+
+__device__ __forceinline__ bool edge_is_stereo(const BaWin& W, int e) { return W.nrow == 3 && !(W.e_ur[e] < 0.0); }   // Optimizer.cc:596
+
+__device__ __forceinline__ EdgeGeom3 edge_eval3(const BaWin& W, int e) {
+    const int kf = W.e_kf[e], pt = W.e_pt[e];
+    const double* T = W.pose + 7 * kf;
+    double Xc[3];
+    quat_rot(T, W.pt + 3 * pt, Xc);
+    Xc[0] += T[4]; Xc[1] += T[5]; Xc[2] += T[6];
+    const double* in = W.intr + 4 * kf;
+    EdgeGeom3 g;
+    g.x = Xc[0]; g.y = Xc[1]; g.z = Xc[2];
+    const double ur = W.e_ur[e];
+    g.stereo = !(ur < 0.0);
+    const double w = W.e_w[e];
+    if (!g.stereo) {
+        g.err0 = W.e_uv[2 * e] - (Xc[0] / Xc[2] * in[0] + in[2]);
+        g.err1 = W.e_uv[2 * e + 1] - (Xc[1] / Xc[2] * in[1] + in[3]);
+        g.err2 = 0.0;
+        g.chi2 = g.err0 * w * g.err0 + g.err1 * w * g.err1;
+    } else {
+        // cam_project (types_six_dof_expmap.cpp:150-157): `const float invz = 1.0f / z` (the quotient rounded to float), bf arrives
+        // through a `const float&`, and bf * invz is a FLOAT product
+        const float invz = (float)(1.0 / Xc[2]);
+        const double r0 = Xc[0] * (double)invz * in[0] + in[2];
+        const double r1 = Xc[1] * (double)invz * in[1] + in[3];
+        const double r2 = r0 - (double)__fmul_rn((float)W.bf[kf], invz);
+        g.err0 = W.e_uv[2 * e] - r0; g.err1 = W.e_uv[2 * e + 1] - r1; g.err2 = ur - r2;
+        g.chi2 = g.err0 * w * g.err0 + g.err1 * w * g.err1 + g.err2 * w * g.err2;
+    }
+    return g;
+}
+
+__device__ __forceinline__ void edge_jacobian3(const BaWin& W, bool robust, int e, double* J /*[31]*/) {
+    const EdgeGeom3 g = edge_eval3(W, e);
+    const int kf = W.e_kf[e];
+    const double* in = W.intr + 4 * kf;
+    const double fx = in[0], fy = in[1];
+    double R[9];
+    quat_to_R(W.pose + 7 * kf, R);
+    const double x = g.x, y = g.y, z = g.z, z_2 = z * z;
+    double delta = W.huber_delta;
+    if (!g.stereo) {   // EdgeSE3ProjectXYZ::linearizeOplus, as in edge_jacobian
+        const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c)
+                J[3 * r + c] = -1. / z * (tmp[3 * r] * R[c] + tmp[3 * r + 1] * R[3 + c] + tmp[3 * r + 2] * R[6 + c]);
+        J[6] = 0; J[7] = 0; J[8] = 0;
+    } else {           // EdgeStereoSE3ProjectXYZ::linearizeOplus (types_six_dof_expmap.cpp:188-234), its expressions as written
+        const double bf = W.bf[kf];
+        for (int c = 0; c < 3; ++c) {
+            J[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+            J[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+            J[6 + c] = J[c] - bf * R[6 + c] / z_2;
+        }
+        delta = W.huber_delta_s;
+    }
+    double* B = J + 9;
+    B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx;
+    B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+    B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy;
+    B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+    if (g.stereo) {
+        const double bf = W.bf[kf];
+        B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2];
+        B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2;
+    } else {
+        for (int i = 12; i < 18; ++i) B[i] = 0;
+    }
+    double rho1 = 1.0;
+    if (robust && g.chi2 > huber_dsqr(delta)) rho1 = delta / sqrt(g.chi2);
+    const double w = W.e_w[e];
+    J[27] = rho1 * w;
+    J[28] = -w * g.err0 * rho1;
+    J[29] = -w * g.err1 * rho1;
+    J[30] = -w * g.err2 * rho1;
+}
+
+// one edge's share of its point's blocks: b[3] += A^T omega_r, h[6] (xx xy xz yy yz zz) += A^T wO A
+__device__ __forceinline__ void point_accum3(const double* J, double* h, double* b) {
+    const double wO = J[27], r0 = J[28], r1 = J[29], r2 = J[30];
+    b[0] += J[0] * r0 + J[3] * r1 + J[6] * r2; b[1] += J[1] * r0 + J[4] * r1 + J[7] * r2; b[2] += J[2] * r0 + J[5] * r1 + J[8] * r2;
+    h[0] += (J[0] * J[0] + J[3] * J[3] + J[6] * J[6]) * wO; h[1] += (J[0] * J[1] + J[3] * J[4] + J[6] * J[7]) * wO; h[2] += (J[0] * J[2] + J[3] * J[5] + J[6] * J[8]) * wO;
+    h[3] += (J[1] * J[1] + J[4] * J[4] + J[7] * J[7]) * wO; h[4] += (J[1] * J[2] + J[4] * J[5] + J[7] * J[8]) * wO; h[5] += (J[2] * J[2] + J[5] * J[5] + J[8] * J[8]) * wO;
+}
+
+// Hpl (6 x 3) of one edge of a stereo window
+__device__ __forceinline__ void hpl_of3(const double* J, double* H /*6x3*/) {
+    const double wO = J[27];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) H[3 * i + j] = (J[9 + i] * J[j] + J[15 + i] * J[3 + j] + J[21 + i] * J[6 + j]) * wO;
+}
+
 // ---- S1: Jacobians + weights of every active edge --------------------------------------------
 __device__ __forceinline__ void edge_jacobian(const BaWin& W, bool robust, int e, double* J /*[21]*/) {
     const EdgeGeom g = edge_eval(W, e);
@@ -87,7 +190,7 @@ __device__ __forceinline__ void edge_jacobian(const BaWin& W, bool robust, int e
     J[9] = -1. / z * fx; J[10] = 0; J[11] = x / z_2 * fx;
     J[12] = (1 + y * y / z_2) * fy; J[13] = -x * y / z_2 * fy; J[14] = -x / z * fy;
     J[15] = 0; J[16] = -1. / z * fy; J[17] = y / z_2 * fy;
-    const double dsqr = W.huber_delta * W.huber_delta;
+    const double dsqr = huber_dsqr(W.huber_delta);
     double rho1 = 1.0;
     if (robust && g.chi2 > dsqr) rho1 = W.huber_delta / sqrt(g.chi2);
     const double w = W.e_w[e];
@@ -103,6 +206,14 @@ __global__ __launch_bounds__(256) void k_linearize(BaWin* wins) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e == 0 && st->it == 0) st->maxdiag_bits = 0ull;
     if (e >= W.n_edge || !W.e_active[e]) return;
+    if (W.nrow == 3) {
+        double J3[BA_JAC_STEREO];
+        edge_jacobian3(W, st->robust != 0, e, J3);
+        double* Jm = W.e_jac + BA_JAC_STEREO * (size_t)e;
+#pragma unroll
+        for (int i = 0; i < BA_JAC_STEREO; ++i) Jm[i] = J3[i];
+        return;
+    }
     double Jr[21];
     edge_jacobian(W, st->robust != 0, e, Jr);
     double* J = W.e_jac + 21 * (size_t)e;
@@ -138,6 +249,7 @@ __global__ __launch_bounds__(256) void k_point_reduce(BaWin* wins) {
         for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
             const int e = W.pt_edges[i];
             if (!W.e_active[e]) continue;
+            if (W.nrow == 3) { point_accum3(W.e_jac + BA_JAC_STEREO * (size_t)e, h, b); continue; }
             const double* J = W.e_jac + 21 * (size_t)e;
             const double wO = J[18], r0 = J[19], r1 = J[20];
             b[0] += J[0] * r0 + J[3] * r1; b[1] += J[1] * r0 + J[4] * r1; b[2] += J[2] * r0 + J[5] * r1;
@@ -186,6 +298,18 @@ __device__ __forceinline__ void pose_reduce_body(const BaWin& W, int kf) {
     for (int i = W.kf_ptr[kf] + tid; i < W.kf_ptr[kf + 1]; i += 256) {
         const int e = W.kf_edges[i];
         if (!W.e_active[e]) continue;
+        if (W.nrow == 3) {
+            const double* J = W.e_jac + BA_JAC_STEREO * (size_t)e;
+            const double wO = J[27], r0 = J[28], r1 = J[29], r2 = J[30];
+            int k = 6;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                acc[a] += J[9 + a] * r0 + J[15 + a] * r1 + J[21 + a] * r2;
+#pragma unroll
+                for (int c = a; c < 6; ++c) acc[k++] += (J[9 + a] * J[9 + c] + J[15 + a] * J[15 + c] + J[21 + a] * J[21 + c]) * wO;
+            }
+            continue;
+        }
         const double* J = W.e_jac + 21 * (size_t)e;
         const double wO = J[18], r0 = J[19], r1 = J[20];
         int k = 6;
@@ -274,7 +398,8 @@ __global__ __launch_bounds__(256) void k_prepare(BaWin* wins) {   // BA_PG lanes
         const int col = W.pose_col[W.e_kf[e]];
         if (col < 0) continue;
         double H[18];
-        hpl_of(W.e_jac + 21 * (size_t)e, H);
+        if (W.nrow == 3) hpl_of3(W.e_jac + BA_JAC_STEREO * (size_t)e, H);
+        else hpl_of(W.e_jac + 21 * (size_t)e, H);
         for (int r = 0; r < 6; ++r) {
             const double h0 = H[3 * r], h1 = H[3 * r + 1], h2 = H[3 * r + 2];
             const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)p;
@@ -306,6 +431,15 @@ __global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
             for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
                 const int e = W.pt_edges[i];
                 if (!W.e_active[e]) continue;
+                if (W.nrow == 3) {
+                    double J3[BA_JAC_STEREO];
+                    edge_jacobian3(W, robust, e, J3);
+                    double* J3m = W.e_jac + BA_JAC_STEREO * (size_t)e;
+#pragma unroll
+                    for (int k = 0; k < BA_JAC_STEREO; ++k) J3m[k] = J3[k];
+                    point_accum3(J3, h, b);
+                    continue;
+                }
                 double J[21];
                 edge_jacobian(W, robust, e, J);
                 double* Jm = W.e_jac + 21 * (size_t)e;
@@ -348,7 +482,8 @@ __global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
         const int col = W.pose_col[W.e_kf[e]];
         if (col < 0) continue;
         double H[18];
-        hpl_of(W.e_jac + 21 * (size_t)e, H);   // this lane's own store when lin (same address, same thread)
+        if (W.nrow == 3) hpl_of3(W.e_jac + BA_JAC_STEREO * (size_t)e, H);
+        else hpl_of(W.e_jac + 21 * (size_t)e, H);   // this lane's own store when lin (same address, same thread)
         for (int r = 0; r < 6; ++r) {
             const double h0 = H[3 * r], h1 = H[3 * r + 1], h2 = H[3 * r + 2];
             const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)p;
@@ -1279,7 +1414,8 @@ __global__ __launch_bounds__(256) void k_backsub_update(BaWin* wins) {   // BA_P
             const int col = W.pose_col[W.e_kf[e]];
             if (col < 0) continue;
             double H[18];
-            hpl_of(W.e_jac + 21 * (size_t)e, H);
+            if (W.nrow == 3) hpl_of3(W.e_jac + BA_JAC_STEREO * (size_t)e, H);
+            else hpl_of(W.e_jac + 21 * (size_t)e, H);
             const double* xp = W.rhs + 6 * col;
             for (int j = 0; j < 3; ++j)
                 for (int r = 0; r < 6; ++r) cl[j] -= H[3 * r + j] * xp[r];
@@ -1328,11 +1464,19 @@ __global__ __launch_bounds__(256) void k_errors(BaWin* wins) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     double rho = 0;
     if (e < W.n_edge && W.e_active[e]) {
+        if (W.nrow == 3) {
+            const EdgeGeom3 g = edge_eval3(W, e);
+            W.e_chi2[e] = g.chi2;
+            const double delta = g.stereo ? W.huber_delta_s : W.huber_delta, dsqr = huber_dsqr(delta);
+            if (st->robust && g.chi2 > dsqr) rho = 2 * sqrt(g.chi2) * delta - dsqr;
+            else rho = g.chi2;
+        } else {
         const EdgeGeom g = edge_eval(W, e);
         W.e_chi2[e] = g.chi2;
-        const double dsqr = W.huber_delta * W.huber_delta;
+        const double dsqr = huber_dsqr(W.huber_delta);
         if (st->robust && g.chi2 > dsqr) rho = 2 * sqrt(g.chi2) * W.huber_delta - dsqr;
         else rho = g.chi2;
+        }
     }
     const double tot = block_sum_256(rho, sh);
     if (threadIdx.x == 0) W.chi_part[blockIdx.x] = tot;
@@ -1405,7 +1549,7 @@ __global__ __launch_bounds__(256) void k_gate(BaWin* wins) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= W.n_edge) return;
     const EdgeGeom g = edge_eval(W, e);
-    const bool out = W.e_chi2[e] > W.chi2_gate || !(g.z > 0.0);
+    const bool out = W.e_chi2[e] > (edge_is_stereo(W, e) ? W.chi2_gate_s : W.chi2_gate) || !(g.z > 0.0);   // Optimizer.cc:680, :696
     W.e_out1[e] = out;
     if (out && W.e_active[e]) {
         W.e_active[e] = 0;
@@ -1485,7 +1629,7 @@ __global__ __launch_bounds__(256) void k_final(BaWin* wins, const BaIo* io) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < W.n_edge) {
         const EdgeGeom g = edge_eval(W, e);
-        O.out_flag[e] = W.e_chi2[e] > W.chi2_gate || !(g.z > 0.0);
+        O.out_flag[e] = W.e_chi2[e] > (edge_is_stereo(W, e) ? W.chi2_gate_s : W.chi2_gate) || !(g.z > 0.0);   // Optimizer.cc:723, :740
         O.out_chi2[e] = W.e_chi2[e];
         O.out_out1[e] = W.e_out1[e];
     }

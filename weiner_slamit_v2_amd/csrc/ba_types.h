@@ -10,6 +10,8 @@
 #define BA_SPLITS 16        // split-K factor of the Schur GEMM
 #define BA_MAX_TILES 10     // 64-row tiles of the reduced system (slamit_ba_create refuses larger handles)
 #define BA_MAX_PANELS 20    // 32-column LDLt panels
+#define BA_JAC_MONO 21      // doubles per edge record: A (2x3) B (2x6) wO r0 r1
+#define BA_JAC_STEREO 31    // ... of a window with stereo observations: A (3x3) B (3x6) wO r0 r1 r2 (a monocular edge's third row is zero)
 #define BA_SOLVER_BAND 0      // narrow row envelope: block LDLt inside LDS (k_ldlt_band)
 #define BA_SOLVER_BLOCKED 1   // any other structure: 32-column panels through L2 (k_ldlt_blocked)
 
@@ -56,6 +58,9 @@ struct BaWin {
     int32_t Kpad;      // padded k extent (3 * n_pt rounded up to BA_KC * BA_SPLITS)
     int32_t n_part;    // partial-sum slots of the chi2 reduction
     double huber_delta, chi2_gate;
+    double huber_delta_s, chi2_gate_s;   // stereo edges (Optimizer.cc:570, :696)
+    int32_t nrow;      // residual rows per edge record: 2 (every edge monocular) or 3 (the window has stereo observations)
+    int32_t pad0;
     // Structure of the window (host, ba_api.hip), conservative for both stages.  Points are stored sorted by the first
     // free keyframe that observes them, so the non-zeros of a 64-row tile of GA / GB sit in ONE k range, and the reduced
     // system has a row envelope (first coupled column per pose) that LDLt without pivoting never leaves.
@@ -76,10 +81,12 @@ struct BaWin {
     BA_G int32_t* e_kf; BA_G int32_t* e_pt;
     BA_G double* e_uv;      // n_edge x 2
     BA_G double* e_w;       // n_edge
+    BA_G double* e_ur;      // n_edge: right-image column, < 0 on a monocular edge (stereo windows only)
+    BA_G double* bf;        // n_kf: baseline x fx (stereo windows only)
     BA_G uint8_t* e_active;
     BA_G uint8_t* e_out1;   // stage-1 outlier flag
     BA_G double* e_chi2;    // chi2 of the last evaluated trial
-    BA_G double* e_jac;     // n_edge x 21: A(2x3) B(2x6) wO r0 r1
+    BA_G double* e_jac;     // n_edge x 21: A(2x3) B(2x6) wO r0 r1  (x 31 in a stereo window: BA_JAC_STEREO)
     BA_G int32_t* pt_ptr; BA_G int32_t* pt_edges;     // CSR: edges of each point
     BA_G int32_t* kf_ptr; BA_G int32_t* kf_edges;     // CSR: edges of each keyframe
     // normal equations

@@ -67,7 +67,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {  // 256 thre
 
 // residual + chi2 of every active edge at pose T; returns the robust cost
 __device__ double pose_errors(const PoseFrameG& F, const double* T, const uint8_t* active, int robust, double delta, double* sh) {
-    const double dsqr = delta * delta;
+    const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float member (g2o/core/robust_kernel_impl.h:84)
     const double fx = F.intr[0], fy = F.intr[1], cx = F.intr[2], cy = F.intr[3];
     double part = 0;
     for (int e = threadIdx.x; e < F.n; e += 256) {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void pose_opt_kernel(const PoseFrame* frames) 
                 double h[21], bb[6];
                 for (int i = 0; i < 21; ++i) h[i] = 0;
                 for (int i = 0; i < 6; ++i) bb[i] = 0;
-                const double dsqr = delta * delta, fx = F.intr[0], fy = F.intr[1];
+                const double dsqr = (double)(float)(delta * delta), fx = F.intr[0], fy = F.intr[1];
                 for (int e = tid; e < n; e += 256) {
                     if (!s_act[e]) continue;
                     double Xc[3];

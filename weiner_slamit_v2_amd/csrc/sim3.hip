@@ -136,7 +136,7 @@ __device__ __forceinline__ double huber(double c2, double delta, double dsqr) { 
 __device__ double sim3_errors(const Sim3Prob& P, const double* S, const uint8_t* active, double delta, double* sSi, double* sh) {
     if (threadIdx.x == 0) sim3_inverse(S, sSi);
     __syncthreads();
-    const double dsqr = delta * delta;
+    const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float member (g2o/core/robust_kernel_impl.h:84)
     double part = 0;
     for (int k = threadIdx.x; k < P.n; k += 256) {
         if (!active[k]) continue;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void sim3_opt_kernel(const Sim3Prob* probs) {
                 double h[28], bb[7];
                 for (int i = 0; i < 28; ++i) h[i] = 0;
                 for (int i = 0; i < 7; ++i) bb[i] = 0;
-                const double dsqr = delta * delta, scalar = 1.0 / (2 * 1e-9);
+                const double dsqr = (double)(float)(delta * delta), scalar = 1.0 / (2 * 1e-9);
                 for (int k = tid; k < n; k += 256) {
                     if (!s_act[k]) continue;
                     const double p1[3] = {P.p1[3 * k], P.p1[3 * k + 1], P.p1[3 * k + 2]}, p2[3] = {P.p2[3 * k], P.p2[3 * k + 1], P.p2[3 * k + 2]};

@@ -16,8 +16,8 @@
 //   MapPoint : mnId, mnBALocalForKF, isBad(), GetObservations(), GetWorldPos(), SetWorldPos(),
 //              UpdateNormalAndDepth(), EraseObservation(KeyFrame*)
 //   Map      : mMutexMapUpdate
-// Stereo observations (mvuRight >= 0, :621-650) are not handled by the HIP path yet; a window that
-// contains one is left untouched and LastStatus() reports SLAMIT_ERR_ARG.
+// Stereo observations (mvuRight >= 0, :621-650: EdgeStereoSE3ProjectXYZ with the keyframe's mbf, Huber width sqrt(7.815), gate
+// 7.815) ride in the same solve: slamit_ba_problem::edge_ur / kf_bf.  (KeyFrame::mbf is read only when a window has one.)
 #ifndef SLAMIT_SHIM_OPTIMIZER_H
 #define SLAMIT_SHIM_OPTIMIZER_H
 
@@ -57,7 +57,7 @@ public:
     // Tracking::CreateInitialMapMonocular and LoopClosing::RunGlobalBundleAdjustment): every keyframe and map point handed
     // in, keyframe id 0 fixed, ONE optimize(nIterations) with Huber delta sqrt(5.99) (or no kernel) -- the same device solve
     // with the schedule (nIterations, 0).  Additional members: KeyFrame : mTcwGBA, mnBAGlobalForKF ; MapPoint : mPosGBA,
-    // mnBAGlobalForKF ; Map : GetAllKeyFrames(), GetAllMapPoints().  Mono only.
+    // mnBAGlobalForKF ; Map : GetAllKeyFrames(), GetAllMapPoints().  Stereo observations as in LocalBundleAdjustment (thHuber3D).
     template <class KeyFrameT, class MapPointT>
     static void BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std::vector<MapPointT*>& vpMP, int nIterations = 5,
                                  bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true);
@@ -112,6 +112,8 @@ inline int Optimizer::LocalBundleAdjustmentPOD(const slamit_ba_problem& prob, co
     o.its_final = 10;                              // :707
     o.huber_delta = (double)(float)sqrt(5.991);    // :569 (a float in the reference)
     o.chi2_gate = 5.991;                           // :680,723
+    o.huber_delta_stereo = (double)(float)sqrt(7.815);   // :570
+    o.chi2_gate_stereo = 7.815;                    // :696,740
     o.stop = reinterpret_cast<const volatile uint8_t*>(stop);
     return SolvePOD(prob, o, res);
 }
@@ -122,7 +124,7 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std
     // ---- vertices (Optimizer.cc:69-85, 91-105) and edges (:107-160), flattened ----
     std::vector<KeyFrameT*> kfs;
     std::map<KeyFrameT*, int> kfIndex;
-    std::vector<double> pose, intr, pts, uv, invSigma2;
+    std::vector<double> pose, intr, pts, uv, invSigma2, ur, bf;
     std::vector<uint8_t> fixed;
     std::vector<int32_t> ekf, ept;
     long unsigned int maxKFid = 0;
@@ -151,25 +153,28 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std
             if (pKF->isBad() || pKF->mnId > maxKFid) continue;
             typename std::map<KeyFrameT*, int>::iterator where = kfIndex.find(pKF);
             if (where == kfIndex.end()) continue;
-            if (pKF->mvuRight[mit->second] >= 0) { hasStereo = true; continue; }
             const cv::KeyPoint& kpUn = pKF->mvKeysUn[mit->second];
             nEdges++;
             ekf.push_back(where->second); ept.push_back(p);
             uv.push_back(kpUn.pt.x); uv.push_back(kpUn.pt.y);
             invSigma2.push_back(pKF->mvInvLevelSigma2[kpUn.octave]);
+            const float kp_ur = pKF->mvuRight[mit->second];          // :112 monocular below zero, :135-160 the stereo edge
+            ur.push_back(kp_ur < 0 ? -1.0 : (double)kp_ur);
+            hasStereo = hasStereo || !(kp_ur < 0);
         }
         if (nEdges == 0) continue;        // optimizer.removeVertex(vPoint)
         cv::Mat X = pMP->GetWorldPos();
         for (int r = 0; r < 3; ++r) pts.push_back((double)X.template at<float>(r, 0));
         mps.push_back(pMP);
     }
-    if (hasStereo) { lastStatus() = SLAMIT_ERR_ARG; return; }
     if (kfs.empty()) return;
+    if (hasStereo) for (size_t k = 0; k < kfs.size(); ++k) bf.push_back((double)kfs[k]->mbf);   // e->bf = pKF->mbf, :152
 
     slamit_ba_problem prob;
     prob.n_kf = (int32_t)kfs.size(); prob.n_pt = (int32_t)mps.size(); prob.n_edge = (int32_t)ekf.size();
     prob.kf_pose = pose.data(); prob.kf_fixed = fixed.data(); prob.kf_intr = intr.data(); prob.pt_xyz = pts.data();
     prob.edge_kf = ekf.data(); prob.edge_pt = ept.data(); prob.edge_uv = uv.data(); prob.edge_inv_sigma2 = invSigma2.data();
+    prob.edge_ur = hasStereo ? ur.data() : 0; prob.kf_bf = hasStereo ? bf.data() : 0;
     std::vector<double> outPose(pose.size()), outPts(pts.size() + 3), chi2(ekf.size() + 1);
     std::vector<uint8_t> outlier(ekf.size() + 1), outlier1(ekf.size() + 1);
     slamit_ba_result res;
@@ -180,6 +185,8 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrameT*>& vpKFs, const std
     o.its_final = 0;
     o.huber_delta = bRobust ? (double)(float)sqrt(5.99) : HUGE_VAL;    // thHuber2D, :87 ; no kernel = a delta nothing exceeds
     o.chi2_gate = 5.991;                                               // unused: there is no second stage
+    o.huber_delta_stereo = bRobust ? (double)(float)sqrt(7.815) : HUGE_VAL;   // thHuber3D, :88
+    o.chi2_gate_stereo = 7.815;
     o.stop = reinterpret_cast<const volatile uint8_t*>(pbStopFlag);
     if (SolvePOD(prob, o, res) != SLAMIT_OK) return;
 
@@ -349,7 +356,7 @@ void Optimizer::LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pM
     // ---- flatten into the C-ABI's arrays (vertices :522-546, edges :572-653) ----
     std::vector<KeyFrameT*> kfs;
     std::map<KeyFrameT*, int> kfIndex;
-    std::vector<double> pose, intr, pts, uv, invSigma2;
+    std::vector<double> pose, intr, pts, uv, invSigma2, ur, bf;
     std::vector<uint8_t> fixed;
     std::vector<int32_t> ekf, ept;
     for (int pass = 0; pass < 2; ++pass) {
@@ -377,15 +384,17 @@ void Optimizer::LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pM
             if (pKFi->isBad()) continue;
             typename std::map<KeyFrameT*, int>::iterator where = kfIndex.find(pKFi);
             if (where == kfIndex.end()) continue;
-            if (pKFi->mvuRight[mit->second] >= 0) { hasStereo = true; continue; }
             const cv::KeyPoint& kpUn = pKFi->mvKeysUn[mit->second];
             ekf.push_back(where->second); ept.push_back((int32_t)p);
             uv.push_back(kpUn.pt.x); uv.push_back(kpUn.pt.y);
             invSigma2.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
+            const float kp_ur = pKFi->mvuRight[mit->second];         // :596 monocular below zero, :621-650 the stereo edge
+            ur.push_back(kp_ur < 0 ? -1.0 : (double)kp_ur);
+            hasStereo = hasStereo || !(kp_ur < 0);
             edgeOwner.push_back(std::make_pair(pKFi, mps[p]));
         }
     }
-    if (hasStereo) { lastStatus() = SLAMIT_ERR_ARG; return; }
+    if (hasStereo) for (size_t k2 = 0; k2 < kfs.size(); ++k2) bf.push_back((double)kfs[k2]->mbf);   // e->bf = pKFi->mbf, :641
     if (pbStopFlag && *pbStopFlag) return;  // :655-657
 
     // ---- (2) the optimisation itself ----
@@ -393,6 +402,7 @@ void Optimizer::LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pM
     prob.n_kf = (int32_t)kfs.size(); prob.n_pt = (int32_t)mps.size(); prob.n_edge = (int32_t)ekf.size();
     prob.kf_pose = pose.data(); prob.kf_fixed = fixed.data(); prob.kf_intr = intr.data(); prob.pt_xyz = pts.data();
     prob.edge_kf = ekf.data(); prob.edge_pt = ept.data(); prob.edge_uv = uv.data(); prob.edge_inv_sigma2 = invSigma2.data();
+    prob.edge_ur = hasStereo ? ur.data() : 0; prob.kf_bf = hasStereo ? bf.data() : 0;
     std::vector<double> outPose(pose.size()), outPts(pts.size()), chi2(ekf.size());
     std::vector<uint8_t> outlier(ekf.size()), outlier1(ekf.size());
     slamit_ba_result res;

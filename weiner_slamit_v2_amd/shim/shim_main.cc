@@ -63,13 +63,13 @@ struct MockMapPoint {
 struct MockKeyFrame {
     long unsigned int mnId, mnBALocalForKF, mnBAFixedForKF, mnBAGlobalForKF;
     cv::Mat Tcw, mTcwGBA;
-    float fx, fy, cx, cy;
+    float fx, fy, cx, cy, mbf;
     std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<float> mvuRight, mvInvLevelSigma2;
     std::vector<MockMapPoint*> matches;
     std::vector<MockKeyFrame*> covisible;
     int erased;
-    MockKeyFrame() : mnId(0), mnBALocalForKF(~0ul), mnBAFixedForKF(~0ul), mnBAGlobalForKF(0), erased(0) {}
+    MockKeyFrame() : mnId(0), mnBALocalForKF(~0ul), mnBAFixedForKF(~0ul), mnBAGlobalForKF(0), mbf(0.f), erased(0) {}
     bool isBad() { return false; }
     std::vector<MockKeyFrame*> GetVectorCovisibleKeyFrames() { return covisible; }
     std::vector<MockMapPoint*> GetMapPointMatches() { return matches; }
@@ -143,6 +143,7 @@ static int run_match(int argc, char** argv) {
 
 // problem.bin: int32 n_kf n_pt n_edge | float pose[n_kf*12] | u8 fixed[n_kf] (padded to 4) |
 //              float intr[4] | float pts[n_pt*3] | int32 ekf[] | int32 ept[] | float uv[2e] | float invsig[e]
+//              [ | float bf | float ur[e] ]   (a window with stereo observations: KeyFrame::mbf and mvuRight, -1 = monocular)
 static int run_ba(int argc, char** argv) {
     if (argc < 4) return 2;
     std::vector<unsigned char> raw = slurp(argv[2]);
@@ -157,7 +158,10 @@ static int run_ba(int argc, char** argv) {
     const int* ekf = (const int*)p; p += 4 * E;
     const int* ept = (const int*)p; p += 4 * E;
     const float* uv = (const float*)p; p += 8 * E;
-    const float* isg = (const float*)p;
+    const float* isg = (const float*)p; p += 4 * E;
+    const bool stereo = (size_t)(p - raw.data()) + 4 + 4 * (size_t)E <= raw.size();
+    const float bf = stereo ? *(const float*)p : 0.f;
+    const float* ur = stereo ? (const float*)(p + 4) : 0;
     std::vector<MockKeyFrame> kfs(K);
     std::vector<MockMapPoint> mps(P);
     for (int k = 0; k < K; ++k) {
@@ -167,7 +171,7 @@ static int run_ba(int argc, char** argv) {
         kf.Tcw = cv::Mat(4, 4, CV_32F);
         for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) kf.Tcw.at<float>(r, c) = pose[12 * k + 3 * r + c]; kf.Tcw.at<float>(r, 3) = pose[12 * k + 9 + r]; kf.Tcw.at<float>(3, r) = 0; }
         kf.Tcw.at<float>(3, 3) = 1;
-        kf.fx = intr[0]; kf.fy = intr[1]; kf.cx = intr[2]; kf.cy = intr[3];
+        kf.fx = intr[0]; kf.fy = intr[1]; kf.cx = intr[2]; kf.cy = intr[3]; kf.mbf = bf;
         kf.mvInvLevelSigma2.assign(1, 1.0f);
     }
     for (int q = 0; q < P; ++q) {
@@ -182,7 +186,7 @@ static int run_ba(int argc, char** argv) {
         kp.octave = (int)kf.mvInvLevelSigma2.size();   // one sigma entry per observation keeps invSigma2 exact
         kf.mvInvLevelSigma2.push_back(isg[e]);
         kf.mvKeysUn.push_back(kp);
-        kf.mvuRight.push_back(-1.f);
+        kf.mvuRight.push_back(ur ? ur[e] : -1.f);
         kf.matches.push_back(&mps[ept[e]]);
         mps[ept[e]].obs[&kf] = slot;
     }

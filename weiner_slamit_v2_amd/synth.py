@@ -136,10 +136,13 @@ def _inv_sigma2_table(nlevels=8, scale=1.2):
     return np.array(out, dtype=np.float32)
 
 
-def synth_ba(n_kf=50, n_pt=2000, obs_per_pt=8, outlier_frac=0.03, seed=12345, n_fixed=1):
+def synth_ba(n_kf=50, n_pt=2000, obs_per_pt=8, outlier_frac=0.03, seed=12345, n_fixed=1, stereo_frac=0.0, baseline=0.08):
     """Returns a dict of numpy arrays laid out as include/slamit.h:slamit_ba_problem wants them.
 
-    obs_per_pt = None or >= n_kf gives the dense pattern (every point in every keyframe)."""
+    obs_per_pt = None or >= n_kf gives the dense pattern (every point in every keyframe).
+    stereo_frac > 0: that fraction of the observations also carries the keypoint's column in the right image (edge_ur; -1 on the
+    monocular ones, KeyFrame::mvuRight) and the dict gains kf_bf = baseline x fx per keyframe (KeyFrame::mbf): the window of a
+    stereo / RGB-D session, Optimizer.cc:621-650.  The monocular arrays do not depend on stereo_frac (own random stream)."""
     rs = np.random.RandomState(seed)
     fx, fy, cx, cy = INTRINSICS
     Rs, ts = [], []
@@ -152,7 +155,9 @@ def synth_ba(n_kf=50, n_pt=2000, obs_per_pt=8, outlier_frac=0.03, seed=12345, n_
     inv_sig = _inv_sigma2_table()
     quota = np.array([217, 181, 151, 126, 105, 87, 73, 60], dtype=np.float64)
     quota /= quota.sum()
-    e_kf, e_pt, e_uv, e_is = [], [], [], []
+    e_kf, e_pt, e_uv, e_is, e_ur = [], [], [], [], []
+    rs2 = np.random.RandomState(seed + 777)
+    bf = float(np.float32(baseline * fx))
     for p in range(n_pt):
         if dense:
             kfs = range(n_kf)
@@ -171,6 +176,11 @@ def synth_ba(n_kf=50, n_pt=2000, obs_per_pt=8, outlier_frac=0.03, seed=12345, n_
             e_pt.append(p)
             e_uv.append((u, v))
             e_is.append(inv_sig[octave])
+            if stereo_frac > 0:
+                ur = u - bf / Xc[2] + rs2.normal(0.0, 1.0)
+                if rs2.uniform() < outlier_frac:
+                    ur += rs2.choice([-20.0, 20.0])
+                e_ur.append(ur if rs2.uniform() < stereo_frac else -1.0)
     # perturbed initial estimates, rounded to float32 then widened (Converter.cc)
     poses = np.zeros((n_kf, 12))
     for k in range(n_kf):
@@ -186,7 +196,11 @@ def synth_ba(n_kf=50, n_pt=2000, obs_per_pt=8, outlier_frac=0.03, seed=12345, n_
     fixed = np.zeros(n_kf, dtype=np.uint8)
     fixed[:n_fixed] = 1
     intr = np.tile(np.array([fx, fy, cx, cy], dtype=np.float32).astype(np.float64), (n_kf, 1))
+    extra = {}
+    if stereo_frac > 0:
+        extra = {"edge_ur": np.array(e_ur, dtype=np.float32).astype(np.float64), "kf_bf": np.full(n_kf, bf)}
     return {
+        **extra,
         "kf_pose": np.ascontiguousarray(poses),
         "kf_fixed": fixed,
         "kf_intr": np.ascontiguousarray(intr),
