@@ -423,6 +423,11 @@ typedef struct slamit_pose_problem {
     const double* xw;        /* n x 3 world points (float positions widened) */
     const double* uv;        /* n x 2 */
     const double* inv_sigma2;/* n */
+    /* Stereo correspondences (EdgeStereoSE3ProjectXYZOnlyPose, Thirdparty/g2o/g2o/types/types_six_dof_expmap.h:174-202;
+       src/Optimizer.cc:319-356): ur[i] = the keypoint's column in the right image (Frame::mvuRight), negative for a
+       monocular one; bf = Frame::mbf.  ur NULL: every correspondence is monocular and bf is not read. */
+    const double* ur;        /* n, nullable */
+    double bf;
 } slamit_pose_problem;
 
 typedef struct slamit_pose_result {

@@ -519,36 +519,54 @@ extern "C" int ba_oracle_solve(const slamit_ba_problem* in, const slamit_ba_opts
 // =================================================================================================
 namespace {
 
-struct PEdge { double X[3], u, v, w; bool active, robust; double err[2], chi2; };
+struct PEdge { double X[3], u, v, w, ur; bool stereo, active, robust; double err[3], chi2; };
 
-double pose_errors(const Pose& T, const double* in, std::vector<PEdge>& E, double delta) {
+// the error of one edge at camera-frame point Xc: EdgeSE3ProjectXYZOnlyPose (project2d, then * f + c) or
+// EdgeStereoSE3ProjectXYZOnlyPose::cam_project (G/types/types_six_dof_expmap.cpp:299-306: the inverse depth is a FLOAT, bf a double)
+inline void pose_edge_error(PEdge& ed, const double* Xc, const double* in, double bf) {
+    if (!ed.stereo) {
+        ed.err[0] = ed.u - (Xc[0] / Xc[2] * in[0] + in[2]);
+        ed.err[1] = ed.v - (Xc[1] / Xc[2] * in[1] + in[3]);
+        ed.err[2] = 0.0;
+        ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1];
+    } else {
+        const float invz = (float)(1.0 / Xc[2]);
+        const double r0 = Xc[0] * (double)invz * in[0] + in[2];
+        const double r1 = Xc[1] * (double)invz * in[1] + in[3];
+        const double r2 = r0 - bf * (double)invz;
+        ed.err[0] = ed.u - r0; ed.err[1] = ed.v - r1; ed.err[2] = ed.ur - r2;
+        ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1] + ed.err[2] * ed.w * ed.err[2];
+    }
+}
+
+double pose_errors(const Pose& T, const double* in, std::vector<PEdge>& E, double delta, double delta_s, double bf) {
     double total = 0;
-    const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float (G/core/robust_kernel_impl.h:84)
+    const double dsqr_m = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float (G/core/robust_kernel_impl.h:84)
+    const double dsqr_s = (double)(float)(delta_s * delta_s);
     for (size_t e = 0; e < E.size(); ++e) {
         PEdge& ed = E[e];
         if (!ed.active) continue;
         double Xc[3];
         quat_rot(T.q, ed.X, Xc);
         for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
-        ed.err[0] = ed.u - (Xc[0] / Xc[2] * in[0] + in[2]);
-        ed.err[1] = ed.v - (Xc[1] / Xc[2] * in[1] + in[3]);
-        ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1];
-        if (ed.robust && ed.chi2 > dsqr) total += 2 * sqrt(ed.chi2) * delta - dsqr;
+        pose_edge_error(ed, Xc, in, bf);
+        const double d = ed.stereo ? delta_s : delta, dsqr = ed.stereo ? dsqr_s : dsqr_m;
+        if (ed.robust && ed.chi2 > dsqr) total += 2 * sqrt(ed.chi2) * d - dsqr;
         else total += ed.chi2;
     }
     return total;
 }
 
-int pose_optimize_round(Pose& T, const double* in, std::vector<PEdge>& E, double delta, int iterations, double* lastChi) {
+int pose_optimize_round(Pose& T, const double* in, std::vector<PEdge>& E, double delta, double delta_s, double bf, int iterations, double* lastChi) {
     bool any = false;
     for (size_t e = 0; e < E.size(); ++e) any |= E[e].active;
     if (!any) return 0;
-    const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float (G/core/robust_kernel_impl.h:84)
+    const double dsqr_m = (double)(float)(delta * delta), dsqr_s = (double)(float)(delta_s * delta_s);
     double lambda = -1, ni = 2;
     int nBad = 0, done = 0;
     bool ok = true;
     for (int it = 0; it < iterations && ok; ++it) {
-        double currentChi = pose_errors(T, in, E, delta), tempChi = currentChi;
+        double currentChi = pose_errors(T, in, E, delta, delta_s, bf), tempChi = currentChi;
         const double iniChi = currentChi;
         double H[36], b[6];
         for (int i = 0; i < 36; ++i) H[i] = 0;
@@ -560,17 +578,28 @@ int pose_optimize_round(Pose& T, const double* in, std::vector<PEdge>& E, double
             quat_rot(T.q, ed.X, Xc);
             for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
             const double x = Xc[0], y = Xc[1], invz = 1.0 / Xc[2], invz_2 = invz * invz, fx = in[0], fy = in[1];
-            double J[12];
+            double J[18];
             J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
             J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
             J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy;
             J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+            if (ed.stereo) {   // EdgeStereoSE3ProjectXYZOnlyPose::linearizeOplus (G/types/types_six_dof_expmap.cpp:335-364)
+                J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2];
+                J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
+            } else {
+                for (int i = 12; i < 18; ++i) J[i] = 0;
+            }
+            const double d = ed.stereo ? delta_s : delta, dsqr = ed.stereo ? dsqr_s : dsqr_m;
             double rho1 = 1.0;
-            if (ed.robust && ed.chi2 > dsqr) rho1 = delta / sqrt(ed.chi2);
+            if (ed.robust && ed.chi2 > dsqr) rho1 = d / sqrt(ed.chi2);
             const double wO = rho1 * ed.w;
             for (int i = 0; i < 6; ++i) {
-                b[i] -= rho1 * (J[i] * ed.w * ed.err[0] + J[6 + i] * ed.w * ed.err[1]);
-                for (int j = 0; j < 6; ++j) H[6 * i + j] += (J[i] * J[j] + J[6 + i] * J[6 + j]) * wO;
+                if (ed.stereo) b[i] -= rho1 * (J[i] * ed.w * ed.err[0] + J[6 + i] * ed.w * ed.err[1] + J[12 + i] * ed.w * ed.err[2]);
+                else b[i] -= rho1 * (J[i] * ed.w * ed.err[0] + J[6 + i] * ed.w * ed.err[1]);
+                for (int j = 0; j < 6; ++j) {
+                    if (ed.stereo) H[6 * i + j] += (J[i] * J[j] + J[6 + i] * J[6 + j] + J[12 + i] * J[12 + j]) * wO;
+                    else H[6 * i + j] += (J[i] * J[j] + J[6 + i] * J[6 + j]) * wO;
+                }
             }
         }
         if (it == 0) {
@@ -586,7 +615,7 @@ int pose_optimize_round(Pose& T, const double* in, std::vector<PEdge>& E, double
             for (int i = 0; i < 36; ++i) A[i] = H[i] + (i % 7 == 0 ? lambda : 0.0);
             bool ok2 = ldlt_solve(A, 6, x);
             if (ok2) pose_oplus(T, x.data()); else x.assign(6, 0.0);
-            tempChi = pose_errors(T, in, E, delta);
+            tempChi = pose_errors(T, in, E, delta, delta_s, bf);
             if (!ok2) tempChi = DBL_MAX;
             rho = currentChi - tempChi;
             double scale = 0;
@@ -624,19 +653,22 @@ extern "C" int pose_oracle_solve(const slamit_pose_problem* pb, slamit_pose_resu
         res->n_inliers = 0;
         return 0;
     }
-    const double delta = (double)(float)sqrt(5.991);
+    const double delta = (double)(float)sqrt(5.991), delta_s = (double)(float)sqrt(7.815);   // deltaMono, deltaStereo (S/Optimizer.cc:264-265)
+    const double bf = pb->ur ? pb->bf : 0.0;
     std::vector<PEdge> E(n);
     for (int e = 0; e < n; ++e) {
         for (int i = 0; i < 3; ++i) E[e].X[i] = pb->xw[3 * e + i];
         E[e].u = pb->uv[2 * e]; E[e].v = pb->uv[2 * e + 1]; E[e].w = pb->inv_sigma2[e];
-        E[e].active = true; E[e].robust = true; E[e].err[0] = E[e].err[1] = 0; E[e].chi2 = 0;
+        E[e].stereo = pb->ur && !(pb->ur[e] < 0);   // S/Optimizer.cc:281: mvuRight < 0 is a monocular observation
+        E[e].ur = E[e].stereo ? pb->ur[e] : -1.0;
+        E[e].active = true; E[e].robust = true; E[e].err[0] = E[e].err[1] = E[e].err[2] = 0; E[e].chi2 = 0;
         res->outlier[e] = 0;
     }
     Pose T = T0;
     int nBad = 0;
     for (int round = 0; round < 4; ++round) {
         T = T0;  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)) at the top of every round
-        res->n_its[round] = pose_optimize_round(T, pb->intr, E, delta, 10, &res->chi2[round]);
+        res->n_its[round] = pose_optimize_round(T, pb->intr, E, delta, delta_s, bf, 10, &res->chi2[round]);
         nBad = 0;
         for (int e = 0; e < n; ++e) {
             PEdge& ed = E[e];
@@ -644,12 +676,10 @@ extern "C" int pose_oracle_solve(const slamit_pose_problem* pb, slamit_pose_resu
                 double Xc[3];
                 quat_rot(T.q, ed.X, Xc);
                 for (int i = 0; i < 3; ++i) Xc[i] += T.t[i];
-                ed.err[0] = ed.u - (Xc[0] / Xc[2] * pb->intr[0] + pb->intr[2]);
-                ed.err[1] = ed.v - (Xc[1] / Xc[2] * pb->intr[1] + pb->intr[3]);
-                ed.chi2 = ed.err[0] * ed.w * ed.err[0] + ed.err[1] * ed.w * ed.err[1];
+                pose_edge_error(ed, Xc, pb->intr, bf);
             }
             const float chi2 = (float)ed.chi2;
-            if (chi2 > 5.991f) { res->outlier[e] = 1; ed.active = false; ++nBad; }
+            if (chi2 > (ed.stereo ? 7.815f : 5.991f)) { res->outlier[e] = 1; ed.active = false; ++nBad; }   // chi2Mono / chi2Stereo (:369-370)
             else { res->outlier[e] = 0; ed.active = true; }
             if (round == 2) ed.robust = false;
         }

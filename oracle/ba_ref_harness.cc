@@ -210,11 +210,35 @@ extern "C" int pose_ref_solve(const slamit_pose_problem* pb, slamit_pose_result*
     optimizer.addVertex(vSE3);
     for (int r = 0; r < 4; ++r) { res->n_its[r] = 0; res->chi2[r] = 0; }
     std::vector<g2o::EdgeSE3ProjectXYZOnlyPose*> edges;
+    std::vector<g2o::EdgeStereoSE3ProjectXYZOnlyPose*> sedges;   // S/Optimizer.cc:319-356
+    std::vector<int> index, sindex;                               // vnIndexEdgeMono / vnIndexEdgeStereo
     const float deltaMono = sqrt(5.991);
+    const float deltaStereo = sqrt(7.815);
     int nInitialCorrespondences = 0;
     for (int i = 0; i < N; ++i) {
         nInitialCorrespondences++;
         res->outlier[i] = 0;
+        if (pb->ur && !(pb->ur[i] < 0)) {
+            Eigen::Matrix<double, 3, 1> obs;
+            const float kp_ur = (float)pb->ur[i];
+            obs << pb->uv[2 * i], pb->uv[2 * i + 1], kp_ur;
+            g2o::EdgeStereoSE3ProjectXYZOnlyPose* e = new g2o::EdgeStereoSE3ProjectXYZOnlyPose();
+            e->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(0)));
+            e->setMeasurement(obs);
+            Eigen::Matrix3d Info = Eigen::Matrix3d::Identity() * pb->inv_sigma2[i];
+            e->setInformation(Info);
+            g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber;
+            e->setRobustKernel(rk);
+            rk->setDelta(deltaStereo);
+            e->fx = pb->intr[0]; e->fy = pb->intr[1]; e->cx = pb->intr[2]; e->cy = pb->intr[3];
+            e->bf = pb->bf;
+            e->Xw[0] = pb->xw[3 * i]; e->Xw[1] = pb->xw[3 * i + 1]; e->Xw[2] = pb->xw[3 * i + 2];
+            optimizer.addEdge(e);
+            sedges.push_back(e);
+            sindex.push_back(i);
+            continue;
+        }
+        index.push_back(i);
         Eigen::Matrix<double, 2, 1> obs;
         obs << pb->uv[2 * i], pb->uv[2 * i + 1];
         g2o::EdgeSE3ProjectXYZOnlyPose* e = new g2o::EdgeSE3ProjectXYZOnlyPose();
@@ -235,6 +259,7 @@ extern "C" int pose_ref_solve(const slamit_pose_problem* pb, slamit_pose_result*
         return 0;
     }
     const float chi2Mono[4] = {5.991, 5.991, 5.991, 5.991};
+    const float chi2Stereo[4] = {7.815, 7.815, 7.815, 7.815};
     const int its[4] = {10, 10, 10, 10};
     int nBad = 0;
     for (size_t it = 0; it < 4; it++) {
@@ -246,10 +271,20 @@ extern "C" int pose_ref_solve(const slamit_pose_problem* pb, slamit_pose_result*
         nBad = 0;
         for (size_t i = 0; i < edges.size(); i++) {
             g2o::EdgeSE3ProjectXYZOnlyPose* e = edges[i];
-            if (res->outlier[i]) e->computeError();
+            const int idx = index[i];
+            if (res->outlier[idx]) e->computeError();
             const float chi2 = e->chi2();
-            if (chi2 > chi2Mono[it]) { res->outlier[i] = 1; e->setLevel(1); nBad++; }
-            else { res->outlier[i] = 0; e->setLevel(0); }
+            if (chi2 > chi2Mono[it]) { res->outlier[idx] = 1; e->setLevel(1); nBad++; }
+            else { res->outlier[idx] = 0; e->setLevel(0); }
+            if (it == 2) e->setRobustKernel(0);
+        }
+        for (size_t i = 0; i < sedges.size(); i++) {
+            g2o::EdgeStereoSE3ProjectXYZOnlyPose* e = sedges[i];
+            const int idx = sindex[i];
+            if (res->outlier[idx]) e->computeError();
+            const float chi2 = e->chi2();
+            if (chi2 > chi2Stereo[it]) { res->outlier[idx] = 1; e->setLevel(1); nBad++; }
+            else { e->setLevel(0); res->outlier[idx] = 0; }
             if (it == 2) e->setRobustKernel(0);
         }
         if (optimizer.edges().size() < 10) break;

@@ -462,7 +462,7 @@ def ba_ref_solve(prob, its_robust=5, its_final=10, huber_delta=HUBER_MONO, chi2_
 # ---------------------------------------------------------------------------------------------
 class _PoseProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("pose", C.c_void_p), ("intr", C.c_void_p), ("xw", C.c_void_p),
-                ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p)]
+                ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p), ("ur", C.c_void_p), ("bf", C.c_double)]   # stereo: right-image columns (< 0: monocular) and Frame::mbf
 
 
 class _PoseResult(C.Structure):
@@ -481,7 +481,10 @@ def _pose_call(which, prob):
         _ba[("pose", which)] = fn
     keep = {k: np.ascontiguousarray(prob[k], np.float64) for k in ("pose", "intr", "xw", "uv", "inv_sigma2")}
     n = len(keep["inv_sigma2"])
-    p = _PoseProblem(n, *[keep[k].ctypes.data for k in ("pose", "intr", "xw", "uv", "inv_sigma2")])
+    if prob.get("ur") is not None:
+        keep["ur"] = np.ascontiguousarray(prob["ur"], np.float64)
+    p = _PoseProblem(n, *[keep[k].ctypes.data for k in ("pose", "intr", "xw", "uv", "inv_sigma2")],
+                     keep["ur"].ctypes.data if "ur" in keep else None, float(prob.get("bf", 0.0)))
     pose = np.zeros(12)
     outl = np.zeros(max(n, 1), np.uint8)
     r = _PoseResult(pose.ctypes.data, outl.ctypes.data, 0)

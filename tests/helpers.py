@@ -41,6 +41,9 @@ def load_ba_golden(path):
 def load_pose_golden(path):
     z = np.load(path)
     prob = {k: z[k].astype(np.float64) for k in ("pose", "intr", "xw", "uv", "inv_sigma2")}
+    if "ur" in z.files:   # a frame with stereo keypoints
+        prob["ur"] = z["ur"].astype(np.float64)
+        prob["bf"] = float(z["bf"])
     ref = {"pose": z["ref_pose"], "outlier": z["ref_outlier"], "n_inliers": int(z["ref_n_inliers"]),
            "n_its": [int(v) for v in z["ref_n_its"]], "chi2": [float(v) for v in z["ref_chi2"]]}
     return prob, ref

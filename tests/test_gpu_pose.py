@@ -41,6 +41,17 @@ def test_batch_of_frames_vs_oracle():
         _close(o, ob.pose_solve(p), "batch[%d]" % i, strict=False)
 
 
+def test_batch_mixes_monocular_and_stereo_frames_vs_oracle():
+    """Frames of a stereo / RGB-D session beside monocular ones in one launch: EdgeStereoSE3ProjectXYZOnlyPose edges (three rows,
+    float inverse depth, Huber width sqrt(7.815), gate 7.815f) on the keypoints that have a right-image column."""
+    probs = [synth.synth_pose(200 + 100 * i, 0.1 + 0.04 * i, 80 + i, 0.02 + 0.01 * i, stereo_frac=(0.0, 1.0, 0.5, 0.8, 0.0, 0.3)[i]) for i in range(6)]
+    outs = api.Optimizer.PoseOptimization(probs)
+    for i, (p, o) in enumerate(zip(probs, outs)):
+        _close(o, ob.pose_solve(p), "mixed[%d]" % i, strict=False)
+    with pytest.raises(api.SlamitError):
+        api.Optimizer.PoseOptimization(dict(probs[1], ur=probs[1]["ur"][:-1]))
+
+
 def test_full_size_batch_64_frames():
     """64 frames x 1000 correspondences in one launch; every frame equals its single-frame result."""
     probs = [synth.synth_pose(1000, 0.25, 100 + (i % 4), 0.04) for i in range(64)]

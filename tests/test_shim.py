@@ -132,12 +132,17 @@ def test_shim_optimizer_local_ba(tmp_path, name):
 
 
 @pytest.mark.gpu
-def test_shim_optimizer_pose_optimization(tmp_path):
+@pytest.mark.parametrize("name", ["typical", "stereo_mixed"])
+def test_shim_optimizer_pose_optimization(tmp_path, name):
+    """Tracking's Optimizer::PoseOptimization(&mCurrentFrame) against a mock Frame; "stereo_mixed": half of the keypoints carry
+    mvuRight >= 0 and the frame an mbf (EdgeStereoSE3ProjectXYZOnlyPose edges, Optimizer.cc:319-356), reference-g2o golden."""
     _build()
-    prob, ref = load_pose_golden(os.path.join(ROOT, "tests", "golden", "pose_typical.npz"))
+    prob, ref = load_pose_golden(os.path.join(ROOT, "tests", "golden", "pose_%s.npz" % name))
     n = len(prob["inv_sigma2"])
     blob = struct.pack("<i", n) + prob["pose"].astype(np.float32).tobytes() + prob["intr"].astype(np.float32).tobytes()
     blob += prob["xw"].astype(np.float32).tobytes() + prob["uv"].astype(np.float32).tobytes() + prob["inv_sigma2"].astype(np.float32).tobytes()
+    if "ur" in prob:
+        blob += struct.pack("<f", prob["bf"]) + prob["ur"].astype(np.float32).tobytes()
     pin, pout = tmp_path / "p.bin", tmp_path / "o.bin"
     open(pin, "wb").write(blob)
     subprocess.check_call([EXE, "pose", str(pin), str(pout)])

@@ -18,17 +18,28 @@ CASES = {  # name: (n, outlier fraction, seed, initial pose perturbation)
     "under10": (8, 0.0, 10, 0.01),      # < 10 edges: one round only (Optimizer.cc:442-443)
     "under3": (2, 0.0, 11, 0.01),       # < 3 correspondences: returns 0, pose untouched (:364-365)
     "hard": (600, 0.50, 12, 0.10),
+    # frames of a stereo / RGB-D session (EdgeStereoSE3ProjectXYZOnlyPose, Optimizer.cc:319-356): a 5th field = the fraction
+    # of keypoints with a right-image column
+    "stereo_all": (400, 0.15, 21, 0.02, 1.0),
+    "stereo_mixed": (500, 0.25, 22, 0.05, 0.5),
+    "stereo_few": (40, 0.10, 23, 0.02, 0.7),
+    "stereo_under10": (9, 0.0, 24, 0.01, 0.6),
 }
 
 
 def main():
     assert ob.ba_ref_available()
-    for name, (n, of, seed, pert) in CASES.items():
-        pr = synth.synth_pose(n, of, seed, pert)
+    only = sys.argv[1:]   # optional: the case names to (re)generate; default all
+    for name, case in CASES.items():
+        if only and not any(name.startswith(o) for o in only):
+            continue
+        n, of, seed, pert = case[:4]
+        pr = synth.synth_pose(n, of, seed, pert, stereo_frac=case[4] if len(case) > 4 else 0.0)
         r = ob.pose_ref_solve(pr)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pose_%s.npz" % name),
                             pose=pr["pose"].astype(np.float32), intr=pr["intr"].astype(np.float32), xw=pr["xw"].astype(np.float32),
                             uv=pr["uv"].astype(np.float32), inv_sigma2=pr["inv_sigma2"].astype(np.float32),
+                            **({"ur": pr["ur"].astype(np.float32), "bf": np.float32(pr["bf"])} if "ur" in pr else {}),
                             ref_pose=r["pose"], ref_outlier=r["outlier"], ref_n_inliers=r["n_inliers"],
                             ref_n_its=np.array(r["n_its"]), ref_chi2=np.array(r["chi2"]))
         print(name, n, "inliers", r["n_inliers"], "its", r["n_its"])

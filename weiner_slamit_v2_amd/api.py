@@ -124,7 +124,7 @@ BA_PHASES = ("linearize", "schur", "solve", "update", "residuals")   # slamit_ba
 
 class PoseProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("pose", C.c_void_p), ("intr", C.c_void_p), ("xw", C.c_void_p),
-                ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p)]
+                ("uv", C.c_void_p), ("inv_sigma2", C.c_void_p), ("ur", C.c_void_p), ("bf", C.c_double)]   # stereo: right-image columns (< 0: monocular) and Frame::mbf
 
 
 class PoseResult(C.Structure):
@@ -701,7 +701,12 @@ class Optimizer:
         for i, pr in enumerate(plist):
             k = {key: np.ascontiguousarray(pr[key], np.float64) for key in ("pose", "intr", "xw", "uv", "inv_sigma2")}
             m = len(k["inv_sigma2"])
-            P[i] = PoseProblem(m, *[k[key].ctypes.data for key in ("pose", "intr", "xw", "uv", "inv_sigma2")])
+            if pr.get("ur") is not None:
+                k["ur"] = np.ascontiguousarray(pr["ur"], np.float64)
+                if len(k["ur"]) != m:
+                    raise SlamitError("ur does not match the correspondences")
+            P[i] = PoseProblem(m, *[k[key].ctypes.data for key in ("pose", "intr", "xw", "uv", "inv_sigma2")],
+                               k["ur"].ctypes.data if "ur" in k else None, float(pr.get("bf", 0.0)))
             o = {"pose": np.zeros(12), "outlier": np.zeros(max(m, 1), np.uint8)}
             R[i] = PoseResult(o["pose"].ctypes.data, o["outlier"].ctypes.data, 0)
             keep.append(k)

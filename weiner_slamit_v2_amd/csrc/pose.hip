@@ -2,7 +2,8 @@
 //
 // Reference: ORB_SLAM2/src/Optimizer.cc:239-451 driving g2o (BlockSolver_6_3 + LinearSolverDense +
 // Levenberg) over EdgeSE3ProjectXYZOnlyPose edges (Thirdparty/g2o/g2o/types/types_six_dof_expmap.{h:143-170,
-// cpp:266-288}).  The system is a single 6x6 block, so the whole schedule — 4 rounds x <= 10 LM
+// cpp:266-288}) and, for the keypoints of a stereo / RGB-D frame that have a right-image column, EdgeStereoSE3ProjectXYZOnlyPose
+// edges ({h:174-202, cpp:299-306, 335-364}; Optimizer.cc:319-356: three residual rows, Huber width sqrt(7.815), gate 7.815f).  The system is a single 6x6 block, so the whole schedule — 4 rounds x <= 10 LM
 // iterations x <= 10 trials, the (float)chi2 > 5.991f relabelling between rounds, the kernel drop after
 // the third round — runs inside ONE workgroup per frame with no host round trip; a batch of frames is
 // one launch.  Reductions are fixed-order (lane-strided partial sums, shuffle tree, 4 waves in order).
@@ -31,6 +32,8 @@ struct PoseFrame {
     int32_t* n_inliers;      // 1
     int32_t* n_its;          // 4
     double* chi2_round;      // 4
+    const double* ur;        // n: right-image column, < 0 on a monocular correspondence; null when the frame has none (Optimizer.cc:281)
+    double bf;               // Frame::mbf
 };
 // The same record as the kernel sees it: pointers in the global address space.  (Read out of a struct in memory a plain
 // pointer is generic, and every access through it a flat_load; host code that fills PoseFrame is parsed in the device
@@ -49,6 +52,8 @@ struct PoseFrameG {
     __attribute__((address_space(1))) int32_t* n_inliers;      // 1
     __attribute__((address_space(1))) int32_t* n_its;          // 4
     __attribute__((address_space(1))) double* chi2_round;      // 4
+    const __attribute__((address_space(1))) double* ur;        // n or null
+    double bf;
 };
 static_assert(sizeof(PoseFrameG) == sizeof(PoseFrame), "PoseFrameG mirrors PoseFrame");
 #else
@@ -65,9 +70,26 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {  // 256 thre
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+#define POSE_DELTA_STEREO ((double)(float)sqrt(7.815))   // deltaStereo, Optimizer.cc:265
+
+__device__ __forceinline__ bool pose_is_stereo(const PoseFrameG& F, int e) { return F.ur && !(F.ur[e] < 0.0); }
+
+// error of a stereo edge at camera-frame point Xc: EdgeStereoSE3ProjectXYZOnlyPose::cam_project (types_six_dof_expmap.cpp:299-306),
+// `const float invz = 1.0f / z` (the quotient rounded to float), bf a double member.  Returns chi2.
+__device__ __forceinline__ double pose_stereo_error(const PoseFrameG& F, int e, const double* Xc, double* err /*[3]*/) {
+    const float invz = (float)(1.0 / Xc[2]);
+    const double r0 = Xc[0] * (double)invz * F.intr[0] + F.intr[2];
+    const double r1 = Xc[1] * (double)invz * F.intr[1] + F.intr[3];
+    const double r2 = r0 - F.bf * (double)invz;
+    err[0] = F.uv[2 * e] - r0; err[1] = F.uv[2 * e + 1] - r1; err[2] = F.ur[e] - r2;
+    const double w = F.w[e];
+    return err[0] * w * err[0] + err[1] * w * err[1] + err[2] * w * err[2];
+}
+
 // residual + chi2 of every active edge at pose T; returns the robust cost
 __device__ double pose_errors(const PoseFrameG& F, const double* T, const uint8_t* active, int robust, double delta, double* sh) {
     const double dsqr = (double)(float)(delta * delta);   // RobustKernelHuber::dsqr is a float member (g2o/core/robust_kernel_impl.h:84)
+    const double delta_s = POSE_DELTA_STEREO, dsqr_s = (double)(float)(delta_s * delta_s);
     const double fx = F.intr[0], fy = F.intr[1], cx = F.intr[2], cy = F.intr[3];
     double part = 0;
     for (int e = threadIdx.x; e < F.n; e += 256) {
@@ -75,6 +97,13 @@ __device__ double pose_errors(const PoseFrameG& F, const double* T, const uint8_
         double Xc[3];
         quat_rot(T, F.xw + 3 * e, Xc);
         Xc[0] += T[4]; Xc[1] += T[5]; Xc[2] += T[6];
+        if (pose_is_stereo(F, e)) {
+            double err[3];
+            const double c2 = pose_stereo_error(F, e, Xc, err);
+            F.chi2[e] = c2;
+            part += (robust && c2 > dsqr_s) ? 2 * sqrt(c2) * delta_s - dsqr_s : c2;
+            continue;
+        }
         const double e0 = F.uv[2 * e] - (Xc[0] / Xc[2] * fx + cx), e1 = F.uv[2 * e + 1] - (Xc[1] / Xc[2] * fy + cy);
         const double w = F.w[e];
         const double c2 = e0 * w * e0 + e1 * w * e1;
@@ -117,6 +146,7 @@ __global__ __launch_bounds__(256) void pose_opt_kernel(const PoseFrame* frames) 
     extern __shared__ uint8_t s_act[];  // n bytes: edge is at level 0
     if (n < 3) {  // Optimizer.cc:364-365
         if (tid < 12) F.pose_out[tid] = F.pose_in[tid];
+        if (tid < n) F.outlier[tid] = 0;
         if (tid == 0) { *F.n_inliers = 0; for (int r = 0; r < 4; ++r) { F.n_its[r] = 0; F.chi2_round[r] = 0; } }
         return;
     }
@@ -168,6 +198,22 @@ __global__ __launch_bounds__(256) void pose_opt_kernel(const PoseFrame* frames) 
                     J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy;
                     J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
                     const double w = F.w[e], c2 = F.chi2[e];
+                    if (pose_is_stereo(F, e)) {   // third row: EdgeStereoSE3ProjectXYZOnlyPose::linearizeOplus (types_six_dof_expmap.cpp:335-364)
+                        const double bf = F.bf, delta_s = POSE_DELTA_STEREO, dsqr_s = (double)(float)(delta_s * delta_s);
+                        const double J2[6] = {J[0] - bf * y * invz_2, J[1] + bf * x * invz_2, J[2], J[3], 0.0, J[5] - bf * invz_2};
+                        double err[3];
+                        pose_stereo_error(F, e, Xc, err);
+                        const double rho1s = (robust && c2 > dsqr_s) ? delta_s / sqrt(c2) : 1.0;
+                        const double wOs = rho1s * w;
+                        int k = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) {
+                            bb[a] -= rho1s * (J[a] * w * err[0] + J[6 + a] * w * err[1] + J2[a] * w * err[2]);
+#pragma unroll
+                            for (int c = a; c < 6; ++c) h[k++] += (J[a] * J[c] + J[6 + a] * J[6 + c] + J2[a] * J2[c]) * wOs;
+                        }
+                        continue;
+                    }
                     const double e0 = F.uv[2 * e] - (x * invz * fx + F.intr[2]), e1 = F.uv[2 * e + 1] - (y * invz * fy + F.intr[3]);
                     const double rho1 = (robust && c2 > dsqr) ? delta / sqrt(c2) : 1.0;
                     const double wO = rho1 * w;
@@ -247,12 +293,17 @@ __global__ __launch_bounds__(256) void pose_opt_kernel(const PoseFrame* frames) 
                 double Xc[3];
                 quat_rot(sT, F.xw + 3 * e, Xc);
                 Xc[0] += sT[4]; Xc[1] += sT[5]; Xc[2] += sT[6];
+                if (pose_is_stereo(F, e)) {
+                    double err[3];
+                    c2 = pose_stereo_error(F, e, Xc, err);
+                } else {
                 const double e0 = F.uv[2 * e] - (Xc[0] / Xc[2] * fx + cx), e1 = F.uv[2 * e + 1] - (Xc[1] / Xc[2] * fy + cy);
                 const double w = F.w[e];
                 c2 = e0 * w * e0 + e1 * w * e1;
+                }
                 F.chi2[e] = c2;
             }
-            const bool out = (float)c2 > 5.991f;
+            const bool out = (float)c2 > (pose_is_stereo(F, e) ? 7.815f : 5.991f);   // chi2Mono / chi2Stereo, Optimizer.cc:369-370
             F.outlier[e] = out;
             s_act[e] = !out;
             bad += out;
@@ -291,8 +342,8 @@ int slamit_pose_optimize_batch(int device, int nframes, const slamit_pose_proble
         if (P.n < 0 || !P.pose || !P.intr || (P.n && (!P.xw || !P.uv || !P.inv_sigma2)) || !results[f].pose || (P.n && !results[f].outlier))
             return slamit_fail(SLAMIT_ERR_ARG, "slamit_pose_optimize_batch: null array");
         off[f] = total; foff[f] = flag_total;
-        // per frame: pose 12 | intr 4 | xw 3n | uv 2n | w n | chi2 n | pose_out 12 | chi2_round 4   (doubles)
-        total += 32 + (size_t)7 * P.n;
+        // per frame: pose 12 | intr 4 | xw 3n | uv 2n | w n | chi2 n | pose_out 12 | chi2_round 4 [| ur n]   (doubles)
+        total += 32 + (size_t)(P.ur ? 8 : 7) * P.n;
         flag_total += ((size_t)P.n + 15) & ~(size_t)7;
         nmax = std::max(nmax, (int)P.n);
     }
@@ -316,6 +367,8 @@ int slamit_pose_optimize_batch(int device, int nframes, const slamit_pose_proble
         PoseFrame& F = fr[f];
         F.n = P.n; F.pose_in = d; F.intr = d + 12; F.xw = d + 16; F.uv = d + 16 + 3 * n; F.w = d + 16 + 5 * n;
         F.chi2 = d + 16 + 6 * n; F.pose_out = d + 16 + 7 * n; F.chi2_round = d + 28 + 7 * n;
+        F.ur = nullptr; F.bf = 0.0;
+        if (P.ur && n) { memcpy(h + 32 + 7 * n, P.ur, 8 * n); F.ur = d + 32 + 7 * n; F.bf = P.bf; }
         F.outlier = d_flags + foff[f];
         F.n_inliers = d_ints + 5 * f; F.n_its = d_ints + 5 * f + 1;
     }

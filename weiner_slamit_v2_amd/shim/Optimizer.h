@@ -47,7 +47,7 @@ public:
 
     // Optimizer::PoseOptimization(Frame*) (Optimizer.cc:239-451) on whatever Frame type the caller has:
     // members used: N, mTcw, mvpMapPoints (elements with GetWorldPos()), mvuRight, mvbOutlier, mvKeysUn,
-    // mvInvLevelSigma2, fx, fy, cx, cy, SetPose().  Returns the number of inliers like the reference.
+    // mvInvLevelSigma2, fx, fy, cx, cy, mbf (only when a keypoint has mvuRight >= 0: its stereo edge), SetPose().  Returns the number of inliers like the reference.
     // (The reference holds MapPoint::mGlobalMutex while reading the points; the caller's Frame type is
     //  expected to do the same inside GetWorldPos or around this call.)
     template <class FrameT>
@@ -278,11 +278,14 @@ int Optimizer::OptimizeSim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPoi
 template <class FrameT>
 int Optimizer::PoseOptimization(FrameT* pFrame) {
     const int N = pFrame->N;
-    std::vector<double> xw, uv, isg;
+    std::vector<double> xw, uv, isg, ur;
     std::vector<int> index;
+    bool hasStereo = false;
     for (int i = 0; i < N; ++i) {
         if (!pFrame->mvpMapPoints[i]) continue;
-        if (pFrame->mvuRight[i] >= 0) { lastStatus() = SLAMIT_ERR_ARG; return 0; }  // stereo edges: not on the HIP path yet
+        const float kp_ur = pFrame->mvuRight[i];            // < 0: monocular observation (:281), else the stereo edge of :319-356
+        ur.push_back(kp_ur < 0 ? -1.0 : (double)kp_ur);
+        hasStereo = hasStereo || !(kp_ur < 0);
         pFrame->mvbOutlier[i] = false;
         const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
         cv::Mat Xw = pFrame->mvpMapPoints[i]->GetWorldPos();
@@ -300,6 +303,8 @@ int Optimizer::PoseOptimization(FrameT* pFrame) {
     std::vector<uint8_t> outlier(index.size());
     slamit_pose_problem P;
     P.n = (int32_t)index.size(); P.pose = pose; P.intr = intr; P.xw = xw.data(); P.uv = uv.data(); P.inv_sigma2 = isg.data();
+    P.ur = hasStereo ? ur.data() : 0;
+    P.bf = hasStereo ? (double)pFrame->mbf : 0.0;          // e->bf = pFrame->mbf, :346 (read only when a keypoint has a right-image column)
     slamit_pose_result R;
     R.pose = out; R.outlier = outlier.data();
     if ((lastStatus() = slamit_pose_optimize(deviceRef(), &P, &R)) != SLAMIT_OK) return 0;

@@ -224,11 +224,11 @@ static int run_ba(int argc, char** argv) {
     return 0;
 }
 
-// pose.bin: int32 n | float pose[12] | float intr[4] | float xw[3n] | float uv[2n] | float invsig[n]
+// pose.bin: int32 n | float pose[12] | float intr[4] | float xw[3n] | float uv[2n] | float invsig[n] [ | float bf | float ur[n] ]
 struct MockFrame {
     int N;
     cv::Mat mTcw;
-    float fx, fy, cx, cy;
+    float fx, fy, cx, cy, mbf;
     std::vector<MockMapPoint*> mvpMapPoints;
     std::vector<float> mvuRight, mvInvLevelSigma2;
     std::vector<bool> mvbOutlier;
@@ -246,8 +246,12 @@ static int run_pose(int argc, char** argv) {
     const float* intr = (const float*)p; p += 16;
     const float* xw = (const float*)p; p += 12 * n;
     const float* uv = (const float*)p; p += 8 * n;
-    const float* isg = (const float*)p;
+    const float* isg = (const float*)p; p += 4 * n;
+    // optional tail: float bf | float ur[n]  (a frame with stereo keypoints: Frame::mbf, mvuRight)
+    const bool stereo = (size_t)(p - raw.data()) + 4 + 4 * (size_t)n <= raw.size();
+    const float* ur = stereo ? (const float*)(p + 4) : 0;
     MockFrame F;
+    F.mbf = stereo ? *(const float*)p : 0.f;
     std::vector<MockMapPoint> mps(n);
     F.N = n + 5;  // a few keypoints without a map point, like a real frame
     F.mTcw = cv::Mat(4, 4, CV_32F);
@@ -260,6 +264,7 @@ static int run_pose(int argc, char** argv) {
         mps[i].pos = cv::Mat(3, 1, CV_32F);
         for (int r = 0; r < 3; ++r) mps[i].pos.at<float>(r, 0) = xw[3 * i + r];
         F.mvpMapPoints[i] = &mps[i];
+        if (ur) F.mvuRight[i] = ur[i];
         F.mvKeysUn[i] = cv::KeyPoint(uv[2 * i], uv[2 * i + 1], 31.f);
         F.mvKeysUn[i].octave = (int)F.mvInvLevelSigma2.size();
         F.mvInvLevelSigma2.push_back(isg[i]);

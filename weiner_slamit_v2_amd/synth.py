@@ -214,7 +214,7 @@ def synth_ba(n_kf=50, n_pt=2000, obs_per_pt=8, outlier_frac=0.03, seed=12345, n_
     }
 
 
-def synth_pose(n=400, outlier_frac=0.15, seed=7, perturb=0.02):
+def synth_pose(n=400, outlier_frac=0.15, seed=7, perturb=0.02, stereo_frac=0.0, baseline=0.08):
     """One PoseOptimization problem (Optimizer.cc:239-451): n map points seen by one frame, pixel
     noise N(0,1), a fraction of gross outliers, initial pose = truth perturbed by exp(N(0, perturb^2)).
     All inputs float32-rounded then widened, as the reference feeds them."""
@@ -233,7 +233,16 @@ def synth_pose(n=400, outlier_frac=0.15, seed=7, perturb=0.02):
     dR, dt = se3_exp(rs.normal(0, perturb, 6))
     pose = np.concatenate([(dR @ R).reshape(-1), dR @ t + dt])
     f32 = lambda a: np.ascontiguousarray(np.asarray(a, np.float32).astype(np.float64))
-    return {"pose": f32(pose), "intr": f32([fx, fy, cx, cy]), "xw": f32(xw), "uv": f32(np.stack([u, v], 1)),
+    extra = {}
+    if stereo_frac > 0:   # a stereo / RGB-D frame: that fraction of the keypoints has a right-image column (own random stream)
+        rs2 = np.random.RandomState(seed + 777)
+        bf = float(np.float32(baseline * fx))
+        ur = u - bf / pts_c[:, 2] + rs2.normal(0, 1, n)
+        bad_r = rs2.uniform(size=n) < outlier_frac
+        ur[bad_r] += rs2.choice([-1, 1], bad_r.sum()) * rs2.uniform(8, 40, bad_r.sum())
+        ur = np.where(rs2.uniform(size=n) < stereo_frac, ur, -1.0)
+        extra = {"ur": f32(ur), "bf": bf}
+    return {**extra, "pose": f32(pose), "intr": f32([fx, fy, cx, cy]), "xw": f32(xw), "uv": f32(np.stack([u, v], 1)),
             "inv_sigma2": f32(inv_sig), "truth_pose": np.concatenate([R.reshape(-1), t]), "truth_outlier": bad}
 
 
