@@ -93,8 +93,8 @@ def measured_valu(batch, fast_avg_ms, pixels_per_frame):
         rel = os.path.relpath(files[-1], ROOT)
         if doc.get("kernel_src_sha16") != sha:
             return {"lane_ops_per_px": None, "source": "%s was taken on another version of csrc/orb_kernels.hip (%s, now %s)" % (rel, doc.get("kernel_src_sha16"), sha)}
-        k = doc["vga"]
-        valu_per_frame = k["SQ_INSTS_VALU_per_launch"] / k["frames_per_launch"]
+        k = doc["geometries"]["vga"]
+        valu_per_frame = k["counters_per_launch"]["SQ_INSTS_VALU"] / k["frames_per_launch"]
         lane_ops_px = 64.0 * valu_per_frame / pixels_per_frame
         achieved = 64.0 * valu_per_frame * batch / (fast_avg_ms * 1e-3) / 1e12 if fast_avg_ms > 0 else 0.0
         out = {"lane_ops_per_px": round(lane_ops_px, 2), "valu_wave_instructions_per_frame": round(valu_per_frame),

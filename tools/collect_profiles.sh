@@ -5,7 +5,7 @@
 # behind `--`.  Raw output lands in gpurun_out/prof_<tag>/; tools/summarize_profiles.py <tag> turns it into profiles/<tag>_*.
 set -e
 export PYTHONPATH=$PWD TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 B="python3 bench.py --no-ba --no-cpu --no-extras"

@@ -102,6 +102,39 @@ def copy_bench(src, name, dst):
     return True
 
 
+# Vector instructions per wave (= per FAST cell) that THIS formulation of exact FAST cannot go below, phase by phase, next to what
+# the shipped kernel issues (static counts of the phases' basic blocks in the gfx950 ISA x the trip counts of the bench content:
+# DESIGN.md section 5 has the table).  The sum, per pyramid pixel and lane, is what bench.py reports as floor_lane_ops_per_px.
+FAST_BUDGET = [
+    # phase, issued now, floor, why the floor
+    ("stage the window (LDS-DMA) + zero the score tile + cell set-up", 74, 30, "one address per 16-byte chunk and the cell's constants"),
+    ("pre-test, 4 pixels per lane and step (4.2 steps per cell)", 4.2 * 27, 4.2 * 21, "2 v_alignbyte + v_not + 4 difference lerps + 8 threshold lerps + 4 combines + 2 mask merges"),
+    ("survivor append: count, wave prefix sum, 4 slot stores (4.2 steps)", 4.2 * 38, 4.2 * 16, "popcount 3 + DPP scan 7 + address 2 + one add per slot"),
+    ("exact score, 2 entries per lane (262 entries per cell: 2.55 passes issued, 2.05 without the half-empty last pass)", 2.55 * 112, 2.05 * 82, "34 half-word packs + 40 v_pk_min3 / max3 + 8 for score, compare and store"),
+    ("non-maximum suppression over the listed corners (118 per cell)", 37, 20, "8 neighbour reads and a 3-level max per corner, two 64-lane rounds"),
+    ("candidate output (25 per cell)", 32, 20, "decode, score fetch, one 8-byte store per candidate"),
+]
+
+
+def fast_floor(vga):
+    c = vga["counters_per_launch"]
+    per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    issued = sum(b[1] for b in FAST_BUDGET)
+    floor = sum(b[2] for b in FAST_BUDGET)
+    lane_ops_now = 64.0 * c["SQ_INSTS_VALU"] / vga["pyramid_pixels_per_launch"]
+    return {
+        "lane_ops_per_px": round(lane_ops_now * floor / per_wave, 1),
+        "valu_per_cell_measured": round(per_wave, 1), "valu_per_cell_accounted": round(issued, 1), "valu_per_cell_floor": round(floor, 1),
+        "phases": [{"phase": b[0], "issued": round(b[1], 1), "floor": round(b[2], 1), "why": b[3]} for b in FAST_BUDGET],
+        "derivation": "exact FAST-9/16 per 30 x 30 cell on this content (27.9 %% of the scan pixels pass the compass pre-test, 12.5 %% are corners): "
+                      "per cell %.0f vector instructions issued (SQ_INSTS_VALU / SQ_WAVES; %.0f accounted by phase), %.0f if every phase ran at the "
+                      "instruction count its arithmetic needs (phases: profiles/<tag>_fast_issue.json floor.phases, DESIGN.md section 5); "
+                      "floor = measured lane-ops per pixel x floor / issued.  The kernel is at %.2f x this floor; the floor itself is %.1f x the "
+                      "5.6 lane-ops per pixel that 0.70 of the HBM roofline would allow." % (
+                          per_wave, issued, floor, per_wave / floor, lane_ops_now * floor / per_wave / 5.6),
+    }
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
@@ -179,6 +212,8 @@ def main():
                          "(v_lerp_u8, v_perm, v_pk_*, 3-operand integer ops), 1.53 ns per full-rate one (v_and/or/xor/add, v_bitop3).",
                "kernel_src_sha16": sha16(os.path.join(ROOT, "weiner_slamit_v2_amd", "csrc", "orb_kernels.hip")), "geometries": fast}
         frames = frames_vga
+        if "vga" in fast and "SQ_INSTS_VALU" in fast["vga"]["counters_per_launch"] and "SQ_WAVES" in fast["vga"]["counters_per_launch"]:
+            doc["floor"] = fast_floor(fast["vga"])
         json.dump(doc, open(os.path.join(dst, tag + "_fast_issue.json"), "w"), indent=1); done.append("_fast_issue.json")
     # ---- BA matrix-core counters per kernel and grid shape ----
     ba = counters_by_kernel_and_grid(os.path.join(src, "ba_mfma"), want=("k_schur", "k_ldlt_solve"))
