@@ -725,18 +725,61 @@ __device__ __forceinline__ void fast_cell_wave(
             {   // append in RASTER order (lane = row, column group; a lane's pixels left to right): the lanes of a scoring pass then
                 // gather their rings from neighbouring tile dwords -- appended slot by slot (one ballot per pixel slot, all lanes'
                 // pixel 0 first) the same entries cost 2.4 x the LDS bank conflicts and 9 % of the kernel.  A lane counts its
-                // pixels, a wave prefix sum gives its first slot; a pixel that did not pass writes the stack's spare last slot
-                // (a select costs one vector instruction, an exec-mask region scalar ones and a branch)
+                // pixels, a wave prefix sum gives its first slot, and each pixel that passed stores under its own exec mask (the
+                // scalar instructions of the mask regions are free here: the kernel is bound by VECTOR issue)
                 int total;
-                unsigned pos = (unsigned)(nE + wave_exclusive_scan(__popc((f6 | (f6 >> 1)) & 0x01010101u), total));
+                const unsigned tb = (f6 | (f6 >> 1)) & 0x01010101u;        // byte j: 1 when pixel j passed
+                const unsigned excl = (unsigned)wave_exclusive_scan(__popc(tb), total);
                 if (total != 0) {
-                    const unsigned g = f6 + 0x0C080400u;         // byte j: 4 j + code = what pixel j adds to e_base (byte selects: SDWA operands)
+                    // byte j of g: 4 j + code = what pixel j adds to e_base; byte j of pf2: twice the number of the lane's pixels that
+                    // passed before pixel j = the byte offset of pixel j's slot behind the lane's first (a 24-bit multiply-add: the
+                    // multiplier's two terms carry pixel 0 into bytes 1, 2 and pixels 1, 2 into bytes 2, 3 / 3; tb << 25 adds pixel 0's
+                    // share of byte 3).  Four masks under the full exec, then each pixel's store under its own; every byte pick
+                    // is an SDWA operand select -- written out, because the compiler shifts and masks bytes 1 and 2 by hand
+                    // (16 vector instructions for the append instead of 27).
+#ifdef FAST_APPEND_C
+                    {
+                    const unsigned g = f6 + 0x0C080400u;
+                    const unsigned pf2 = __umul24(tb, 0x020200u) + (tb << 25);
+                    unsigned char* const slot0 = reinterpret_cast<unsigned char*>(s_ent + nE) + (excl << 1);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool mine = ((f6 >> (8 * j)) & 0xFFu) != 0u;
-                        s_ent[mine ? pos : (unsigned)(FAST_ENT_CAP - 1)] = (unsigned short)(e_base + ((g >> (8 * j)) & 0xFFu));
-                        pos = add_flag(pos, __builtin_amdgcn_ballot_w64(mine));
+                    for (int j = 0; j < 4; ++j)
+                        if (((f6 >> (8 * j)) & 0xFFu) != 0u)
+                            *reinterpret_cast<unsigned short*>(slot0 + ((pf2 >> (8 * j)) & 0xFFu)) = (unsigned short)(e_base + ((g >> (8 * j)) & 0xFFu));
                     }
+#else
+                    const unsigned g = f6 + 0x0C080400u, zero = 0u;
+                    const unsigned slot0 = (unsigned)(size_t)(s_ent + nE) + (excl << 1);   // LDS byte address (s_ent + nE is scalar)
+                    unsigned pf2, dat, adr;
+                    unsigned long long sv, m0, m1, m2, m3;
+                    asm volatile(
+                        "v_lshlrev_b32 %[pf2], 25, %[tb]\n\t"
+                        "v_mad_u32_u24 %[pf2], %[tb], %[k], %[pf2]\n\t"
+                        "v_cmp_ne_u32_sdwa %[m0], %[f6], %[z] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+                        "v_cmp_ne_u32_sdwa %[m1], %[f6], %[z] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+                        "v_cmp_ne_u32_sdwa %[m2], %[f6], %[z] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+                        "v_cmp_ne_u32_sdwa %[m3], %[f6], %[z] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+                        "s_mov_b64 %[sv], exec\n\t"
+                        "s_mov_b64 exec, %[m0]\n\t"
+                        "v_add_u32_sdwa %[dat], %[eb], %[g] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                        "ds_write_b16 %[s0], %[dat]\n\t"
+                        "s_mov_b64 exec, %[m1]\n\t"
+                        "v_add_u32_sdwa %[dat], %[eb], %[g] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+                        "v_add_u32_sdwa %[adr], %[s0], %[pf2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+                        "ds_write_b16 %[adr], %[dat]\n\t"
+                        "s_mov_b64 exec, %[m2]\n\t"
+                        "v_add_u32_sdwa %[dat], %[eb], %[g] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                        "v_add_u32_sdwa %[adr], %[s0], %[pf2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                        "ds_write_b16 %[adr], %[dat]\n\t"
+                        "s_mov_b64 exec, %[m3]\n\t"
+                        "v_add_u32_sdwa %[dat], %[eb], %[g] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+                        "v_add_u32_sdwa %[adr], %[s0], %[pf2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+                        "ds_write_b16 %[adr], %[dat]\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [pf2] "=&v"(pf2), [dat] "=&v"(dat), [adr] "=&v"(adr), [sv] "=&s"(sv), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
+                        : [tb] "v"(tb), [k] "v"(0x020200u), [f6] "v"(f6), [z] "v"(zero), [eb] "v"(e_base), [g] "v"(g), [s0] "v"(slot0)
+                        : "memory");
+#endif
                     nE += total;
                 }
             }
