@@ -388,7 +388,7 @@ def main():
                          "pipeline = BASELINE configs[4]: --streams 720p streams dealt over the ranks (stream s on rank s %% N), "
                          "each rank also solving its streams' local-BA windows, results gathered in fixed-capacity slots")
     ap.add_argument("--streams", type=int, default=8, help="pipeline config: total camera streams over all ranks")
-    ap.add_argument("--ba-workers", type=int, default=3, help="pipeline config: local-BA batches in flight per rank (host threads, each with its own "
+    ap.add_argument("--ba-workers", type=int, default=6, help="pipeline config: local-BA batches in flight per rank (host threads, each with its own "
                     "BA handle and HIP stream); a step's slot carries the poses of the batch submitted that many steps earlier")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the collectives even on ONE rank (a one-GPU "
                     "test then drives RCCL: communicator, device-tensor all_gather_into_tensor, async work handles)")
