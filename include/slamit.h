@@ -204,8 +204,9 @@ typedef struct slamit_search_rule {
 
 /* match_kp[q] = index of the keypoint the query took, or -1; *nmatches = number of accepted queries.
  * best_dist / best_level / second_dist / second_level (any may be NULL) report the selection of every
- * query that had candidates (256 / -1 otherwise).  At most SLAMIT_SEARCH_MAX_KP keypoints and
- * SLAMIT_SEARCH_MAX_CAND candidates per query. */
+ * query that had candidates (256 / -1 otherwise).  At most SLAMIT_SEARCH_MAX_KP keypoints per frame.  A window may hold any
+ * number of them: SLAMIT_SEARCH_MAX_CAND is only the length of the stored candidate list a query's re-scan reads; a query
+ * with more candidates whose tentative pair was taken by an earlier query walks the frame's keypoints again. */
 #define SLAMIT_SEARCH_MAX_KP 8191
 #define SLAMIT_SEARCH_MAX_CAND 1024
 int slamit_guided_search(int device, const slamit_frame_view* frame, const slamit_search_queries* queries,
@@ -296,7 +297,8 @@ int slamit_frame_finish_batch_dev(int device, const slamit_camera* cam, const sl
 
 /* The same for a batch of frames whose data is resident in HBM (one wavefront walks each frame's queries, all frames
  * in parallel): keypoints in the layout slamit_frame_finish_batch_dev writes, everything else [nframes][cap] strided.
- * A window may hold at most SLAMIT_SEARCH_BATCH_CAND keypoints; a frame that exceeds it reports d_nmatches = -1. */
+ * SLAMIT_SEARCH_BATCH_CAND candidates are stored per query (the workspace's size); windows with more are still exact: a re-scan of
+ * such a query walks the frame's keypoints again (the reference has no limit, ORBmatcher.cc:85-117). */
 #define SLAMIT_SEARCH_BATCH_CAND 128
 typedef struct slamit_search_batch {
     int32_t nframes, kp_cap, q_cap;

@@ -639,7 +639,11 @@ __device__ __forceinline__ void fast_cell_wave(
             const unsigned olo = elo >> 2, ohi = ehi >> 2;
             const uint8_t* qlo = tile + olo + (SC_COL0 - 3);
             const uint8_t* qhi = tile + ohi + (SC_COL0 - 3);
+#ifdef FAST_DIAG_NO_XOR   // timing experiment only (wrong scores for "darker" entries)
+            const uint32_t pm = 0u;
+#else
             const uint32_t pm = __umul24(((ehi << 16) | elo) & 0x00010001u, 0xFFu);   // 0xFF in the half of an entry scored as "darker": complements its bytes
+#endif
 #define PX(dx, dy) ((((uint32_t)qhi[((dy) + 3) * PITCH + (dx) + 3] << 16) | (uint32_t)qlo[((dy) + 3) * PITCH + (dx) + 3]) ^ pm)
             // ring in the order of cv::FAST's 16-pattern: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
             uint32_t r[16];

@@ -47,7 +47,7 @@ struct SearchDev {
     float chi2_gate; float inv_sigma2[16];   // Fuse's reprojection gate (chi2_gate <= 0: off)
     int mode;                                 // 0 taken flags, 1 SearchForInitialization's matched-distance state
     int* match_kp; int* out4;   // [nframes][q_cap], [nframes][q_cap][4] (best_dist, best_level, second_dist, second_level) or null
-    int* nmatches;              // [nframes]; -1 = a window of this frame held more than cand_cap keypoints
+    int* nmatches;              // [nframes]
 };
 
 // key = distance << 32 | cell << 17 | keypoint << 4 | octave: ordered by (distance, cell, keypoint) = the reference's
@@ -79,6 +79,55 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return ab < cd ? ab : cd;
 }
 
+// A query's search window (Frame::GetFeaturesInArea, Frame.cc:452-466) and descriptor; ok = the window meets the grid.
+struct QueryWin {
+    float x, y, r;
+    int nMinCellX, nMaxCellX, nMinCellY, nMaxCellY, minLevel, maxLevel;
+    uint4 a0, a1;
+};
+__device__ __forceinline__ bool query_window(const SearchDev& D, size_t qo, QueryWin& W) {
+    W.x = D.uvr[3 * qo]; W.y = D.uvr[3 * qo + 1]; W.r = D.uvr[3 * qo + 2];
+    W.nMinCellX = max(0, (int)floorf((W.x - D.min_x - W.r) * D.inv_w));
+    if (W.nMinCellX >= GRID_COLS) return false;
+    W.nMaxCellX = min(GRID_COLS - 1, (int)ceilf((W.x - D.min_x + W.r) * D.inv_w));
+    if (W.nMaxCellX < 0) return false;
+    W.nMinCellY = max(0, (int)floorf((W.y - D.min_y - W.r) * D.inv_h));
+    if (W.nMinCellY >= GRID_ROWS) return false;
+    W.nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((W.y - D.min_y + W.r) * D.inv_h));
+    if (W.nMaxCellY < 0) return false;
+    W.minLevel = D.lmin[qo]; W.maxLevel = D.lmax[qo];
+    const uint4* Q = reinterpret_cast<const uint4*>(D.qdesc + 32 * qo);
+    W.a0 = Q[0]; W.a1 = Q[1];
+    return true;
+}
+// keypoint i against the window: is it a candidate, and its key (distance, cell, keypoint, octave)
+__device__ __forceinline__ bool window_key(const SearchDev& D, const QueryWin& W, const uint8_t* KP, const uint8_t* KD, int i, unsigned long long& key) {
+    const uint8_t* rec = KP + (size_t)i * D.kp_rec;
+    const float px = *reinterpret_cast<const float*>(rec), py = *reinterpret_cast<const float*>(rec + 4);
+    // Frame::PosInGrid, Frame.cc:505-517 (round = half away from zero)
+    const int posX = (int)roundf((px - D.min_x) * D.inv_w), posY = (int)roundf((py - D.min_y) * D.inv_h);
+    const bool ingrid = !(posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS);
+    const int oct = *reinterpret_cast<const int*>(rec + D.kp_oct_off);
+    const bool lev = !(oct < W.minLevel) && !(W.maxLevel >= 0 && oct > W.maxLevel);
+    const float distx = px - W.x, disty = py - W.y;
+    bool hit = ingrid && posX >= W.nMinCellX && posX <= W.nMaxCellX && posY >= W.nMinCellY && posY <= W.nMaxCellY && lev &&
+               fabsf(distx) < W.r && fabsf(disty) < W.r;
+    if (hit && D.chi2_gate > 0.f) {   // ORBmatcher::Fuse, ORBmatcher.cc:925-936 (mono branch)
+        const float e2 = distx * distx + disty * disty;
+        if (e2 * D.inv_sigma2[oct & 15] > D.chi2_gate) hit = false;
+    }
+    if (hit) {
+        const uint4* T = reinterpret_cast<const uint4*>(KD + 32 * (size_t)i);
+        const uint4 t0 = T[0], t1 = T[1];
+        const int d = __popc(W.a0.x ^ t0.x) + __popc(W.a0.y ^ t0.y) + __popc(W.a0.z ^ t0.z) + __popc(W.a0.w ^ t0.w) +
+                      __popc(W.a1.x ^ t1.x) + __popc(W.a1.y ^ t1.y) + __popc(W.a1.z ^ t1.z) + __popc(W.a1.w ^ t1.w);
+        hit = d < 256;   // bestDist starts at 256 and the test is a strict '<': a complement never wins
+        key = ((unsigned long long)d << 32) | ((unsigned long long)(posX * GRID_ROWS + posY) << 17) |
+              ((unsigned long long)i << 4) | (unsigned long long)(oct & 15);
+    }
+    return hit;
+}
+
 __global__ __launch_bounds__(256) void search_candidates_kernel(SearchDev D) {
     const int lane = threadIdx.x & 63;
     const int f = blockIdx.y;
@@ -89,19 +138,8 @@ __global__ __launch_bounds__(256) void search_candidates_kernel(SearchDev D) {
     const size_t qo = (size_t)f * D.q_cap + q;
     if (lane == 0) { D.cand_n[qo] = 0; D.tent[2 * qo] = ~0ull; D.tent[2 * qo + 1] = ~0ull; }
     if (!D.valid[qo]) return;
-    const float x = D.uvr[3 * qo], y = D.uvr[3 * qo + 1], r = D.uvr[3 * qo + 2];
-    // Frame::GetFeaturesInArea, Frame.cc:452-466
-    const int nMinCellX = max(0, (int)floorf((x - D.min_x - r) * D.inv_w));
-    if (nMinCellX >= GRID_COLS) return;
-    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - D.min_x + r) * D.inv_w));
-    if (nMaxCellX < 0) return;
-    const int nMinCellY = max(0, (int)floorf((y - D.min_y - r) * D.inv_h));
-    if (nMinCellY >= GRID_ROWS) return;
-    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - D.min_y + r) * D.inv_h));
-    if (nMaxCellY < 0) return;
-    const int minLevel = D.lmin[qo], maxLevel = D.lmax[qo];
-    const uint4* Q = reinterpret_cast<const uint4*>(D.qdesc + 32 * qo);
-    const uint4 a0 = Q[0], a1 = Q[1];
+    QueryWin W;
+    if (!query_window(D, qo, W)) return;
     unsigned long long* out = D.cand + qo * D.cand_cap;
     const uint8_t* KP = D.kp + (size_t)f * D.kp_cap * D.kp_rec;
     const uint8_t* KD = D.kp_desc + (size_t)f * D.kp_cap * 32;
@@ -110,33 +148,8 @@ __global__ __launch_bounds__(256) void search_candidates_kernel(SearchDev D) {
     unsigned long long k1 = ~0ull, k2 = ~0ull;   // this lane's two smallest keys among keypoints free on entry
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
-        bool hit = false;
         unsigned long long key = 0;
-        if (i < n) {
-            const uint8_t* rec = KP + (size_t)i * D.kp_rec;
-            const float px = *reinterpret_cast<const float*>(rec), py = *reinterpret_cast<const float*>(rec + 4);
-            // Frame::PosInGrid, Frame.cc:505-517 (round = half away from zero)
-            const int posX = (int)roundf((px - D.min_x) * D.inv_w), posY = (int)roundf((py - D.min_y) * D.inv_h);
-            const bool ingrid = !(posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS);
-            const int oct = *reinterpret_cast<const int*>(rec + D.kp_oct_off);
-            const bool lev = !(oct < minLevel) && !(maxLevel >= 0 && oct > maxLevel);
-            const float distx = px - x, disty = py - y;
-            hit = ingrid && posX >= nMinCellX && posX <= nMaxCellX && posY >= nMinCellY && posY <= nMaxCellY && lev &&
-                  fabsf(distx) < r && fabsf(disty) < r;
-            if (hit && D.chi2_gate > 0.f) {   // ORBmatcher::Fuse, ORBmatcher.cc:925-936 (mono branch)
-                const float e2 = distx * distx + disty * disty;
-                if (e2 * D.inv_sigma2[oct & 15] > D.chi2_gate) hit = false;
-            }
-            if (hit) {
-                const uint4* T = reinterpret_cast<const uint4*>(KD + 32 * (size_t)i);
-                const uint4 t0 = T[0], t1 = T[1];
-                const int d = __popc(a0.x ^ t0.x) + __popc(a0.y ^ t0.y) + __popc(a0.z ^ t0.z) + __popc(a0.w ^ t0.w) +
-                              __popc(a1.x ^ t1.x) + __popc(a1.y ^ t1.y) + __popc(a1.z ^ t1.z) + __popc(a1.w ^ t1.w);
-                hit = d < 256;   // bestDist starts at 256 and the test is a strict '<': a complement never wins
-                key = ((unsigned long long)d << 32) | ((unsigned long long)(posX * GRID_ROWS + posY) << 17) |
-                      ((unsigned long long)i << 4) | (unsigned long long)(oct & 15);
-            }
-        }
+        const bool hit = i < n && window_key(D, W, KP, KD, i, key);
         const unsigned long long mk = __ballot(hit);
         if (hit) {
             const int o = count + __popcll(mk & ((1ull << lane) - 1ull));
@@ -171,7 +184,7 @@ __global__ __launch_bounds__(64) void search_resolve_kernel(SearchDev D) {
     __builtin_amdgcn_wave_barrier();
     const unsigned long long NONE = ~0ull;
     const size_t q0 = (size_t)f * D.q_cap;
-    int nmatches = 0, overflow = 0;
+    int nmatches = 0;
     for (int qb = 0; qb < m; qb += 64) {
         const int qj = qb + lane;
         const bool live = qj < m;
@@ -188,18 +201,29 @@ __global__ __launch_bounds__(64) void search_resolve_kernel(SearchDev D) {
                 const bool stale = (((taken[bi0 >> 5] >> (bi0 & 31)) | (taken[si0 >> 5] >> (si0 & 31))) & 1u) != 0;
                 if (stale) {   // an earlier query of this call took one of the two: re-scan this query's candidates
                     const size_t qo = q0 + qb + j;
-                    const int nc_all = __builtin_amdgcn_readlane(ncq, j), nc = min(nc_all, D.cand_cap);
+                    const int nc_all = __builtin_amdgcn_readlane(ncq, j);
                     // The stored list is only read HERE.  The tentative pair was reduced over every hit, so a window that holds
-                    // more than cand_cap keypoints is still exact as long as no re-scan of it is needed; only a re-scan of
-                    // a truncated list voids the frame (the reference has no such limit, ORBmatcher.cc:85-117).
-                    if (nc_all > D.cand_cap) overflow = 1;
-                    const unsigned long long* C = D.cand + qo * D.cand_cap;
+                    // more than cand_cap keypoints is exact as long as no re-scan of it is needed; a re-scan of a TRUNCATED list
+                    // walks the frame's keypoints again instead (the reference has no limit on a window's size, ORBmatcher.cc:85-117).
                     unsigned long long k1 = NONE, k2 = NONE;
-                    for (int c = lane; c < nc; c += 64) {
-                        const unsigned long long k = C[c];
-                        const int i = KEY_KP(k);
-                        if ((taken[i >> 5] >> (i & 31)) & 1u) continue;   // F.mvpMapPoints[idx] with observations
-                        if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+                    if (nc_all <= D.cand_cap) {
+                        const unsigned long long* C = D.cand + qo * D.cand_cap;
+                        for (int c = lane; c < nc_all; c += 64) {
+                            const unsigned long long k = C[c];
+                            const int i = KEY_KP(k);
+                            if ((taken[i >> 5] >> (i & 31)) & 1u) continue;   // F.mvpMapPoints[idx] with observations
+                            if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+                        }
+                    } else {
+                        QueryWin W;
+                        query_window(D, qo, W);   // (it met the grid: the query has candidates)
+                        const uint8_t* KP = D.kp + (size_t)f * D.kp_cap * D.kp_rec;
+                        const uint8_t* KD = D.kp_desc + (size_t)f * D.kp_cap * 32;
+                        for (int i = lane; i < n; i += 64) {
+                            unsigned long long k;
+                            if (!window_key(D, W, KP, KD, i, k) || ((taken[i >> 5] >> (i & 31)) & 1u)) continue;
+                            if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+                        }
                     }
                     best = wave_min_u64(k1);
                     second = wave_min_u64(k1 == best ? k2 : k1);
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(64) void search_resolve_kernel(SearchDev D) {
             if (D.out4) *reinterpret_cast<int4*>(&D.out4[4 * qo]) = make_int4(bd, bl, sd, sl);
         }
     }
-    if (lane == 0) D.nmatches[f] = overflow ? -1 : nmatches;
+    if (lane == 0) D.nmatches[f] = nmatches;
 }
 
 // mode 1 (ORBmatcher::SearchForInitialization): the per-keypoint state is the distance of its current match and the query
@@ -249,7 +273,7 @@ __global__ __launch_bounds__(64) void search_resolve_init_kernel(SearchDev D) {
     __builtin_amdgcn_wave_barrier();
     const unsigned long long NONE = ~0ull;
     const size_t q0 = (size_t)f * D.q_cap;
-    int nmatches = 0, overflow = 0;
+    int nmatches = 0;
     for (int qb = 0; qb < m; qb += 64) {
         const int qj = qb + lane;
         const bool live = qj < m;
@@ -265,14 +289,25 @@ __global__ __launch_bounds__(64) void search_resolve_init_kernel(SearchDev D) {
                 const bool xs = second != NONE && md[KEY_KP(second)] <= (int)(second >> 32);
                 if (xb || xs) {
                     const size_t qo = q0 + qb + j;
-                    const int nc_all = __builtin_amdgcn_readlane(ncq, j), nc = min(nc_all, D.cand_cap);
-                    if (nc_all > D.cand_cap) overflow = 1;   // a truncated list is being consumed (see search_resolve_kernel)
-                    const unsigned long long* C = D.cand + qo * D.cand_cap;
+                    const int nc_all = __builtin_amdgcn_readlane(ncq, j);
                     unsigned long long k1 = NONE, k2 = NONE;
-                    for (int c = lane; c < nc; c += 64) {
-                        const unsigned long long k = C[c];
-                        if (md[KEY_KP(k)] <= (int)(k >> 32)) continue;   // ORBmatcher.cc:448
-                        if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+                    if (nc_all <= D.cand_cap) {
+                        const unsigned long long* C = D.cand + qo * D.cand_cap;
+                        for (int c = lane; c < nc_all; c += 64) {
+                            const unsigned long long k = C[c];
+                            if (md[KEY_KP(k)] <= (int)(k >> 32)) continue;   // ORBmatcher.cc:448
+                            if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+                        }
+                    } else {   // a truncated list: walk the frame's keypoints again (see search_resolve_kernel)
+                        QueryWin W;
+                        query_window(D, qo, W);
+                        const uint8_t* KP = D.kp + (size_t)f * D.kp_cap * D.kp_rec;
+                        const uint8_t* KD = D.kp_desc + (size_t)f * D.kp_cap * 32;
+                        for (int i = lane; i < n; i += 64) {
+                            unsigned long long k;
+                            if (!window_key(D, W, KP, KD, i, k) || md[i] <= (int)(k >> 32)) continue;
+                            if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+                        }
                     }
                     best = wave_min_u64(k1);
                     second = wave_min_u64(k1 == best ? k2 : k1);
@@ -309,7 +344,7 @@ __global__ __launch_bounds__(64) void search_resolve_init_kernel(SearchDev D) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // later chunks may reset entries of this one through global memory
     }
-    if (lane == 0) D.nmatches[f] = overflow ? -1 : nmatches;
+    if (lane == 0) D.nmatches[f] = nmatches;
 }
 
 static void search_launch(hipStream_t st, const SearchDev& D, int max_m) {
@@ -383,7 +418,6 @@ extern "C" int slamit_guided_search(int device, const slamit_frame_view* F, cons
     if (e != hipSuccess) return slamit_fail_hip(e, "slamit_guided_search");
     int nm = 0;
     memcpy(&nm, hb + o_nm, 4);
-    if (nm < 0) return slamit_fail(SLAMIT_ERR_CAPACITY, "slamit_guided_search: a window holds more than SLAMIT_SEARCH_MAX_CAND keypoints");
     memcpy(match_kp, hb + o_mk, 4 * (size_t)m);
     *nmatches = nm;
     const int* o4 = reinterpret_cast<const int*>(hb + o_o4);
