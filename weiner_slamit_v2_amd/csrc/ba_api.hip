@@ -149,8 +149,10 @@ int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int de
         h->win_bytes = h->io_cap + carve_work(nullptr, probe, max_kf, max_pt, max_edge, h->Npad_max, h->Kpad_max, h->n_part);
     }
     hipError_t e = hipMalloc((void**)&h->d_slab, h->win_bytes * (size_t)max_batch);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_wins, sizeof(BaWin) * max_batch);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_states, sizeof(BaState) * max_batch);
+    // one block: the LM states in REVERSE order right in front of the window table (state b = (BaState*)d_wins - (b + 1)): a kernel
+    // finds its state from the table's address alone (BA_ST, ba_kernels.hip)
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_states, (sizeof(BaState) + sizeof(BaWin)) * (size_t)max_batch);
+    if (e == hipSuccess) h->d_wins = reinterpret_cast<BaWin*>(h->d_states + max_batch);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_io, sizeof(BaIo) * max_batch);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming);
@@ -166,7 +168,7 @@ int slamit_ba_create(int max_kf, int max_pt, int max_edge, int max_batch, int de
 void slamit_ba_destroy(slamit_ba* h) {
     if (!h) return;
     SlamitDeviceGuard guard(h->device);
-    hipFree(h->d_slab); hipFree(h->d_wins); hipFree(h->d_states); hipFree(h->d_io);
+    hipFree(h->d_slab); hipFree(h->d_states); hipFree(h->d_io);
     if (h->h_pin) hipHostFree(h->h_pin);
     for (int i = 0; i < 2; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->pev) hipEventDestroy(e);
@@ -269,7 +271,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         w.chi2_gate_s = opts->chi2_gate_stereo > 0 ? opts->chi2_gate_stereo : 7.815;                           // Optimizer.cc:696, 740
         w.nrow = P.edge_ur ? 3 : 2;
         w.e_ur = D.e_ur; w.bf = D.bf;
-        w.st = h->d_states + b;
+        w.st = reinterpret_cast<BaState*>(h->d_wins) - (b + 1);
         // ---- structure of the window (g2o's BlockSolver / SimplicialLDLT exploit the same sparsity on the CPU,
         // block_solver.hpp:381-432, linear_solver_eigen.h:94-124) ----
         // Points are stored on the device sorted by the first free keyframe that observes them: the rows of GA / GB that
@@ -424,7 +426,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
                 static const bool no_fuse = getenv("SLAMIT_BA_NO_FUSE") && atoi(getenv("SLAMIT_BA_NO_FUSE"));   // A/B runs: every slot as the first
                 for (int sl = 0; sl < nslots; ++sl) bak_slot(st, h->d_wins, nwin, mk, mp, me, Npad, (was_first && sl == 0) || no_fuse, solvers, slot_events());
                 budget -= nslots;
-                HIP_TRY(hipMemcpyAsync(hs[cur], h->d_states, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(hs[cur], reinterpret_cast<BaState*>(h->d_wins) - nwin, sizeof(BaState) * nwin, hipMemcpyDeviceToHost, st));   // (reverse order: only `done` of all is read)
                 HIP_TRY(hipEventRecord(h->ev[cur], st));
             }
             if (pending >= 0) {

@@ -51,6 +51,11 @@ __device__ double block_sum_256(double v, double* sh /*[4]*/) {
     return r;
 }
 
+// The LM state of window b sits at a FIXED place relative to the window table -- states are laid out in reverse order right in front of
+// it (ba_api.hip) --, so a kernel's first load of `done` does not wait for the BaWin load that would hand it the pointer: one dependent
+// global round trip (~1 us) less at the head of every launch of an LM slot.
+#define BA_ST(wins, b) (reinterpret_cast<BaState*>(wins) - ((int)(b) + 1))
+
 // ---- per-edge geometry -----------------------------------------------------------------------
 struct EdgeGeom { double err0, err1, chi2, x, y, z; };
 
@@ -201,7 +206,7 @@ __device__ __forceinline__ void edge_jacobian(const BaWin& W, bool robust, int e
 
 __global__ __launch_bounds__(256) void k_linearize(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done || !st->need_linearize) return;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e == 0 && st->it == 0) st->maxdiag_bits = 0ull;
@@ -239,7 +244,7 @@ __device__ __forceinline__ double group_sum(double v) {   // sum over the BA_PG 
 
 __global__ __launch_bounds__(256) void k_point_reduce(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done || !st->need_linearize) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int p = t / BA_PG, g = t % BA_PG;
@@ -285,8 +290,7 @@ __device__ __forceinline__ double row16_sum(double v) {   // all 16 lanes of a D
     return v;
 }
 
-__device__ __forceinline__ void pose_reduce_body(const BaWin& W, int kf) {
-    BaState* st = W.st;
+__device__ __forceinline__ void pose_reduce_body(const BaWin& W, BaState* st, int kf) {
     if (st->done || !st->need_linearize) return;
     if (kf >= W.n_kf) return;
     const int col = W.pose_col[kf];
@@ -343,12 +347,12 @@ __device__ __forceinline__ void pose_reduce_body(const BaWin& W, int kf) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_pose_reduce(BaWin* wins) { pose_reduce_body(wins[blockIdx.y], blockIdx.x); }
+__global__ __launch_bounds__(256) void k_pose_reduce(BaWin* wins) { pose_reduce_body(wins[blockIdx.y], BA_ST(wins, blockIdx.y), blockIdx.x); }
 
 // ---- S4: iteration bookkeeping (one thread per window) -----------------------------------------
 __global__ void k_iter_begin(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (threadIdx.x != 0 || st->done || !st->need_linearize) return;
     if (st->it == 0) {  // computeLambdaInit: tau * max |H_jj|
         st->lambda = 1e-5 * __longlong_as_double((long long)st->maxdiag_bits);
@@ -371,7 +375,7 @@ __device__ __forceinline__ void hpl_of(const double* J, double* H /*6x3*/) {
 
 __global__ __launch_bounds__(256) void k_prepare(BaWin* wins) {   // BA_PG lanes per point, like k_point_reduce
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int p = t / BA_PG, g = t % BA_PG;
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(256) void k_prepare(BaWin* wins) {   // BA_PG lanes
 // k_backsub_update); after a rejected trial only the damping part runs.  Same expressions, same summation order.
 __global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int p = t / BA_PG, g = t % BA_PG;
@@ -511,8 +515,8 @@ __device__ __forceinline__ bool schur_tile_needed(const BaWin& W, int I, int J) 
     return true;
 }
 
-__device__ __forceinline__ void schur_body(const BaWin& W, int tile, int s, int nsplit) {
-    if (W.st->done) return;
+__device__ __forceinline__ void schur_body(const BaWin& W, const BaState* st, int tile, int s, int nsplit) {
+    if (st->done) return;
     const int T = W.Npad / BA_TILE;
     // `tile` enumerates upper-triangular macro tiles
     int I = 0, rem = tile;
@@ -584,14 +588,14 @@ __device__ __forceinline__ void schur_body(const BaWin& W, int tile, int s, int 
         }
 }
 
-__global__ __launch_bounds__(256) void k_schur(BaWin* wins) { schur_body(wins[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.y); }
+__global__ __launch_bounds__(256) void k_schur(BaWin* wins) { schur_body(wins[blockIdx.z], BA_ST(wins, blockIdx.z), blockIdx.x, blockIdx.y, gridDim.y); }
 
 // Both in one launch for the slots after a stage's first (neither needs the other; k_schur_reduce needs both): the pose blocks ride
 // as extra workgroups behind the Schur tiles -- keyframe (x - ntiles) * (splits of the launch) + y.
 __global__ __launch_bounds__(256) void k_schur_pose(BaWin* wins, int ntiles) {
     const BaWin& W = wins[blockIdx.z];
-    if ((int)blockIdx.x < ntiles) schur_body(W, blockIdx.x, blockIdx.y, gridDim.y);
-    else pose_reduce_body(W, ((int)blockIdx.x - ntiles) * (int)gridDim.y + (int)blockIdx.y);
+    if ((int)blockIdx.x < ntiles) schur_body(W, BA_ST(wins, blockIdx.z), blockIdx.x, blockIdx.y, gridDim.y);
+    else pose_reduce_body(W, BA_ST(wins, blockIdx.z), ((int)blockIdx.x - ntiles) * (int)gridDim.y + (int)blockIdx.y);
 }
 
 __host__ __device__ inline int ldlt_band_rs(int bw);
@@ -600,7 +604,7 @@ __host__ __device__ inline bool ldlt_band_ok(int n, int bw);
 // ---- S7: S = Hpp + lambda*I - sum_s part[s],  b_s = bp - coeff --------------------------------------
 __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins, int nsplit) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done) return;
     const int n = W.nS, N = W.Npad;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1177,7 +1181,7 @@ __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, dou
 // false): it is the first single-workgroup kernel behind the last reader of need_linearize (k_pose_reduce).
 __global__ __launch_bounds__(LD_THREADS) void k_ldlt_band(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (W.solver != BA_SOLVER_BAND || st->done) return;
     if (threadIdx.x == 0 && st->need_linearize) { st->iniChi = st->currentChi; st->qmax = 0; st->need_linearize = 0; }
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1189,7 +1193,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_band(BaWin* wins) {
 
 __global__ __launch_bounds__(LD_THREADS) void k_ldlt_blocked(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (W.solver != BA_SOLVER_BLOCKED || st->done) return;
     const int n = W.nS, N = W.Npad;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1398,7 +1402,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_blocked(BaWin* wins) {
 // ---- S9: landmark back-substitution, push(), oplus ------------------------------------------------
 __global__ __launch_bounds__(256) void k_backsub_update(BaWin* wins) {   // BA_PG lanes per point; thread t < n_kf also moves pose t
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done) return;
     __shared__ double sh[4];
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -1458,7 +1462,7 @@ __global__ __launch_bounds__(256) void k_backsub_update(BaWin* wins) {   // BA_P
 // ---- S10: residuals at the tentative state, robust cost partial sums ------------------------------------
 __global__ __launch_bounds__(256) void k_errors(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done) return;
     __shared__ double sh[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -1491,7 +1495,7 @@ __device__ double sum_parts(const double* part, int n, double* sh) {
 // ---- S11: accept / reject, lambda update, stop rules (one workgroup per window) ----------------------------
 __global__ __launch_bounds__(256) void k_decide(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done) return;
     __shared__ double sh[4];
     __shared__ int s_reject;
@@ -1589,7 +1593,7 @@ __global__ __launch_bounds__(256) void k_zero_operands(BaWin* wins) {
 // stage entry: counts the active edges; the following k_errors + k_stage_begin2 set the start cost
 __global__ __launch_bounds__(256) void k_stage_begin(BaWin* wins, int stage, int max_it, int robust) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
@@ -1614,7 +1618,7 @@ __global__ __launch_bounds__(256) void k_stage_begin(BaWin* wins, int stage, int
 }
 __global__ __launch_bounds__(256) void k_stage_begin2(BaWin* wins) {
     const BaWin& W = wins[blockIdx.y];
-    BaState* st = W.st;
+    BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done) return;
     __shared__ double sh[4];
     const double chi = sum_parts(W.chi_part, (W.n_edge + 255) / 256, sh);
