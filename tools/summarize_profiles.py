@@ -109,7 +109,7 @@ FAST_BUDGET = [
     # phase, issued now, floor, why the floor
     ("stage the window (LDS-DMA) + zero the score tile + cell set-up", 74, 30, "one address per 16-byte chunk and the cell's constants"),
     ("pre-test, 4 pixels per lane and step (4.2 steps per cell)", 4.2 * 27, 4.2 * 21, "2 v_alignbyte + v_not + 4 difference lerps + 8 threshold lerps + 4 combines + 2 mask merges"),
-    ("survivor append: count, wave prefix sum, 4 slot stores (4.2 steps)", 4.2 * 38, 4.2 * 16, "popcount 3 + DPP scan 7 + address 2 + one add per slot"),
+    ("survivor append: count, wave prefix sum, 4 slot stores (4.2 steps)", 4.2 * 27, 4.2 * 16, "popcount 3 + DPP scan 7 + address 2 + one add per slot"),
     ("exact score, 2 entries per lane (262 entries per cell: 2.55 passes issued, 2.05 without the half-empty last pass)", 2.55 * 112, 2.05 * 82, "34 half-word packs + 40 v_pk_min3 / max3 + 8 for score, compare and store"),
     ("non-maximum suppression over the listed corners (118 per cell)", 37, 20, "8 neighbour reads and a 3-level max per corner, two 64-lane rounds"),
     ("candidate output (25 per cell)", 32, 20, "decode, score fetch, one 8-byte store per candidate"),
