@@ -179,6 +179,35 @@ def test_degenerate_windows(opt):
     _close(opt.LocalBundleAdjustment(allfixed), ob.ba_solve(allfixed), "allfixed")
 
 
+def test_stereo_window_edge_cases(opt):
+    """Stereo windows at the edges of the interface: no edges, a window whose stereo flags are all negative
+    (= monocular: same result as without the arrays), kf_bf missing at the C boundary, custom stereo thresholds."""
+    import ctypes as C
+
+    prob = synth.synth_ba(6, 60, 3, seed=65, stereo_frac=0.5)
+    empty = dict(prob)
+    for k in ("edge_kf", "edge_pt", "edge_uv", "edge_inv_sigma2", "edge_ur"):
+        empty[k] = prob[k][:0]
+    r = opt.LocalBundleAdjustment(empty)
+    assert r["stats"]["n_its"] == [0, 0] and np.allclose(r["pt_xyz"], prob["pt_xyz"])
+    mono = {k: v for k, v in prob.items() if k not in ("edge_ur", "kf_bf")}
+    as_mono = dict(prob, edge_ur=np.full(len(prob["edge_ur"]), -1.0))
+    a, b = opt.LocalBundleAdjustment(mono), opt.LocalBundleAdjustment(as_mono)
+    assert a["stats"]["n_its"] == b["stats"]["n_its"] and a["stats"]["trials"] == b["stats"]["trials"]
+    assert np.allclose(a["kf_pose"], b["kf_pose"], rtol=0, atol=1e-7) and np.array_equal(a["edge_outlier"], b["edge_outlier"])   # (three-row code path, zero third row: other roundings)
+    # a wider stereo gate and Huber width change the stereo edges' verdicts only
+    wide = opt.LocalBundleAdjustment(prob, huber_delta_stereo=10.0, chi2_gate_stereo=1e9)
+    st = prob["edge_ur"] >= 0
+    assert not wide["edge_outlier"][st & (wide["edge_chi2"] < 1e8)].any()
+    # the C boundary refuses stereo observations without the keyframes' bf
+    p, keep = api._ba_problem(prob)
+    p.kf_bf = None
+    res, out, stt = opt._result(p.n_kf, p.n_pt, p.n_edge)
+    o = api.BaOpts(5, 10, api.HUBER_MONO, 5.991, None, 0.0, 0.0)
+    assert api.lib().slamit_ba_solve(opt._h, C.byref(p), C.byref(o), C.byref(res)) != 0
+    assert b"kf_bf" in api.lib().slamit_last_error()
+
+
 def test_stop_flag_aborts_a_running_solve(opt):
     """LocalMapping::InterruptBA (src/LocalMapping.cc:681-684) raises *pbStopFlag from the tracking thread while the
     optimiser runs; g2o polls it before every iteration (core/sparse_optimizer.cpp:376).  Here LM slots are queued in
