@@ -457,7 +457,7 @@ def main():
     d_idx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_best = torch.zeros((B, cap), dtype=torch.int32, device=dev)
     d_second = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    gather = shard.SummaryGather(B, 2, cdev, world)  # per-frame (keypoints, matches) to every rank
+    gather = shard.SummaryGather(B, 2, cdev, world, force_collective=args.force_dist)  # per-frame (keypoints, matches) to every rank
     slots = ba = ba_probs = None
     ba_its = [0]
     if pipeline:
@@ -515,8 +515,11 @@ def main():
             ev_m[prv].record(mstream)
         if pipeline:
             ba_jobs.append(ba.submit(ba_probs))   # this step's windows; never waited for here
-        if world > 1 and not pipeline:  # result summary to every rank (the only cross-GPU traffic of the path)
-            gather.local[:, 0] = d_n[cur]
+        if (world > 1 or args.force_dist) and not pipeline:  # result summary to every rank (the only cross-GPU traffic of the path)
+            if cdev.type == "cpu":
+                gather.local[:, 0] = d_n[cur].cpu()
+            else:
+                gather.local[:, 0] = d_n[cur]
             gather.step()
         if pipeline:
             # fixed-capacity result slots: header, first 2000 keypoints + descriptors, and the 50 poses of the BA batch that was
@@ -569,7 +572,7 @@ def main():
         for k in range(k_next, k_next + args.steps):
             step(k)
         k_next += args.steps
-        if world > 1 and not pipeline:
+        if (world > 1 or args.force_dist) and not pipeline:
             gather.flush()   # the last step's summary is part of the timed work
         if pipeline:
             last_slots = slots.flush()
@@ -587,7 +590,7 @@ def main():
     # per-stage breakdown: a separate, untimed pass with events around every stage
     for k in range(k_next, k_next + (1 if pipeline else 5)):
         step(k)
-    if world > 1 and not pipeline:
+    if (world > 1 or args.force_dist) and not pipeline:
         gather.flush()
     if pipeline:
         slots.flush()

@@ -72,3 +72,14 @@ def test_bench_pipeline_forced_collective_on_one_gpu():
     d = _line(out)
     assert d["n_gpus"] == 1 and d["config"]["frames_per_step_per_gpu"] == 8 and d["config"].get("collective") == "nccl"
     assert d["secondary"]["value"] > 0
+
+
+def test_bench_default_config_forced_collective_on_one_gpu():
+    """The driver's multi-GPU run of the DEFAULT config differs from N = 1 only by the process group, the per-step
+    all_gather_into_tensor of the [frames, 2] summary and the max-over-ranks all_reduce: --force-dist runs exactly those through
+    nccl (= RCCL) at world size one, so the code a node will execute has run on a GPU before."""
+    out = subprocess.check_output([sys.executable, "bench.py", "--force-dist", "--steps", "4", "--warmup", "1", "--reps", "2", "--no-cpu", "--no-ba",
+                                   "--no-extras"], cwd=ROOT, stderr=subprocess.STDOUT, timeout=600)
+    d = _line(out)
+    assert d["n_gpus"] == 1 and d["config"].get("collective") == "nccl" and d["config"]["frames_per_step_per_gpu"] == 256
+    assert abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 0.01

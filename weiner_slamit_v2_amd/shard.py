@@ -32,19 +32,22 @@ class SummaryGather:
     gather, so the collective's latency overlaps the next step's kernels instead of sitting on the compute stream.
     `local` / the gathered tensors are double-buffered; flush() returns the newest result."""
 
-    def __init__(self, rows, cols, device, world):
+    def __init__(self, rows, cols, device, world, force_collective=False):
         self.world = world
+        # force_collective: run the all_gather even on one rank (an initialised process group of size 1), so that the RCCL path of the
+        # default bench is exercised by a one-GPU test before a node sees it
+        self.collective = world > 1 or force_collective
         self._loc = [torch.zeros((rows, cols), dtype=torch.int32, device=device) for _ in range(2)]
-        self._all = [torch.zeros((world * rows, cols), dtype=torch.int32, device=device) for _ in range(2)] if world > 1 else self._loc
+        self._all = [torch.zeros((world * rows, cols), dtype=torch.int32, device=device) for _ in range(2)] if self.collective else self._loc
         self._k = 0
         self._pending = None
         self.local = self._loc[0]
 
     def step(self):
         """Publishes `local`; returns the fleet summary of the previous step (None on the first call)."""
-        prev = self.flush() if (self._pending is not None or self.world == 1 and self._k > 0) else None
+        prev = self.flush() if (self._pending is not None or not self.collective and self._k > 0) else None
         cur = self._k & 1
-        if self.world > 1:
+        if self.collective:
             self._pending = (dist.all_gather_into_tensor(self._all[cur], self._loc[cur], async_op=True), self._all[cur])
         else:
             self._pending = (None, self._loc[cur])
