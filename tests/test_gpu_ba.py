@@ -179,6 +179,23 @@ def test_degenerate_windows(opt):
     _close(opt.LocalBundleAdjustment(allfixed), ob.ba_solve(allfixed), "allfixed")
 
 
+def test_profiled_solve_reports_its_phases(opt):
+    """slamit_ba_profile / slamit_ba_profile_read (the per-phase times of g2o's G2OBatchStatistics, G/core/batch_stats.h:39-77): a profiled
+    solve gives the same result as an unprofiled one, five positive phase sums over as many slots as LM trials were queued, and the
+    flops its Schur products executed (at least the algorithmic ones); profiling stays on until it is switched off."""
+    prob = synth.synth_ba(20, 500, 6, seed=81)
+    plain = opt.LocalBundleAdjustment(prob)
+    opt.profile(True)
+    prof = opt.LocalBundleAdjustment(prob)
+    p = opt.profile_read()
+    assert np.array_equal(plain["kf_pose"], prof["kf_pose"]) and plain["stats"]["trials"] == prof["stats"]["trials"]
+    trials = sum(sum(t) for t in prof["stats"]["trials"])
+    assert p["nwin"] == 1 and p["slots"] >= trials and set(p["phase_ms"]) == set(api.BA_PHASES)
+    assert all(v > 0 for v in p["phase_ms"].values()) and sum(p["phase_ms"].values()) < 50.0
+    assert p["schur_exec_mflop"] > 0
+    opt.profile(False)
+
+
 def test_stereo_window_edge_cases(opt):
     """Stereo windows at the edges of the interface: no edges, a window whose stereo flags are all negative
     (= monocular: same result as without the arrays), kf_bf missing at the C boundary, custom stereo thresholds."""
