@@ -2052,7 +2052,9 @@ hipError_t orbk_octree_prepare(int node_cap, int key_cap) {
     prepared = want;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
 }
 
 void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsigned long long* cand,
@@ -2064,14 +2066,20 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
     // longer alone (74 vs 67 us at 128 frames) but leave the side stream's blur more of the chip, and the STEP is 2 % shorter
     // (0.551 vs 0.562 ms); at 64 frames they cost 5 %.
     static const int nt_env = getenv("SLAMIT_OCT_THREADS") ? atoi(getenv("SLAMIT_OCT_THREADS")) : 0;
-    const int nt = nt_env == 256 || nt_env == 512 ? nt_env : (nframes >= 96 ? 256 : OCT_THREADS);
+    // ... and with a handful of frames (<= 16: at most 128 workgroups, half a chip) the pass is the level-0 workgroup's critical path:
+    // 1,024 threads shorten its key sweeps (8 frames of 720p: 0.095 -> 0.069 ms; 64 frames: 512 threads are better, 0.038 vs 0.054 at VGA)
+    const int nt = nt_env == 256 || nt_env == 512 || nt_env == 1024 ? nt_env : (nframes >= 96 ? 256 : nframes <= 16 ? 1024 : OCT_THREADS);
     // A big batch is bound by how many of its (frame, level) workgroups a CU holds at once, and that by their LDS: with the
     // handle's full key arrays (48 KB) three fit, with room for 2,048 keys five do, and the lists above that go through the HBM
     // workspace (L2 resident) at little cost: 0.116 -> 0.092 ms per 256 VGA frames.  (1,536 keys = six per CU: the pass alone
     // 0.088 ms, but the step 2 % LONGER -- the side stream's blur finds less of the chip.)  A few frames keep the big arrays.
     static const bool keys_env = getenv("SLAMIT_OCT_KEYS") || getenv("SLAMIT_OCT_LDS_KB");
     if (nframes >= 96 && !keys_env) key_cap = std::min(key_cap, 2048);
-    if (nt == 256)
+    if (nt == 1024)
+        hipLaunchKernelGGL(octree_kernel<1024>, grid, dim3(1024), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
+                           cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
+                           key_cap, level_override);
+    else if (nt == 256)
         hipLaunchKernelGGL(octree_kernel<256>, grid, dim3(256), orbk_octree_smem(node_cap, key_cap), st, levels, nlevels, cand,
                            cand_frame_stride, cand_count, ws_xy, ws_node, lkp, kp_frame_stride, kp_count, node_cap,
                            key_cap, level_override);
