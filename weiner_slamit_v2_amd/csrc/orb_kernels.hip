@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cell = blockIdx.x * 4 + wv;
+    const int cell = blockIdx.x * (blockDim.x >> 6) + wv;   // (a workgroup of 1, 2 or 4 waves: SLAMIT_FAST_WPB)
     if (cell >= ncells) return;
     fast_cell_wave<PITCH>(fsm, lane, wv, blockIdx.y, cell, tab, cells, nlevels, img0, img0_stride, img0_frame, pyr, cand,
                           cand_frame_stride, cand_count, iniTh, minTh, tile_rows, sc_rows, kp_cap);
@@ -2012,8 +2012,14 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
                int max_wcell, int max_hcell, int nframes) {
     const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
     const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
-    const dim3 grid((cells_per_frame + 3) / 4, nframes);
-    const size_t smem = orbk_fast_smem(max_wcell, max_hcell);
+    // The waves of a workgroup need nothing from each other, and a four-wave workgroup holds its LDS until its slowest cell is done
+    // (cells differ 3x in work).  One wave (= one cell) per workgroup: 0.2825 -> 0.2715 ms per 256 VGA frames (1.5 - 4 % at 64 - 256
+    // frames); at 1280 x 720 (2,656 cells per frame) four per workgroup stay 1 - 2 % ahead at 16 - 128 frames, so the choice goes by
+    // the frame's cell count -- two measured geometries, no model.  (SLAMIT_FAST_WPB=1|2|4: A/B runs.)
+    static const int wpb_env = getenv("SLAMIT_FAST_WPB") ? atoi(getenv("SLAMIT_FAST_WPB")) : 0;
+    const int wpb = wpb_env == 1 || wpb_env == 2 || wpb_env == 4 ? wpb_env : cells_per_frame < 1600 ? 1 : 4;
+    const dim3 grid((cells_per_frame + wpb - 1) / wpb, nframes);
+    const size_t smem = orbk_fast_smem(max_wcell, max_hcell) / 4 * wpb;
     FastTab tab = {};
     for (int l = 0; l < nlevels && l < ORB_MAX_LEVELS; ++l) {
         const OrbLevel& S = host_levels[l];
@@ -2023,11 +2029,11 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
         D.plane_off = S.plane_off; D.plane_bytes = S.plane_bytes; D.cand_off = S.cand_off;
     }
     if (fast_pitch(max_wcell) == FAST_PS)
-        hipLaunchKernelGGL(fast_cells_kernel<FAST_PS>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
+        hipLaunchKernelGGL(fast_cells_kernel<FAST_PS>, grid, dim3(64 * wpb), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
                            (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
                            sc_rows, kp_cap);
     else
-        hipLaunchKernelGGL(fast_cells_kernel<FAST_PL>, grid, dim3(256), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
+        hipLaunchKernelGGL(fast_cells_kernel<FAST_PL>, grid, dim3(64 * wpb), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
                            (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
                            sc_rows, kp_cap);
 }
