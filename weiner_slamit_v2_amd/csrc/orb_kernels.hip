@@ -882,7 +882,15 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cell = blockIdx.x * (blockDim.x >> 6) + wv;   // (a workgroup of 1, 2 or 4 waves: SLAMIT_FAST_WPB)
+    // A workgroup holds 1, 2 or 4 cells (waves).  One-cell workgroups: consecutive workgroup ids go to consecutive XCDs (8, an L2 each), but
+    // neighbouring cells share image lines (6-pixel halos inside 128-byte lines) -- dealt cell by cell the launch fetched 545 MB instead of
+    // 247 per 256 VGA frames.  So inside every run of 32 cells XCD x takes cells 4 x .. 4 x + 3 (what a four-wave workgroup held), and the
+    // XCDs still walk the frame side by side.
+    int cell;
+    if (blockDim.x == 64) {
+        const unsigned w = blockIdx.x;
+        cell = (int)((w & ~31u) + ((w & 7u) << 2) + ((w >> 3) & 3u));
+    } else cell = blockIdx.x * (blockDim.x >> 6) + wv;
     if (cell >= ncells) return;
     fast_cell_wave<PITCH>(fsm, lane, wv, blockIdx.y, cell, tab, cells, nlevels, img0, img0_stride, img0_frame, pyr, cand,
                           cand_frame_stride, cand_count, iniTh, minTh, tile_rows, sc_rows, kp_cap);
@@ -2013,12 +2021,13 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
     const int tile_rows = max_hcell + 6, sc_rows = max_hcell + 2;
     const int kp_cap = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
     // The waves of a workgroup need nothing from each other, and a four-wave workgroup holds its LDS until its slowest cell is done
-    // (cells differ 3x in work).  One wave (= one cell) per workgroup: 0.2825 -> 0.2715 ms per 256 VGA frames (1.5 - 4 % at 64 - 256
-    // frames); at 1280 x 720 (2,656 cells per frame) four per workgroup stay 1 - 2 % ahead at 16 - 128 frames, so the choice goes by
-    // the frame's cell count -- two measured geometries, no model.  (SLAMIT_FAST_WPB=1|2|4: A/B runs.)
+    // (cells differ 3x in work).  One wave (= one cell) per workgroup, cells dealt to the XCDs in runs of four (fast_cells_kernel):
+    // 0.283 -> 0.278 ms per 256 VGA frames at the same HBM traffic; at 1280 x 720 (2,656 cells per frame) four per workgroup stay
+    // 1 - 2 % ahead at 16 - 128 frames, so the choice goes by the frame's cell count -- two measured geometries, no model.
+    // (SLAMIT_FAST_WPB=1|2|4: A/B runs.)
     static const int wpb_env = getenv("SLAMIT_FAST_WPB") ? atoi(getenv("SLAMIT_FAST_WPB")) : 0;
     const int wpb = wpb_env == 1 || wpb_env == 2 || wpb_env == 4 ? wpb_env : cells_per_frame < 1600 ? 1 : 4;
-    const dim3 grid((cells_per_frame + wpb - 1) / wpb, nframes);
+    const dim3 grid(wpb == 1 ? (unsigned)((cells_per_frame + 31) & ~31) : (unsigned)((cells_per_frame + wpb - 1) / wpb), nframes);
     const size_t smem = orbk_fast_smem(max_wcell, max_hcell) / 4 * wpb;
     FastTab tab = {};
     for (int l = 0; l < nlevels && l < ORB_MAX_LEVELS; ++l) {
