@@ -69,12 +69,12 @@ def measured_traffic(batch):
     try:
         doc = json.load(open(path))
         k = [v for n, v in doc["kernels"].items() if n.startswith("fast_cells_kernel")][0]
-        kb = k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]
+        kb = k.get("FETCH_KB_corrected_x2", k["FETCH_SIZE_KB_per_launch"]) + k["WRITE_SIZE_KB_per_launch"]   # (16-B/lane reads: FETCH_SIZE x 2 on gfx950)
         rel = os.path.relpath(path, ROOT)
         sha = _sha16(os.path.join(ROOT, "weiner_slamit_v2_amd", "csrc", "orb_kernels.hip"))
         if doc.get("kernel_src_sha16") != sha:
             return None, "%s was taken on another version of csrc/orb_kernels.hip (%s, now %s)" % (rel, doc.get("kernel_src_sha16"), sha)
-        return int(kb * 1024 * batch / doc["frames_per_launch"]), "%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch; kernel source %s)" % (rel, sha)
+        return int(kb * 1024 * batch / doc["frames_per_launch"]), "%s (rocprofv3 --pmc FETCH_SIZE x 2 [gfx950: 16-B/lane reads are tallied at half] + WRITE_SIZE, separate passes; bytes per launch; kernel source %s)" % (rel, sha)
     except Exception as e:
         return None, "unreadable %s: %r" % (path, e)
 

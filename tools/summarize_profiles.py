@@ -26,6 +26,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SKIP = ("__amd_rocclr", "at::native", "Cijk", "ncclDevKernel")
+WIDE_READERS = ("fast_cells_kernel", "describe_kernel", "ic_angle_kernel", "resize_rows8_kernel", "hamming_best2_mfma_kernel")   # 16 bytes per lane and load
 
 
 def newest(path, pattern):
@@ -162,12 +163,16 @@ def main():
         if k.startswith(SKIP):
             continue
         kernels[k] = {"FETCH_SIZE_KB_per_launch": round(fetch.get(k, 0.0), 1), "WRITE_SIZE_KB_per_launch": round(write.get(k, 0.0), 1)}
+        # gfx950: FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane reads at 64 bytes (MI355X_MICROARCH.md, HBM): the kernels whose
+        # reads are of that kind (LDS-DMA / dwordx4 window loads) get the doubled figure next to the raw one
+        if k.startswith(WIDE_READERS):
+            kernels[k]["FETCH_KB_corrected_x2"] = round(2 * fetch.get(k, 0.0), 1)
     if kernels:
         doc = {"_about": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --no-ba --no-cpu --steps 3 "
                          "--warmup 1` on MI355X, averaged per launch; %d VGA frames per launch. Units: KB as rocprofv3 reports them "
-                         "(bytes = value*1024). gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide 16-B/lane "
-                         "streaming reads by 2x; these kernels read 1-4 B per lane, an uncalibrated width, so the values are reported "
-                         "as measured." % frames,
+                         "(bytes = value*1024). gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of the bytes of "
+                         "16-B/lane reads; kernels that read that way carry FETCH_KB_corrected_x2 (the others read 4-12 B per lane, an "
+                         "uncalibrated width: as measured)." % frames,
                "frames_per_launch": frames,
                "kernel_src_sha16": sha16(os.path.join(ROOT, "weiner_slamit_v2_amd", "csrc", "orb_kernels.hip")),
                "kernels": kernels}

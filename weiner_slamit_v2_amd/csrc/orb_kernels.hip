@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     const uint8_t* __restrict__ img0, unsigned img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr,
     unsigned long long* __restrict__ cand, size_t cand_frame_stride,
-    int* __restrict__ cand_count, int iniTh, int minTh, int tile_rows, int sc_rows, int kp_cap) {
+    int* __restrict__ cand_count, int iniTh, int minTh, int tile_rows, int sc_rows, int kp_cap, int xcd_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -886,13 +886,18 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     // neighbouring cells share image lines (6-pixel halos inside 128-byte lines) -- dealt cell by cell the launch fetched 545 MB instead of
     // 247 per 256 VGA frames.  So inside every run of 32 cells XCD x takes cells 4 x .. 4 x + 3 (what a four-wave workgroup held), and the
     // XCDs still walk the frame side by side.
-    int cell;
-    if (blockDim.x == 64) {
+    int cell, frame = blockIdx.y;
+    if (xcd_frames) {   // 1-D grid, frames dealt to the XCDs: an XCD walks its frames one after the other, cell by cell
+        const unsigned w = blockIdx.x, k = w >> 3, wpb = blockDim.x >> 6, P = ((unsigned)ncells + wpb - 1) / wpb, fq = k / P, local = k - fq * P;
+        frame = (int)(8u * fq + (w & 7u));
+        if (frame >= xcd_frames) return;
+        cell = (int)(local * wpb) + wv;
+    } else if (blockDim.x == 64) {
         const unsigned w = blockIdx.x;
         cell = (int)((w & ~31u) + ((w & 7u) << 2) + ((w >> 3) & 3u));
     } else cell = blockIdx.x * (blockDim.x >> 6) + wv;
     if (cell >= ncells) return;
-    fast_cell_wave<PITCH>(fsm, lane, wv, blockIdx.y, cell, tab, cells, nlevels, img0, img0_stride, img0_frame, pyr, cand,
+    fast_cell_wave<PITCH>(fsm, lane, wv, frame, cell, tab, cells, nlevels, img0, img0_stride, img0_frame, pyr, cand,
                           cand_frame_stride, cand_count, iniTh, minTh, tile_rows, sc_rows, kp_cap);
 }
 
@@ -1413,12 +1418,18 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
     const OrbLevel* __restrict__ levels, int nlevels,
     const uint8_t* __restrict__ img0, size_t img0_stride, size_t img0_frame,
     const uint8_t* __restrict__ pyr,
-    OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, const int* __restrict__ kp_count) {
+    OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, const int* __restrict__ kp_count, int xcd_frames, int kblocks) {
     const int lane = threadIdx.x & 63;
-    const int level = blockIdx.y, frame = blockIdx.z;
+    int level, frame, kb;
+    if (xcd_frames) {   // 1-D grid, frames dealt to the XCDs (see describe_kernel)
+        const unsigned w = blockIdx.x, k = w >> 3, P = (unsigned)(nlevels * kblocks), fq = k / P, local = k - fq * P;
+        frame = (int)(8u * fq + (w & 7u));
+        if (frame >= xcd_frames) return;
+        level = (int)(local / (unsigned)kblocks); kb = (int)(local - (unsigned)level * (unsigned)kblocks);
+    } else { level = blockIdx.y; frame = blockIdx.z; kb = blockIdx.x; }
     const OrbLevel& L = levels[level];
     const int count = kp_count[frame * nlevels + level];
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * IC_KP_PER_WAVE;
+    const int i0 = (kb * 4 + (threadIdx.x >> 6)) * IC_KP_PER_WAVE;
     if (i0 >= count) return;
     const uint8_t* src;
     int stride;
@@ -1793,10 +1804,19 @@ __global__ __launch_bounds__(256) void describe_kernel(
     const uint8_t* __restrict__ blur,
     const OrbLevelKp* __restrict__ lkp, size_t kp_frame_stride, const int* __restrict__ kp_count,
     slamit_kp* __restrict__ out_kps, uint8_t* __restrict__ out_desc, int out_cap,
-    int* __restrict__ out_n) {
+    int* __restrict__ out_n, int xcd_frames /* 0: grid (blocks, levels, frames); else the frame count of a 1-D grid */, int kblocks) {
     const int lane = threadIdx.x & 63;
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_KP_PER_WAVE;
-    const int level = blockIdx.y, frame = blockIdx.z;
+    int level, frame, kb;
+    if (xcd_frames) {
+        // 1-D grid, frames dealt to the XCDs: consecutive workgroup ids go to consecutive XCDs (an L2 each), so workgroup w works on frame
+        // 8 (k / P) + (w & 7) with k = w >> 3 and P workgroups per frame -- an XCD walks ITS frames one after the other and the patches of
+        // a frame's neighbouring keypoints meet in one L2 instead of eight
+        const unsigned w = blockIdx.x, k = w >> 3, P = (unsigned)(nlevels * kblocks), fq = k / P, local = k - fq * P;
+        frame = (int)(8u * fq + (w & 7u));
+        if (frame >= xcd_frames) return;
+        level = (int)(local / (unsigned)kblocks); kb = (int)(local - (unsigned)level * (unsigned)kblocks);
+    } else { level = blockIdx.y; frame = blockIdx.z; kb = blockIdx.x; }
+    const int i0 = (kb * 4 + (threadIdx.x >> 6)) * DESC_KP_PER_WAVE;
     const OrbLevel& L = levels[level];
     const int* counts = kp_count + frame * nlevels;
     int offset = 0, total = 0;
@@ -2027,7 +2047,10 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
     // (SLAMIT_FAST_WPB=1|2|4: A/B runs.)
     static const int wpb_env = getenv("SLAMIT_FAST_WPB") ? atoi(getenv("SLAMIT_FAST_WPB")) : 0;
     const int wpb = wpb_env == 1 || wpb_env == 2 || wpb_env == 4 ? wpb_env : cells_per_frame < 1600 ? 1 : 4;
-    const dim3 grid(wpb == 1 ? (unsigned)((cells_per_frame + 31) & ~31) : (unsigned)((cells_per_frame + wpb - 1) / wpb), nframes);
+    static const int xcd_env = getenv("SLAMIT_XCD_FRAMES") ? atoi(getenv("SLAMIT_XCD_FRAMES")) : 1;
+    const int xcd_frames = xcd_env && nframes >= 16 ? nframes : 0;
+    const dim3 grid = xcd_frames ? dim3((unsigned)(((nframes + 7) / 8) * 8) * (unsigned)((cells_per_frame + wpb - 1) / wpb))
+                                 : dim3(wpb == 1 ? (unsigned)((cells_per_frame + 31) & ~31) : (unsigned)((cells_per_frame + wpb - 1) / wpb), nframes);
     const size_t smem = orbk_fast_smem(max_wcell, max_hcell) / 4 * wpb;
     FastTab tab = {};
     for (int l = 0; l < nlevels && l < ORB_MAX_LEVELS; ++l) {
@@ -2040,11 +2063,11 @@ void orbk_fast(hipStream_t st, const OrbLevel* host_levels, int nlevels, const u
     if (fast_pitch(max_wcell) == FAST_PS)
         hipLaunchKernelGGL(fast_cells_kernel<FAST_PS>, grid, dim3(64 * wpb), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
                            (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
-                           sc_rows, kp_cap);
+                           sc_rows, kp_cap, xcd_frames);
     else
         hipLaunchKernelGGL(fast_cells_kernel<FAST_PL>, grid, dim3(64 * wpb), smem, st, tab, reinterpret_cast<const uint4*>(d_cells), nlevels, cells_per_frame, img0,
                            (unsigned)img0_stride, img0_frame, pyr, cand, cand_frame_stride, cand_count, iniTh, minTh, tile_rows,
-                           sc_rows, kp_cap);
+                           sc_rows, kp_cap, xcd_frames);
 }
 
 // candidates kept in LDS: as many as fit beside the node arrays in half a CU's LDS (lists above that use the HBM workspace)
@@ -2107,8 +2130,14 @@ void orbk_octree(hipStream_t st, const OrbLevel* levels, int nlevels, const unsi
 void orbk_ic_angle(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* img0,
                    size_t img0_stride, size_t img0_frame, const uint8_t* pyr, OrbLevelKp* lkp,
                    size_t kp_frame_stride, const int* kp_count, int max_kp, int nframes) {
-    hipLaunchKernelGGL(ic_angle_kernel, dim3((max_kp + 4 * IC_KP_PER_WAVE - 1) / (4 * IC_KP_PER_WAVE), nlevels, nframes), dim3(256), 0, st, levels,
-                       nlevels, img0, img0_stride, img0_frame, pyr, lkp, kp_frame_stride, kp_count);
+    const int kblocks = (max_kp + 4 * IC_KP_PER_WAVE - 1) / (4 * IC_KP_PER_WAVE);
+    static const int xcd_env = getenv("SLAMIT_XCD_FRAMES") ? atoi(getenv("SLAMIT_XCD_FRAMES")) : 1;
+    if (xcd_env && nframes >= 16)
+        hipLaunchKernelGGL(ic_angle_kernel, dim3((unsigned)(((nframes + 7) / 8) * 8 * nlevels * kblocks)), dim3(256), 0, st, levels,
+                           nlevels, img0, img0_stride, img0_frame, pyr, lkp, kp_frame_stride, kp_count, nframes, kblocks);
+    else
+        hipLaunchKernelGGL(ic_angle_kernel, dim3(kblocks, nlevels, nframes), dim3(256), 0, st, levels,
+                           nlevels, img0, img0_stride, img0_frame, pyr, lkp, kp_frame_stride, kp_count, 0, kblocks);
 }
 
 // Strip table of blur_all_kernel: (level, bx, by0, 0) for every 64 x 64 strip of every level, level-major
@@ -2158,8 +2187,14 @@ void orbk_blur(hipStream_t st, const OrbLevel* levels, const uint32_t* d_tiles, 
 void orbk_describe(hipStream_t st, const OrbLevel* levels, int nlevels, const uint8_t* blur,
                    const OrbLevelKp* lkp, size_t kp_frame_stride, const int* kp_count, slamit_kp* out_kps,
                    uint8_t* out_desc, int out_cap, int* out_n, int max_kp, int nframes) {
-    hipLaunchKernelGGL(describe_kernel, dim3((max_kp + 4 * DESC_KP_PER_WAVE - 1) / (4 * DESC_KP_PER_WAVE), nlevels, nframes), dim3(256), 0, st, levels,
-                       nlevels, blur, lkp, kp_frame_stride, kp_count, out_kps, out_desc, out_cap, out_n);
+    const int kblocks = (max_kp + 4 * DESC_KP_PER_WAVE - 1) / (4 * DESC_KP_PER_WAVE);
+    static const int xcd_env = getenv("SLAMIT_XCD_FRAMES") ? atoi(getenv("SLAMIT_XCD_FRAMES")) : 1;   // 0: the (blocks, levels, frames) grid (A/B runs)
+    if (xcd_env && nframes >= 16)
+        hipLaunchKernelGGL(describe_kernel, dim3((unsigned)(((nframes + 7) / 8) * 8 * nlevels * kblocks)), dim3(256), 0, st, levels,
+                           nlevels, blur, lkp, kp_frame_stride, kp_count, out_kps, out_desc, out_cap, out_n, nframes, kblocks);
+    else
+        hipLaunchKernelGGL(describe_kernel, dim3(kblocks, nlevels, nframes), dim3(256), 0, st, levels,
+                           nlevels, blur, lkp, kp_frame_stride, kp_count, out_kps, out_desc, out_cap, out_n, 0, kblocks);
 }
 
 void orbk_pad(hipStream_t st, const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst) {
