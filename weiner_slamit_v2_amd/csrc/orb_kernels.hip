@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(
     int cell, frame = blockIdx.y;
     if (xcd_frames) {   // 1-D grid, frames dealt to the XCDs: an XCD walks its frames one after the other, cell by cell
         const unsigned w = blockIdx.x, k = w >> 3, wpb = blockDim.x >> 6, P = ((unsigned)ncells + wpb - 1) / wpb, fq = k / P, local = k - fq * P;
-        frame = (int)(8u * fq + (w & 7u));
+        frame = (int)(8u * fq + ((w + fq) & 7u));   // (rotated per group of eight frames: an XCD does not keep meeting every eighth frame of a periodic input)
         if (frame >= xcd_frames) return;
         cell = (int)(local * wpb) + wv;
     } else if (blockDim.x == 64) {
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(256) void ic_angle_kernel(
     int level, frame, kb;
     if (xcd_frames) {   // 1-D grid, frames dealt to the XCDs (see describe_kernel)
         const unsigned w = blockIdx.x, k = w >> 3, P = (unsigned)(nlevels * kblocks), fq = k / P, local = k - fq * P;
-        frame = (int)(8u * fq + (w & 7u));
+        frame = (int)(8u * fq + ((w + fq) & 7u));   // (rotated per group of eight frames: an XCD does not keep meeting every eighth frame of a periodic input)
         if (frame >= xcd_frames) return;
         level = (int)(local / (unsigned)kblocks); kb = (int)(local - (unsigned)level * (unsigned)kblocks);
     } else { level = blockIdx.y; frame = blockIdx.z; kb = blockIdx.x; }
@@ -1812,7 +1812,7 @@ __global__ __launch_bounds__(256) void describe_kernel(
         // 8 (k / P) + (w & 7) with k = w >> 3 and P workgroups per frame -- an XCD walks ITS frames one after the other and the patches of
         // a frame's neighbouring keypoints meet in one L2 instead of eight
         const unsigned w = blockIdx.x, k = w >> 3, P = (unsigned)(nlevels * kblocks), fq = k / P, local = k - fq * P;
-        frame = (int)(8u * fq + (w & 7u));
+        frame = (int)(8u * fq + ((w + fq) & 7u));   // (rotated per group of eight frames: an XCD does not keep meeting every eighth frame of a periodic input)
         if (frame >= xcd_frames) return;
         level = (int)(local / (unsigned)kblocks); kb = (int)(local - (unsigned)level * (unsigned)kblocks);
     } else { level = blockIdx.y; frame = blockIdx.z; kb = blockIdx.x; }
