@@ -164,6 +164,21 @@ def test_large_batch_launch_shape_is_bit_exact():
     assert len(ext.debug_candidates(0, 0)) > 2048
 
 
+def test_batch_sizes_around_the_xcd_grids():
+    """From 16 frames per call the FAST, orientation and descriptor launches are 1-D grids that deal whole frames to the eight XCDs
+    (frame = 8 (k / P) + ((w + k / P) mod 8)); frame counts that are no multiple of eight leave padding workgroups that must do nothing, and
+    smaller calls keep the (work, frames) grids: every slot of 15, 16, 20 and 27 frames equals the same frame extracted alone."""
+    kinds = [synth.synth_frame(640, 480, 44 + i) for i in range(3)]
+    one = api.ORBextractor(1000, 1.2, 8, 20, 7)
+    want = [one(f) for f in kinds]
+    for n in (15, 16, 20, 27):
+        frames = np.stack([kinds[i % 3] for i in range(n)])
+        ext = api.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=n)
+        ks, ds = ext.extract_batch(frames)
+        for i in range(n):
+            assert np.array_equal(ks[i], want[i % 3][0]) and np.array_equal(ds[i], want[i % 3][1]), (n, i)
+
+
 def test_device_buffer_entry_point():
     import torch
 
