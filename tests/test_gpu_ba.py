@@ -55,7 +55,7 @@ def _close(res, ref, tag, counts=True, prob=None):
             assert np.allclose(s["lambda"][st], r["lambda"][st], rtol=0.7 if stereo else 1e-3), tag
         for st in range(2):  # the start cost is only evaluated for a stage that iterates
             if r["n_its"][st] > 0:
-                assert np.isclose(s["chi2_init"][st], r["chi2_init"][st], rtol=1e-8), tag
+                assert np.isclose(s["chi2_init"][st], r["chi2_init"][st], rtol=1e-5 if stereo else 1e-8), tag   # (stereo: the bound of the chi2 sequence above)
 
 
 @pytest.fixture(scope="module")
@@ -127,6 +127,46 @@ def test_banded_windows_in_lds_and_through_the_blocked_path(opt, k, p, o, seed, 
     assert np.abs(res["kf_pose"] - d["kf_pose"]).max() / scale <= 1e-7
     assert np.abs(res["pt_xyz"] - d["pt_xyz"]).max() / max(np.abs(d["pt_xyz"]).max(), 1.0) <= 1e-7
     assert (res["edge_outlier"] == d["edge_outlier"]).all() and list(d["n_its"]) == list(res["stats"]["n_its"])
+
+
+def test_schur_over_floating_windows_and_over_tile_pairs(monkeypatch):
+    """The Schur product of a window whose k slabs each touch <= 63 rows runs over floating row windows (BaWin::sf_*, csrc/ba_api.hip:
+    groups of slabs, one 64 x 64 partial tile each); SLAMIT_BA_SF=0 sends the same window through the 64 x 64 tile pairs.  Both give the
+    same poses, points, flags and LM path, the floating form executes fewer flops, and a window it cannot take (dense visibility; ten keyframes
+    per point: a slab's rows span 66; more groups than the launch has workgroups) falls back inside the same batch.  Window widths 2 .. 10 keyframes, ragged system sizes, fixed
+    keyframes in front, a stereo window, and SLAMIT_BA_SF_CAP = 1 / 64 (one slab per group / as many as the rows allow)."""
+    probs = [synth.synth_ba(50, 2000, 8, seed=12345, n_fixed=2), synth.synth_ba(50, 1200, 3, seed=41), synth.synth_ba(50, 1500, 10, seed=42, n_fixed=3),
+             synth.synth_ba(12, 300, 4, seed=43), synth.synth_ba(41, 900, 5, seed=45), synth.synth_ba(50, 1000, 2, seed=47), synth.synth_ba(23, 500, 9, seed=48),
+             synth.synth_ba(50, 500, None, seed=22), synth.synth_ba(5, 1500, 2, seed=49), synth.synth_ba(30, 800, 6, seed=44, stereo_frac=0.6)]
+    probs += [synth.synth_ba(10 + 2 * i, 150 + 30 * i, 3 + i, seed=60 + i) for i in range(6)]   # 16 windows: a batch's launch shapes (eight splits, pose blocks on their own)
+    opt = api.Optimizer(max_kf=64, max_pt=2048, max_edge=110000, max_batch=16)
+
+    def run(**env):
+        for k in ("SLAMIT_BA_SF", "SLAMIT_BA_SF_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        opt.profile(True)
+        single = [opt.LocalBundleAdjustment(probs[0])]
+        mflop1 = opt.profile_read()["schur_exec_mflop"]   # (of the window-8 window)
+        single += [opt.LocalBundleAdjustment(q) for q in probs[1:3]]
+        batch = opt.LocalBundleAdjustmentBatch(probs)
+        opt.profile(False)
+        return single, batch, mflop1
+
+    s_tile, b_tile, m_tile = run(SLAMIT_BA_SF="0")
+    for env in ({}, {"SLAMIT_BA_SF_CAP": "1"}, {"SLAMIT_BA_SF_CAP": "64"}):
+        s_sf, b_sf, m_sf = run(**env)
+        assert m_sf < 0.5 * m_tile, (env, m_sf, m_tile)
+        for i, (a, b) in enumerate(list(zip(s_sf, s_tile)) + list(zip(b_sf, b_tile))):
+            scale = max(np.abs(b["kf_pose"]).max(), 1.0)
+            tol = 3e-5 if i == len(s_sf) + 9 else 1e-7   # (the stereo window: the float projection's noise, _close)
+            assert np.abs(a["kf_pose"] - b["kf_pose"]).max() / scale <= tol, (env, i)
+            assert np.abs(a["pt_xyz"] - b["pt_xyz"]).max() / max(np.abs(b["pt_xyz"]).max(), 1.0) <= tol, (env, i)
+            assert (a["edge_outlier"] == b["edge_outlier"]).all() and a["stats"]["n_its"] == b["stats"]["n_its"] and a["stats"]["trials"] == b["stats"]["trials"], (env, i)
+    for i, (q, o) in enumerate(zip(probs, b_sf)):
+        _close(o, ob.ba_solve(q), "sf[%d]" % i, prob=q)
+    opt.close()
 
 
 def test_config4_dense_50kf_2000pt(opt):

@@ -27,6 +27,7 @@ void bak_import(hipStream_t st, BaWin* wins, const BaIo* io, int max_kf, int max
 void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int stage, int max_it, int robust, bool gate);
 void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, unsigned solvers, hipEvent_t* ev);
 int bak_solver_kind(int n, int band);
+int bak_nsplit(int nwin);
 void bak_final(hipStream_t st, BaWin* wins, const BaIo* io, int nwin, int max_kf, int max_pt, int max_edge);
 
 static_assert(BA_MAX_ITS == SLAMIT_BA_MAX_ITS, "stats capacity");
@@ -327,6 +328,66 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
             for (int c = 0; c < nfree; ++c) band = std::max(band, 6 * c + 5 - 6 * fcol[c]);
             w.band = std::min(band, std::max(n - 1, 0));
             w.solver = bak_solver_kind(n, w.band);
+            // ---- the Schur product over floating row windows (BaWin::sf_*), when every k slab's rows fit one ----
+            w.sf_groups = 0;
+            const char* sf_env = getenv("SLAMIT_BA_SF");        // 0: always the tiled product (A/B runs and the tests that compare the two)
+            const char* cap_env = getenv("SLAMIT_BA_SF_CAP");   // slabs per group
+            if (!(sf_env && atoi(sf_env) == 0) && nfree > 0) {
+                const int nslab_all = w.Kpad / BA_KC;
+                std::vector<int32_t> slo(nslab_all, INT32_MAX), shi(nslab_all, -1);
+                for (int pn = 0; pn < P.n_pt; ++pn) {
+                    const int po = new2old[pn];
+                    if (maxc[po] < 0) continue;   // no free keyframe observes it: its columns stay zero
+                    for (int j = 0; j < 3; ++j) {
+                        const int sl = (3 * pn + j) / BA_KC;
+                        slo[sl] = std::min(slo[sl], 6 * minc[po]); shi[sl] = std::max(shi[sl], 6 * maxc[po] + 5);
+                    }
+                }
+                // a single window wants many short workgroups (latency), a batch fewer partial tiles to write and to add
+                const int cap = cap_env && atoi(cap_env) > 0 ? atoi(cap_env) : nwin >= 16 ? 8 : 4;
+                const int maxg = (int)std::min<size_t>(std::min<size_t>(BA_SF_MAXG, (size_t)BA_SPLITS * h->Npad_max * h->Npad_max / (BA_TILE * BA_TILE)),   // what `part` holds
+                                                       (size_t)(T * (T + 1) / 2) * bak_nsplit(nwin));                                          // workgroups of the launch
+                bool ok = true;
+                int G = 0, cnt = 0, clo = 0, chi = 0, kstart = 0;
+                auto close = [&](int kend) {
+                    if (!cnt) return;
+                    if (G == maxg) { ok = false; return; }
+                    w.sf_row[G] = (int16_t)clo; w.sf_k0[G] = (int16_t)kstart; w.sf_k1[G] = (int16_t)kend;
+                    ++G; cnt = 0;
+                };
+                for (int sl = 0; sl < nslab_all && ok; ++sl) {
+                    if (shi[sl] < 0) { close(sl); continue; }
+                    if (shi[sl] - slo[sl] + 1 > BA_SF_ROWS || nslab_all > INT16_MAX) { ok = false; break; }
+                    if (cnt && (std::max(chi, shi[sl]) - std::min(clo, slo[sl]) + 1 > BA_SF_ROWS || cnt == cap)) close(sl);
+                    if (!cnt) { clo = slo[sl]; chi = shi[sl]; kstart = sl; }
+                    else { clo = std::min(clo, slo[sl]); chi = std::max(chi, shi[sl]); }
+                    ++cnt;
+                }
+                if (ok) close(nslab_all);
+                for (int g = 1; g < G && ok; ++g) if (w.sf_row[g] < w.sf_row[g - 1]) ok = false;   // (sorted points: cannot happen)
+                if (ok && G > 0) {
+                    w.sf_groups = G;
+                    int ga = 0, gb = -1;   // groups whose window reaches row r (first) / has begun at row r (last)
+                    for (int r = 0; r < w.Npad; ++r) {
+                        while (ga < G && w.sf_row[ga] + BA_SF_ROWS - 1 < r) ++ga;
+                        while (gb + 1 < G && w.sf_row[gb + 1] <= r) ++gb;
+                        w.sf_glo[r] = (int16_t)ga; w.sf_ghi[r] = (int16_t)gb;
+                    }
+                    // what k_zero_operands clears once per solve has to cover what the windows read
+                    for (int g = 0; g < G; ++g) {
+                        const int t0 = w.sf_row[g] / BA_TILE, t1 = std::min(w.sf_row[g] + BA_SF_ROWS - 1, w.Npad - 1) / BA_TILE;
+                        for (int t = t0; t <= t1; ++t) {
+                            const int lo = w.sf_k0[g] * BA_KC, hi = w.sf_k1[g] * BA_KC;
+                            if (w.tile_ahi[t] <= w.tile_alo[t]) { w.tile_alo[t] = lo; w.tile_ahi[t] = hi; }
+                            else { w.tile_alo[t] = std::min(w.tile_alo[t], lo); w.tile_ahi[t] = std::max(w.tile_ahi[t], hi); }
+                            if (w.tile_bhi[t] <= w.tile_blo[t]) { w.tile_blo[t] = lo; w.tile_bhi[t] = hi; }
+                            else { w.tile_blo[t] = std::min(w.tile_blo[t], lo); w.tile_bhi[t] = std::max(w.tile_bhi[t], hi); }
+                        }
+                        exec_mflop[b] += 2.0 * BA_TILE * BA_TILE * BA_KC * (w.sf_k1[g] - w.sf_k0[g]) * 1e-6;
+                    }
+                }
+            }
+            if (!w.sf_groups)
             for (int I = 0; I < T; ++I)   // the product's granule: 64 x 64 tile pairs (I <= J) over the k range both have non-zeros in,
                 for (int J = I; J < T; ++J) {   // less the tiles a banded window's solver never reads (schur_tile_needed, ba_kernels.hip)
                     if (w.solver == BA_SOLVER_BAND && BA_TILE * J - (BA_TILE * I + BA_TILE - 1) > w.band && w.nS / BA_TILE != J) continue;

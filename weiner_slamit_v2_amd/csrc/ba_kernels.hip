@@ -38,6 +38,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // flat_load / flat_store, which also counts in lgkmcnt -- so each LDS wait of a software pipeline waits for the
 // prefetched HBM data as well.  The hot kernels cast their matrices to the global address space once.
 typedef __attribute__((address_space(1))) double gdouble;
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 #include "se3_device.h"
 
@@ -518,53 +519,72 @@ __device__ __forceinline__ bool schur_tile_needed(const BaWin& W, int I, int J) 
 __device__ __forceinline__ void schur_body(const BaWin& W, const BaState* st, int tile, int s, int nsplit) {
     if (st->done) return;
     const int T = W.Npad / BA_TILE;
-    // `tile` enumerates upper-triangular macro tiles
-    int I = 0, rem = tile;
-    while (I < T && rem >= T - I) { rem -= T - I; ++I; }
-    const int J = I + rem;
-    if (I >= T || !schur_tile_needed(W, I, J)) return;
-    // Only the k range in which BOTH row tiles have non-zeros is multiplied (points are sorted by their first observing
-    // keyframe, ba_api.hip): its slabs of BA_KC are dealt to the launch's nsplit <= BA_SPLITS splits (gridDim.y: sixteen for a single
-    // window, which needs the parallelism; eight for a batch, whose windows already fill the chip -- half of the partial
-    // tiles to write and to sum); a split without a slab stores zeros.
-    const int klo = max(W.tile_alo[I], W.tile_blo[J]), khi = min(W.tile_ahi[I], W.tile_bhi[J]);
-    const int nslab = khi > klo ? (khi - klo) / BA_KC : 0;
-    const int k0 = klo + (int)((long)nslab * s / nsplit) * BA_KC, kend = klo + (int)((long)nslab * (s + 1) / nsplit) * BA_KC;
-    __shared__ double As[BA_TILE * LDS_PITCH];
-    __shared__ double Bs[BA_TILE * LDS_PITCH];
+    // What the workgroup multiplies: rows rbaseA + r of GA against rows rbaseB + r of GB (r = 0 .. 63; rows past the matrix are read as its
+    // last row -- zeros in GA, and a column of the result nobody reads in GB --, row 63 of the B operand is row lastB) over the k range
+    // [k0, kend), into the 64 x 64 tile at `out` (row pitch opitch).
+    int rbaseA, rbaseB, lastB, k0, kend, opitch;
+    gdouble* out;
+    if (W.sf_groups) {
+        // floating row windows (BaWin::sf_*): group g = the launch's workgroup number inside the window
+        const int g = tile * nsplit + s;
+        if (g >= W.sf_groups) return;
+        rbaseA = rbaseB = W.sf_row[g]; lastB = W.nS;
+        k0 = W.sf_k0[g] * BA_KC; kend = W.sf_k1[g] * BA_KC;
+        out = (gdouble*)W.part + (size_t)g * (BA_TILE * BA_TILE); opitch = BA_TILE;
+    } else {
+        // `tile` enumerates upper-triangular macro tiles
+        int I = 0, rem = tile;
+        while (I < T && rem >= T - I) { rem -= T - I; ++I; }
+        const int J = I + rem;
+        if (I >= T || !schur_tile_needed(W, I, J)) return;
+        // Only the k range in which BOTH row tiles have non-zeros is multiplied (points are sorted by their first observing
+        // keyframe, ba_api.hip): its slabs of BA_KC are dealt to the launch's nsplit <= BA_SPLITS splits (gridDim.y: sixteen for a single
+        // window, which needs the parallelism; eight for a batch, whose windows already fill the chip -- half of the partial
+        // tiles to write and to sum); a split without a slab stores zeros.
+        const int klo = max(W.tile_alo[I], W.tile_blo[J]), khi = min(W.tile_ahi[I], W.tile_bhi[J]);
+        const int nslab = khi > klo ? (khi - klo) / BA_KC : 0;
+        k0 = klo + (int)((long)nslab * s / nsplit) * BA_KC; kend = klo + (int)((long)nslab * (s + 1) / nsplit) * BA_KC;
+        rbaseA = I * BA_TILE; rbaseB = J * BA_TILE; lastB = J * BA_TILE + BA_TILE - 1;
+        out = (gdouble*)W.part + (size_t)s * W.Npad * W.Npad + (size_t)(I * BA_TILE) * W.Npad + J * BA_TILE; opitch = W.Npad;
+    }
+    __shared__ __attribute__((aligned(16))) double As[BA_TILE * LDS_PITCH];
+    __shared__ __attribute__((aligned(16))) double Bs[BA_TILE * LDS_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t K = (size_t)W.Kpad;
-    const gdouble* A = (const gdouble*)W.GA + (size_t)(I * BA_TILE) * K;
-    const gdouble* B = (const gdouble*)W.GB + (size_t)(J * BA_TILE) * K;
     double4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0, 0, 0, 0};
-    // software pipeline: the next slab is fetched into registers while the current one feeds the MFMAs
-    double pa[8], pb[8];
+    // software pipeline: the next slab is fetched into registers while the current one feeds the MFMAs; 16 bytes per lane and load
+    // (a slab row is 32 doubles = 16 lanes; k ranges are multiples of BA_KC, Kpad of BA_KC * BA_SPLITS, so every address is 16-byte aligned)
+    typedef __attribute__((address_space(1))) double2_t gdouble2s;
+    const gdouble2s* srcA[4];
+    const gdouble2s* srcB[4];
+    {
+        const int lastrow = W.Npad - 1, c = (tid & 15) * 2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = (tid >> 4) + 16 * u;
+            srcA[u] = (const gdouble2s*)((const gdouble*)W.GA + (size_t)min(rbaseA + r, lastrow) * K + c);
+            srcB[u] = (const gdouble2s*)((const gdouble*)W.GB + (size_t)(r == BA_TILE - 1 ? lastB : min(rbaseB + r, lastrow)) * K + c);
+        }
+    }
+    double2_t pa[4], pb[4];
     if (kend > k0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = tid + 256 * u, r = i >> 5, c = i & 31;
-            pa[u] = A[(size_t)r * K + k0 + c];
-            pb[u] = B[(size_t)r * K + k0 + c];
-        }
+        for (int u = 0; u < 4; ++u) { pa[u] = srcA[u][k0 >> 1]; pb[u] = srcB[u][k0 >> 1]; }
     }
     for (int kk = k0; kk < kend; kk += BA_KC) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = tid + 256 * u, r = i >> 5, c = i & 31;
-            As[r * LDS_PITCH + c] = pa[u];
-            Bs[r * LDS_PITCH + c] = pb[u];
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, c = (i & 15) * 2;
+            *reinterpret_cast<double2_t*>(&As[r * LDS_PITCH + c]) = pa[u];
+            *reinterpret_cast<double2_t*>(&Bs[r * LDS_PITCH + c]) = pb[u];
         }
         __syncthreads();
         if (kk + BA_KC < kend) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = tid + 256 * u, r = i >> 5, c = i & 31;
-                pa[u] = A[(size_t)r * K + kk + BA_KC + c];
-                pb[u] = B[(size_t)r * K + kk + BA_KC + c];
-            }
+            for (int u = 0; u < 4; ++u) { pa[u] = srcA[u][(kk + BA_KC) >> 1]; pb[u] = srcB[u][(kk + BA_KC) >> 1]; }
         }
 #pragma unroll
         for (int ks = 0; ks < BA_KC; ks += 4) {
@@ -577,15 +597,11 @@ __device__ __forceinline__ void schur_body(const BaWin& W, const BaState* st, in
         }
     }
     // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
-    gdouble* P = (gdouble*)W.part + (size_t)s * W.Npad * W.Npad;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = I * BA_TILE + 16 * wv + (lane >> 4) + 4 * r;
-            const int col = J * BA_TILE + 16 * j + (lane & 15);
-            P[(size_t)row * W.Npad + col] = acc[j][r];
-        }
+        for (int r = 0; r < 4; ++r)
+            out[(size_t)(16 * wv + (lane >> 4) + 4 * r) * opitch + 16 * j + (lane & 15)] = acc[j][r];
 }
 
 __global__ __launch_bounds__(256) void k_schur(BaWin* wins) { schur_body(wins[blockIdx.z], BA_ST(wins, blockIdx.z), blockIdx.x, blockIdx.y, gridDim.y); }
@@ -602,19 +618,53 @@ __host__ __device__ inline int ldlt_band_rs(int bw);
 __host__ __device__ inline bool ldlt_band_ok(int n, int bw);
 
 // ---- S7: S = Hpp + lambda*I - sum_s part[s],  b_s = bp - coeff --------------------------------------
+// A window of the blocked solver: thread -> entry (r, c) of the upper triangle, the full matrix is written (both halves).  A banded
+// window: ONE WAVE PER ROW -- lanes 0 .. band are the row's entries r .. r + band, lane 63 its right-hand side (band <= 59) -- and only the
+// solver's LDS image is written: as thread -> entry, four waves of five held no entry of the band (one launch of a batch of 64: 62 us).
+// The partial sums are added in split order whatever the mapping.
 __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins, int nsplit) {
     const BaWin& W = wins[blockIdx.y];
     BaState* st = BA_ST(wins, blockIdx.y);
     if (st->done) return;
     const int n = W.nS, N = W.Npad;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int r = idx / N, c = idx - r * N;
-    if (r >= n || c > n || c < r) return;
-    // a banded window's solver only reads the band (and the right-hand side): the entries beyond are neither summed nor stored
-    if (W.solver == BA_SOLVER_BAND && c - r > W.band && c != n) return;
+    const bool banded = W.solver == BA_SOLVER_BAND;
+    int r, c;
+    if (banded) {
+        const int lane = threadIdx.x & 63;
+        r = blockIdx.x * 4 + (threadIdx.x >> 6);
+        c = lane == 63 ? n : r + lane;
+        if (r >= n || (lane != 63 && (lane > W.band || c >= n))) return;
+    } else {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        r = idx / N; c = idx - r * N;
+        if (r >= n || c > n || c < r) return;
+    }
     double v = 0;
-    if (schur_tile_needed(W, r / BA_TILE, c / BA_TILE))   // (else the product's block is zero and no workgroup wrote its partials)
-        for (int s = 0; s < nsplit; ++s) v += W.part[(size_t)s * N * N + (size_t)r * N + c];
+    if (W.sf_groups) {
+        // floating windows: the tiles of the groups that hold both rows (the right-hand side: row r), in group order
+        const int g0 = c == n ? W.sf_glo[r] : W.sf_glo[c], g1 = W.sf_ghi[r];
+        const gdouble* part = (const gdouble*)W.part;
+        for (int q = g0; q <= g1; q += 4) {   // four loads in flight; a group behind the last adds 0
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = min(q + u, g1), lo = W.sf_row[g];
+                x[u] = part[(size_t)g * (BA_TILE * BA_TILE) + (r - lo) * BA_TILE + (c == n ? BA_TILE - 1 : c - lo)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v += q + u <= g1 ? x[u] : 0.0;
+        }
+    } else if (schur_tile_needed(W, r / BA_TILE, c / BA_TILE)) {   // (else the product's block is zero and no workgroup wrote its partials)
+        const gdouble* p = (const gdouble*)W.part + (size_t)r * N + c;
+        const size_t NN = (size_t)N * N;
+        for (int s0 = 0; s0 < nsplit; s0 += 4) {   // four loads in flight; a split behind the last adds 0
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = p[(size_t)min(s0 + u, nsplit - 1) * NN];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v += s0 + u < nsplit ? x[u] : 0.0;
+        }
+    }
     if (c == n) {
         W.rhs[r] = W.bp[r] - v;  // _bschur = _b - coefficients
         return;
@@ -625,11 +675,13 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BaWin* wins, int nsplit) {
         if (r == c) hv += st->lambda;
     }
     const double sv = hv - v;
-    W.S[(size_t)r * N + c] = sv;
-    W.S[(size_t)c * N + r] = sv;
-    // a banded window's solve reads its LDS image instead: entry (row c, column r) of the lower band (ldlt_band_solve's layout)
-    const int bw = W.band;
-    if (W.solver == BA_SOLVER_BAND && c - r <= bw) W.Sb[(size_t)c * ldlt_band_rs(bw) + (r - c + bw + 3)] = sv;
+    if (banded) {   // entry (row c, column r) of the lower band in ldlt_band_solve's layout; nobody reads S
+        const int bw = W.band;
+        W.Sb[(size_t)c * ldlt_band_rs(bw) + (r - c + bw + 3)] = sv;
+    } else {
+        W.S[(size_t)r * N + c] = sv;
+        W.S[(size_t)c * N + r] = sv;
+    }
 }
 
 // ---- S8: dense blocked LDLt (no pivoting) of the reduced system + solve, one workgroup -------------
@@ -866,7 +918,6 @@ __device__ __forceinline__ void ldlt_piv4(const double* e, int nv, double* G, bo
     G[12] = -g03; G[13] = -g13; G[14] = -g23; G[15] = -g33;
 }
 
-typedef double double2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void ldlt_band_solve(const BaWin& W, BaState* st, double* sm, int* s_fail) {
     const int n = W.nS, N = W.Npad, bw = W.band, RS = ldlt_band_rs(bw);
@@ -1701,6 +1752,13 @@ void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int st
     hipLaunchKernelGGL(k_stage_begin2, dim3(1, nwin), dim3(256), 0, st, wins);
 }
 
+// split-K of the tiled Schur product (gridDim.y of its launch): a batch brings its own parallelism (64 windows: 2 / 4 / 8 / 16 splits -> 47.8k /
+// 49.7k / 52.8k / 50.0k LM it/s).  (SLAMIT_BA_NSPLIT: A/B runs.)
+int bak_nsplit(int nwin) {
+    static const int nsplit_env = getenv("SLAMIT_BA_NSPLIT") ? atoi(getenv("SLAMIT_BA_NSPLIT")) : 0;
+    return nsplit_env >= 1 && nsplit_env <= BA_SPLITS ? nsplit_env : nwin >= 16 ? 8 : BA_SPLITS;
+}
+
 // one LM trial slot for every window of the batch
 // (`first`: the first slot of a stage, whose lambda comes out of the reductions; every later slot runs them and the
 // damping in one launch, the pose blocks ride with the Schur product, and the iteration bookkeeping is left to the reduced solve's kernel: 7 launches
@@ -1708,8 +1766,7 @@ void bak_stage_begin(hipStream_t st, BaWin* wins, int nwin, int max_edge, int st
 // `ev` (profiling solves only, slamit_ba_profile): six events recorded at the phase boundaries of the slot -- before the
 // linearisation, after it, after the Schur complement, after the reduced solve, after the update, after residuals + decision
 void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int max_edge, int Npad, bool first, unsigned solvers, hipEvent_t* ev) {
-    static const int nsplit_env = getenv("SLAMIT_BA_NSPLIT") ? atoi(getenv("SLAMIT_BA_NSPLIT")) : 0;   // A/B runs
-    const int nsplit = nsplit_env >= 1 && nsplit_env <= BA_SPLITS ? nsplit_env : nwin >= 16 ? 8 : BA_SPLITS;   // split-K of the Schur product: a batch brings its own parallelism (64 windows: 2 / 4 / 8 / 16 splits -> 47.8k / 49.7k / 52.8k / 50.0k LM it/s)
+    const int nsplit = bak_nsplit(nwin);
     const dim3 ge((max_edge + 255) / 256, nwin), gp((max_pt * BA_PG + 255) / 256, nwin);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (first) {
@@ -1723,9 +1780,17 @@ void bak_slot(hipStream_t st, BaWin* wins, int nwin, int max_kf, int max_pt, int
     }
     if (ev) (void)hipEventRecord(ev[1], st);
     const int T = Npad / BA_TILE, ntiles = T * (T + 1) / 2;
+    // The pose blocks ride in the Schur launch of a single window (one launch less on its latency chain); a batch launches them on their own:
+    // the fused kernel's register count is the pose reduction's (142 + 32: two waves per SIMD), the product alone runs three
+    // (batch of 64, Schur phase: 2.97 -> 2.73 ms per 16 slots).
+    if (!first && nwin >= 16) {
+        hipLaunchKernelGGL(k_pose_reduce, dim3(max_kf, nwin), dim3(256), 0, st, wins);
+        hipLaunchKernelGGL(k_schur, dim3(ntiles, nsplit, nwin), dim3(256), 0, st, wins);
+    } else
     if (first) hipLaunchKernelGGL(k_schur, dim3(ntiles, nsplit, nwin), dim3(256), 0, st, wins);
     else hipLaunchKernelGGL(k_schur_pose, dim3(ntiles + (max_kf + nsplit - 1) / nsplit, nsplit, nwin), dim3(256), 0, st, wins, ntiles);
-    hipLaunchKernelGGL(k_schur_reduce, dim3((Npad * Npad + 255) / 256, nwin), dim3(256), 0, st, wins, nsplit);
+    // (a batch without a window of the blocked solver only needs the banded mapping's workgroups: four rows each)
+    hipLaunchKernelGGL(k_schur_reduce, dim3((solvers & (1u << BA_SOLVER_BLOCKED)) ? (Npad * Npad + 255) / 256 : (Npad + 3) / 4, nwin), dim3(256), 0, st, wins, nsplit);
     if (ev) (void)hipEventRecord(ev[2], st);
     // `solvers`: bit BA_SOLVER_* set when a window of the batch takes that kernel
     if (solvers & (1u << BA_SOLVER_BAND)) hipLaunchKernelGGL(k_ldlt_band, dim3(1, nwin), dim3(LD_THREADS), bak_ldlt_smem(Npad), st, wins);

@@ -12,6 +12,8 @@
 #define BA_MAX_PANELS 20    // 32-column LDLt panels
 #define BA_JAC_MONO 21      // doubles per edge record: A (2x3) B (2x6) wO r0 r1
 #define BA_JAC_STEREO 31    // ... of a window with stereo observations: A (3x3) B (3x6) wO r0 r1 r2 (a monocular edge's third row is zero)
+#define BA_SF_MAXG 256      // groups of k slabs of the floating-window Schur product (BaWin::sf_*)
+#define BA_SF_ROWS 63       // matrix rows one window holds (row 64 of its B operand is the right-hand side's row)
 #define BA_SOLVER_BAND 0      // narrow row envelope: block LDLt inside LDS (k_ldlt_band)
 #define BA_SOLVER_BLOCKED 1   // any other structure: 32-column panels through L2 (k_ldlt_blocked)
 
@@ -70,6 +72,16 @@ struct BaWin {
     int16_t back_lo[BA_MAX_PANELS];    // first column any row of panel i's 32 rows reaches (back-substitution)
     int32_t band;      // half bandwidth of the reduced system's row envelope: max over rows r of r - first column of r (nS - 1: full)
     int32_t solver;    // which reduced solve takes the window (host, from nS and band): BA_SOLVER_*; one launch per kind present in a batch
+    // Schur product over FLOATING row windows (host, ba_api.hip; sf_groups == 0: 64 x 64 tile pairs over k ranges as above).  The points are sorted
+    // by their first observing keyframe, so the rows with non-zeros in one k slab of 32 (about eleven points) are a short run -- 48 rows
+    // when every point is seen by eight consecutive keyframes.  Consecutive slabs whose rows fit ONE run of BA_SF_ROWS rows form a group:
+    // one workgroup multiplies GA(rows, slabs) GB(rows + the right-hand side's row, slabs)^T into a 64 x 64 partial tile, and
+    // k_schur_reduce adds, for an entry (r, c), the tiles of the groups whose window holds both rows -- a contiguous run of groups,
+    // in group order.  Aligned 64 x 64 tile pairs multiply 3.8 x as many zeros on such a window.
+    int32_t sf_groups, pad1;
+    int16_t sf_row[BA_SF_MAXG];                       // first matrix row of group g's window
+    int16_t sf_k0[BA_SF_MAXG], sf_k1[BA_SF_MAXG];     // its slabs [k0, k1), in units of BA_KC
+    int16_t sf_glo[BA_MAX_TILES * BA_TILE], sf_ghi[BA_MAX_TILES * BA_TILE];   // per matrix row: the groups whose window holds it (glo > ghi: none)
     // vertices
     BA_G double* pose;      // n_kf x 7: q(x,y,z,w), t
     BA_G double* pose_bak;
