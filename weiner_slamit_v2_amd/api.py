@@ -632,8 +632,9 @@ class Optimizer:
 
     @staticmethod
     def _result(n_kf, n_pt, n_e):
-        out = {"kf_pose": np.zeros((n_kf, 12)), "pt_xyz": np.zeros((n_pt, 3)), "edge_chi2": np.zeros(n_e),
-               "edge_outlier": np.zeros(n_e, np.uint8), "edge_stage1_outlier": np.zeros(n_e, np.uint8)}
+        # (np.empty: the call writes every element of every output or fails; zero-filling 210 KB per window was 4 ms of a 17-ms batch of 64)
+        out = {"kf_pose": np.empty((n_kf, 12)), "pt_xyz": np.empty((n_pt, 3)), "edge_chi2": np.empty(n_e),
+               "edge_outlier": np.empty(n_e, np.uint8), "edge_stage1_outlier": np.empty(n_e, np.uint8)}
         st = BaStats()
         r = BaResult(out["kf_pose"].ctypes.data, out["pt_xyz"].ctypes.data, out["edge_chi2"].ctypes.data,
                      out["edge_outlier"].ctypes.data, out["edge_stage1_outlier"].ctypes.data, C.addressof(st))
@@ -642,9 +643,9 @@ class Optimizer:
     @staticmethod
     def _stats(st):
         n = list(st.n_its)
-        return {"n_its": n, "chi2": [list(st.chi2[s])[:n[s]] for s in range(2)],
-                "lambda": [list(st.lambda_[s])[:n[s]] for s in range(2)],
-                "trials": [list(st.trials[s])[:n[s]] for s in range(2)], "chi2_init": list(st.chi2_init)}
+        return {"n_its": n, "chi2": [st.chi2[s][:n[s]] for s in range(2)],
+                "lambda": [st.lambda_[s][:n[s]] for s in range(2)],
+                "trials": [st.trials[s][:n[s]] for s in range(2)], "chi2_init": list(st.chi2_init)}
 
     def LocalBundleAdjustment(self, problem, its_robust=5, its_final=10, huber_delta=HUBER_MONO, chi2_gate=5.991,
                               stop=None, huber_delta_stereo=HUBER_STEREO, chi2_gate_stereo=7.815):
