@@ -169,6 +169,52 @@ def test_schur_over_floating_windows_and_over_tile_pairs(monkeypatch):
     opt.close()
 
 
+def _shuffle_keyframes(prob, seed):
+    """The same window with its keyframes listed in a random order (the first stays first: the fixed one)."""
+    n = len(prob["kf_fixed"])
+    perm = np.concatenate([[0], 1 + np.random.RandomState(seed).permutation(n - 1)])   # new position i holds old keyframe perm[i]
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    q = dict(prob)
+    for k in ("kf_pose", "kf_fixed", "kf_intr") + (("kf_bf",) if prob.get("kf_bf") is not None else ()):
+        q[k] = np.ascontiguousarray(np.asarray(prob[k])[perm])
+    q["edge_kf"] = inv[np.asarray(prob["edge_kf"])].astype(np.int32)
+    return q, perm
+
+
+def test_keyframes_listed_out_of_trajectory_order(opt, monkeypatch):
+    """ORB-SLAM2 lists a local window by co-visibility weight, not along the trajectory (Optimizer.cc:456-470): the reduced system of such a
+    list has its couplings scattered.  ba_order_columns (csrc/ba_api.hip) renumbers the free keyframes by reverse Cuthill-McKee when that narrows the
+    band, so the shuffled window-8 window takes the banded solve and the floating-window Schur product like the ordered one (executed flops
+    within 1.5x of it, against 10x in the caller's order: SLAMIT_BA_KEEP_ORDER=1), and either order gives the oracle's result on the
+    shuffled problem and the ordered window's poses."""
+    base = synth.synth_ba(50, 1200, 8, seed=77, n_fixed=1)
+    shuf, perm = _shuffle_keyframes(base, 5)
+    opt.profile(True)
+    r_base = opt.LocalBundleAdjustment(base)
+    m_base = opt.profile_read()["schur_exec_mflop"]
+    r_shuf = opt.LocalBundleAdjustment(shuf)
+    m_shuf = opt.profile_read()["schur_exec_mflop"]
+    monkeypatch.setenv("SLAMIT_BA_KEEP_ORDER", "1")
+    r_keep = opt.LocalBundleAdjustment(shuf)
+    m_keep = opt.profile_read()["schur_exec_mflop"]
+    monkeypatch.delenv("SLAMIT_BA_KEEP_ORDER")
+    opt.profile(False)
+    assert m_shuf <= 1.5 * m_base and m_keep >= 5 * m_base, (m_base, m_shuf, m_keep)
+    ref = ob.ba_solve(shuf)
+    _close(r_shuf, ref, "shuffled")
+    _close(r_keep, ref, "shuffled, caller's order")
+    scale = max(np.abs(r_base["kf_pose"]).max(), 1.0)
+    assert np.abs(r_shuf["kf_pose"] - r_base["kf_pose"][perm]).max() / scale <= 1e-7
+    assert r_shuf["stats"]["n_its"] == r_base["stats"]["n_its"] and (r_shuf["edge_outlier"] == r_base["edge_outlier"]).all()
+    # a stereo window and a batch that mixes orders
+    s_base = synth.synth_ba(30, 700, 6, seed=78, stereo_frac=0.5)
+    s_shuf, _ = _shuffle_keyframes(s_base, 6)
+    outs = opt.LocalBundleAdjustmentBatch([shuf, base, s_shuf])
+    for q, o in zip([shuf, base, s_shuf], outs):
+        _close(o, ob.ba_solve(q), "shuffled batch", prob=q)
+
+
 def test_config4_dense_50kf_2000pt(opt):
     """BASELINE config 4, dense visibility: 50 KF x 2000 points, 100,000 edges."""
     prob = synth.synth_ba(50, 2000, None, seed=12345)

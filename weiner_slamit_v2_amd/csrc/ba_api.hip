@@ -190,6 +190,65 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
     }
 }
 
+// Column order of the free keyframes in the reduced system.  The banded solve and the floating-window Schur product want keyframes that share
+// points to be NEIGHBOURS in that order; a caller that lists its local window by co-visibility weight (Optimizer.cc:456-470 walks
+// GetVectorCovisibleKeyFrames) instead of along the trajectory gives the same graph in a scattered order.  If a reverse Cuthill-McKee
+// order of the co-visibility graph (free keyframes; an edge = a shared point) has a narrower band than the caller's, `col` is renumbered
+// to it; g2o orders the same system by approximate minimum degree (linear_solver_eigen.h:77-92) -- any order gives the same solution up
+// to rounding.  The caller's order is kept when it is already as narrow (SLAMIT_BA_KEEP_ORDER=1: always).
+static void ba_order_columns(const slamit_ba_problem& P, int32_t* col, int nfree) {
+    if (nfree < 3 || getenv("SLAMIT_BA_KEEP_ORDER")) return;
+    const int W64 = (nfree + 63) / 64;
+    std::vector<uint64_t> adj((size_t)nfree * W64, 0), seen((size_t)std::max(P.n_pt, 1) * W64, 0);
+    for (int e = 0; e < P.n_edge; ++e) {
+        const int c = col[P.edge_kf[e]];
+        if (c >= 0) seen[(size_t)P.edge_pt[e] * W64 + (c >> 6)] |= 1ull << (c & 63);
+    }
+    for (int p = 0; p < P.n_pt; ++p) {
+        const uint64_t* m = &seen[(size_t)p * W64];
+        for (int w = 0; w < W64; ++w)
+            for (uint64_t bits = m[w]; bits; bits &= bits - 1) {
+                const int c = 64 * w + __builtin_ctzll(bits);
+                for (int v = 0; v < W64; ++v) adj[(size_t)c * W64 + v] |= m[v];
+            }
+    }
+    auto has = [&](int a, int b2) { return (adj[(size_t)a * W64 + (b2 >> 6)] >> (b2 & 63)) & 1ull; };
+    auto band_of = [&](const std::vector<int>& pos) {   // max over columns of (position - leftmost coupled position), in keyframes
+        int band = 0;
+        for (int a = 0; a < nfree; ++a)
+            for (int b2 = 0; b2 < nfree; ++b2)
+                if (a != b2 && has(a, b2)) band = std::max(band, pos[a] - pos[b2]);
+        return band;
+    };
+    std::vector<int> ident(nfree), deg(nfree, 0);
+    for (int a = 0; a < nfree; ++a) {
+        ident[a] = a;
+        for (int w = 0; w < W64; ++w) deg[a] += __builtin_popcountll(adj[(size_t)a * W64 + w]);
+    }
+    const int band0 = band_of(ident);
+    if (band0 <= 1) return;
+    // Cuthill-McKee per component from a node of minimum degree, neighbours by increasing degree (ties: the caller's order), then reversed
+    std::vector<int> order; order.reserve(nfree);
+    std::vector<char> used(nfree, 0);
+    while ((int)order.size() < nfree) {
+        int start = -1;
+        for (int a = 0; a < nfree; ++a) if (!used[a] && (start < 0 || deg[a] < deg[start])) start = a;
+        size_t head = order.size();
+        order.push_back(start); used[start] = 1;
+        while (head < order.size()) {
+            const int a = order[head++];
+            const size_t first = order.size();
+            for (int b2 = 0; b2 < nfree; ++b2) if (!used[b2] && has(a, b2)) { order.push_back(b2); used[b2] = 1; }
+            std::stable_sort(order.begin() + first, order.end(), [&](int x, int y) { return deg[x] < deg[y]; });
+        }
+    }
+    std::reverse(order.begin(), order.end());
+    std::vector<int> pos(nfree);
+    for (int i = 0; i < nfree; ++i) pos[order[i]] = i;
+    if (band_of(pos) >= band0) return;
+    for (int k = 0; k < P.n_kf; ++k) if (col[k] >= 0) col[k] = pos[col[k]];
+}
+
 static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* probs, const slamit_ba_opts* opts,
                                slamit_ba_result* results) {
     if (!h || !probs || !opts || !results || nwin < 0) return slamit_fail(SLAMIT_ERR_ARG, "slamit_ba_solve_batch: bad argument");
@@ -262,6 +321,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         int32_t* col = H.pose_col;
         int nfree = 0;
         for (int k = 0; k < P.n_kf; ++k) col[k] = P.kf_fixed[k] ? -1 : nfree++;
+        ba_order_columns(P, col, nfree);   // (edge indices were checked above)
         w.n_free = nfree; w.nS = 6 * nfree;
         w.Npad = (int)rup((size_t)w.nS + 1, BA_TILE);
         w.Kpad = (int)rup((size_t)std::max(3 * P.n_pt, 1), (size_t)BA_KC * BA_SPLITS);
