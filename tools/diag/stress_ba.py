@@ -18,6 +18,13 @@ while time.time() < t_end:
     nk, npt = int(rs.randint(3, 51)), int(rs.randint(20, 1200))
     obs = None if rs.rand() < 0.2 else int(rs.randint(2, min(nk, 12) + 1))
     prob = synth.synth_ba(nk, npt, obs, outlier_frac=float(rs.choice([0.0, 0.03, 0.1])), seed=seed, n_fixed=int(rs.randint(1, min(nk, 4))))
+    if rs.rand() < 0.5:   # keyframes listed out of trajectory order (the free ones are renumbered on the host: ba_order_columns)
+        n = len(prob["kf_fixed"])
+        perm = rs.permutation(n)
+        inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+        for k in ("kf_pose", "kf_fixed", "kf_intr"):
+            prob[k] = np.ascontiguousarray(np.asarray(prob[k])[perm])
+        prob["edge_kf"] = inv[np.asarray(prob["edge_kf"])].astype(np.int32)
     g = opt.LocalBundleAdjustment(prob)
     o = ob.ba_solve(prob)
     same_its = list(g["stats"]["n_its"]) == list(o["stats"]["n_its"])
