@@ -117,7 +117,7 @@ size_t carve_work(uint8_t* base, BaWin& w, int max_kf, int max_pt, int max_edge,
     w.Hll = c.take<double>(6 * (size_t)max_pt); w.bl = c.take<double>(3 * (size_t)max_pt);
     w.Dinv = c.take<double>(6 * (size_t)max_pt);
     w.Hpp = c.take<double>(36 * (size_t)max_kf); w.bp = c.take<double>(6 * (size_t)max_kf + 8);
-    w.GA = c.take<double>((size_t)Npad * Kpad); w.GB = c.take<double>((size_t)Npad * Kpad);
+    w.GA = c.take<double>((size_t)Npad * Kpad);
     w.part = c.take<double>((size_t)BA_SPLITS * Npad * Npad);
     w.S = c.take<double>((size_t)Npad * Npad); w.Sb = c.take<double>(((size_t)Npad + 1) * 64); w.rhs = c.take<double>(Npad);
     w.x_l = c.take<double>(3 * (size_t)max_pt);
@@ -335,7 +335,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         w.st = reinterpret_cast<BaState*>(h->d_wins) - (b + 1);
         // ---- structure of the window (g2o's BlockSolver / SimplicialLDLT exploit the same sparsity on the CPU,
         // block_solver.hpp:381-432, linear_solver_eigen.h:94-124) ----
-        // Points are stored on the device sorted by the first free keyframe that observes them: the rows of GA / GB that
+        // Points are stored on the device sorted by the first free keyframe that observes them: the rows of the Schur operand GA that
         // belong to a 64-row tile then have their non-zeros in one k range, and the Schur product skips the rest.
         std::vector<int32_t> minc(P.n_pt, INT32_MAX), maxc(P.n_pt, -1);
         for (int e = 0; e < P.n_edge; ++e) {
@@ -369,7 +369,7 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
                 if (hi < 0) { lo = 0; hi = 0; }
                 lo = lo / BA_KC * BA_KC; hi = std::min((hi + BA_KC - 1) / BA_KC * BA_KC, kmax);
                 w.tile_alo[t] = lo; w.tile_ahi[t] = hi; w.tile_blo[t] = lo; w.tile_bhi[t] = hi;
-                if (w.nS >= BA_TILE * t && w.nS < BA_TILE * (t + 1)) { w.tile_blo[t] = 0; w.tile_bhi[t] = kmax; }   // row nS of GB = bl of every point
+                if (w.nS >= BA_TILE * t && w.nS < BA_TILE * (t + 1)) { w.tile_blo[t] = 0; w.tile_bhi[t] = kmax; }   // row nS = the right-hand side's row: every point
             }
             // LDLt: row envelope.  first[r] = 6 * fcol[r / 6]; panel i (columns 32 i ..) only touches rows r with first[r] < 32 i + 32
             const int n = w.nS;

@@ -7,9 +7,9 @@
 //   k_point_reduce     constructQuadraticForm, landmark side            G/core/base_binary_edge.hpp:55-120
 //   k_pose_reduce      constructQuadraticForm, pose side
 //   k_iter_begin       computeLambdaInit                                G/core/optimization_algorithm_levenberg.cpp:93-97,166-180
-//   k_prepare          setLambda + Dinv + Hpl, B*Dinv                    G/core/block_solver.hpp:564-589,381-400
+//   k_prepare          setLambda + Dinv + the Schur operand Hpl Ci^T      G/core/block_solver.hpp:564-589,381-400
 //   k_schur / _reduce  Schur complement  S = Hpp - sum_p B Dinv B^T      G/core/block_solver.hpp:401-439
-//                      as ONE dense split-K product GA * GB^T on v_mfma_f64_16x16x4_f64
+//                      as the product G G^T of ONE operand (G = Hpl Ci^T, point_chol) on v_mfma_f64_16x16x4_f64
 //   k_point_pass       k_linearize + k_point_reduce + k_prepare in one launch: every LM trial after a stage's first
 //   k_schur_pose       k_schur with k_pose_reduce's workgroups behind its tiles: the same trials
 //   k_ldlt_band / k_ldlt_blocked   LinearSolverEigen::solve              G/solvers/linear_solver_eigen.h:94-124
@@ -374,6 +374,28 @@ __device__ __forceinline__ void hpl_of(const double* J, double* H /*6x3*/) {
         for (int j = 0; j < 3; ++j) H[3 * i + j] = (J[6 + i] * J[j] + J[12 + i] * J[3 + j]) * wO;
 }
 
+// The Schur operand of one point.  With M = Hll + lambda I = C C^T (Cholesky, C lower) and Ci = C^-1:
+//     Hpl M^-1 Hpl^T = (Hpl Ci^T)(Hpl Ci^T)^T     and     Hpl M^-1 bl = (Hpl Ci^T)(Ci bl),
+// so ONE operand G = Hpl Ci^T per edge block (and Ci bl in the right-hand side's row) gives the whole product as G G^T: half the
+// operand stores of the point pass and half the slab loads of the product that the pair (Hpl M^-1, Hpl) took.  (M is positive
+// definite for lambda > 0; g2o forms Hpl (Hll^-1 Hpl^T) with the explicit inverse, block_solver.hpp:381-432.)
+struct PointChol { double i00, i10, i11, i20, i21, i22; };
+__device__ __forceinline__ PointChol point_chol(double a, double b, double c, double d, double e, double f) {   // M = [a b c; b d e; c e f]
+    PointChol q;
+    const double c00 = sqrt(a);
+    q.i00 = 1.0 / c00;
+    const double c10 = b * q.i00, c20 = c * q.i00;
+    const double c11 = sqrt(d - c10 * c10);
+    q.i11 = 1.0 / c11;
+    const double c21 = (e - c20 * c10) * q.i11;
+    const double c22 = sqrt(f - c20 * c20 - c21 * c21);
+    q.i22 = 1.0 / c22;
+    q.i10 = -c10 * q.i00 * q.i11;
+    q.i21 = -c21 * q.i11 * q.i22;
+    q.i20 = -(c20 * q.i00 + c21 * q.i10) * q.i22;
+    return q;
+}
+
 __global__ __launch_bounds__(256) void k_prepare(BaWin* wins) {   // BA_PG lanes per point, like k_point_reduce
     const BaWin& W = wins[blockIdx.y];
     BaState* st = BA_ST(wins, blockIdx.y);
@@ -392,10 +414,12 @@ __global__ __launch_bounds__(256) void k_prepare(BaWin* wins) {   // BA_PG lanes
     Di[0] = c0 * id; Di[1] = c1 * id; Di[2] = c2 * id;
     Di[3] = (a * f - c * c) * id; Di[4] = (b * c - a * e_) * id; Di[5] = (a * d - b * b) * id;
     const size_t K = (size_t)W.Kpad;
+    const PointChol L = point_chol(a, b, c, d, e_, f);
     if (g == 0) {
         for (int i = 0; i < 6; ++i) W.Dinv[6 * (size_t)p + i] = Di[i];
         const double* bl = W.bl + 3 * (size_t)p;
-        for (int j = 0; j < 3; ++j) W.GB[(size_t)W.nS * K + 3 * (size_t)p + j] = bl[j];
+        gdouble* q = (gdouble*)W.GA + (size_t)W.nS * K + 3 * (size_t)p;
+        q[0] = L.i00 * bl[0]; q[1] = L.i10 * bl[0] + L.i11 * bl[1]; q[2] = L.i20 * bl[0] + L.i21 * bl[1] + L.i22 * bl[2];
     }
     for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
         const int e = W.pt_edges[i];
@@ -408,10 +432,9 @@ __global__ __launch_bounds__(256) void k_prepare(BaWin* wins) {   // BA_PG lanes
         for (int r = 0; r < 6; ++r) {
             const double h0 = H[3 * r], h1 = H[3 * r + 1], h2 = H[3 * r + 2];
             const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)p;
-            W.GB[o] = h0; W.GB[o + 1] = h1; W.GB[o + 2] = h2;
-            W.GA[o] = h0 * Di[0] + h1 * Di[1] + h2 * Di[2];
-            W.GA[o + 1] = h0 * Di[1] + h1 * Di[3] + h2 * Di[4];
-            W.GA[o + 2] = h0 * Di[2] + h1 * Di[4] + h2 * Di[5];
+            W.GA[o] = h0 * L.i00;
+            W.GA[o + 1] = h0 * L.i10 + h1 * L.i11;
+            W.GA[o + 2] = h0 * L.i20 + h1 * L.i21 + h2 * L.i22;
         }
     }
 }
@@ -477,9 +500,11 @@ __global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
     Di[0] = c0 * id; Di[1] = c1 * id; Di[2] = c2 * id;
     Di[3] = (a * f - c * c) * id; Di[4] = (bq * c - a * e_) * id; Di[5] = (a * d - bq * bq) * id;
     const size_t K = (size_t)W.Kpad;
+    const PointChol L = point_chol(a, bq, c, d, e_, f);
     if (g == 0) {
         for (int i = 0; i < 6; ++i) W.Dinv[6 * (size_t)p + i] = Di[i];
-        for (int j = 0; j < 3; ++j) W.GB[(size_t)W.nS * K + 3 * (size_t)p + j] = b[j];
+        gdouble* q = (gdouble*)W.GA + (size_t)W.nS * K + 3 * (size_t)p;
+        q[0] = L.i00 * b[0]; q[1] = L.i10 * b[0] + L.i11 * b[1]; q[2] = L.i20 * b[0] + L.i21 * b[1] + L.i22 * b[2];
     }
     for (int i = W.pt_ptr[p] + g; i < W.pt_ptr[p + 1]; i += BA_PG) {
         const int e = W.pt_edges[i];
@@ -492,15 +517,14 @@ __global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
         for (int r = 0; r < 6; ++r) {
             const double h0 = H[3 * r], h1 = H[3 * r + 1], h2 = H[3 * r + 2];
             const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)p;
-            W.GB[o] = h0; W.GB[o + 1] = h1; W.GB[o + 2] = h2;
-            W.GA[o] = h0 * Di[0] + h1 * Di[1] + h2 * Di[2];
-            W.GA[o + 1] = h0 * Di[1] + h1 * Di[3] + h2 * Di[4];
-            W.GA[o + 2] = h0 * Di[2] + h1 * Di[4] + h2 * Di[5];
+            W.GA[o] = h0 * L.i00;
+            W.GA[o + 1] = h0 * L.i10 + h1 * L.i11;
+            W.GA[o + 2] = h0 * L.i20 + h1 * L.i21 + h2 * L.i22;
         }
     }
 }
 
-// ---- S6: split-K dense product  part[s] = GA[:, ks] * GB[:, ks]^T  on fp64 MFMA ------------------
+// ---- S6: split-K dense product  part[s] = GA[:, ks] * GA[:, ks]^T  on fp64 MFMA (GA = Hpl Ci^T: point_chol) ------------------
 // Workgroup = 4 wavefronts, one 64x64 macro tile (I <= J) of one k split.  Wave w owns rows
 // 16w..16w+15 and all four 16-wide column tiles (4 x double4 accumulators).  Slabs of 64 rows x
 // 32 k of both operands are staged in LDS (pitch 34 doubles: conflict-free ds_read_b64 for the
@@ -509,7 +533,7 @@ __global__ __launch_bounds__(256) void k_point_pass(BaWin* wins) {
 
 // does the reduced system need tile pair (I, J), I <= J, of the product?  Not when the two row tiles share no k range (the block
 // is zero: k_schur_reduce writes the zeros itself), and not when the banded solver takes the window and the whole tile lies
-// outside the band (nobody reads it) -- except for the tile column that holds the right-hand side (row nS of GB)
+// outside the band (nobody reads it) -- except for the tile column that holds the right-hand side (row nS of the operand)
 __device__ __forceinline__ bool schur_tile_needed(const BaWin& W, int I, int J) {
     if (max(W.tile_alo[I], W.tile_blo[J]) >= min(W.tile_ahi[I], W.tile_bhi[J])) return false;
     if (W.solver == BA_SOLVER_BAND && BA_TILE * J - (BA_TILE * I + BA_TILE - 1) > W.band && W.nS / BA_TILE != J) return false;
@@ -519,8 +543,8 @@ __device__ __forceinline__ bool schur_tile_needed(const BaWin& W, int I, int J) 
 __device__ __forceinline__ void schur_body(const BaWin& W, const BaState* st, int tile, int s, int nsplit) {
     if (st->done) return;
     const int T = W.Npad / BA_TILE;
-    // What the workgroup multiplies: rows rbaseA + r of GA against rows rbaseB + r of GB (r = 0 .. 63; rows past the matrix are read as its
-    // last row -- zeros in GA, and a column of the result nobody reads in GB --, row 63 of the B operand is row lastB) over the k range
+    // What the workgroup multiplies: rows rbaseA + r of GA against its rows rbaseB + r (r = 0 .. 63; rows past the matrix are read as its
+    // last row: a row / column of the result nobody reads --, row 63 of the B operand is row lastB) over the k range
     // [k0, kend), into the 64 x 64 tile at `out` (row pitch opitch).
     int rbaseA, rbaseB, lastB, k0, kend, opitch;
     gdouble* out;
@@ -565,13 +589,16 @@ __device__ __forceinline__ void schur_body(const BaWin& W, const BaState* st, in
         for (int u = 0; u < 4; ++u) {
             const int r = (tid >> 4) + 16 * u;
             srcA[u] = (const gdouble2s*)((const gdouble*)W.GA + (size_t)min(rbaseA + r, lastrow) * K + c);
-            srcB[u] = (const gdouble2s*)((const gdouble*)W.GB + (size_t)(r == BA_TILE - 1 ? lastB : min(rbaseB + r, lastrow)) * K + c);
+            srcB[u] = (const gdouble2s*)((const gdouble*)W.GA + (size_t)(r == BA_TILE - 1 ? lastB : min(rbaseB + r, lastrow)) * K + c);
         }
     }
+    // (a floating window's B rows are its A rows, but for the last: only the lanes of row 63 fetch a B operand of their own)
+    const bool own_b3 = !W.sf_groups || (tid >> 4) == 15;
+    const bool own_b = !W.sf_groups;
     double2_t pa[4], pb[4];
     if (kend > k0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { pa[u] = srcA[u][k0 >> 1]; pb[u] = srcB[u][k0 >> 1]; }
+        for (int u = 0; u < 4; ++u) { pa[u] = srcA[u][k0 >> 1]; pb[u] = pa[u]; if (u == 3 ? own_b3 : own_b) pb[u] = srcB[u][k0 >> 1]; }
     }
     for (int kk = k0; kk < kend; kk += BA_KC) {
         __syncthreads();
@@ -584,7 +611,7 @@ __device__ __forceinline__ void schur_body(const BaWin& W, const BaState* st, in
         __syncthreads();
         if (kk + BA_KC < kend) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { pa[u] = srcA[u][(kk + BA_KC) >> 1]; pb[u] = srcB[u][(kk + BA_KC) >> 1]; }
+            for (int u = 0; u < 4; ++u) { pa[u] = srcA[u][(kk + BA_KC) >> 1]; pb[u] = pa[u]; if (u == 3 ? own_b3 : own_b) pb[u] = srcB[u][(kk + BA_KC) >> 1]; }
         }
 #pragma unroll
         for (int ks = 0; ks < BA_KC; ks += 4) {
@@ -1615,29 +1642,29 @@ __global__ __launch_bounds__(256) void k_gate(BaWin* wins) {
             for (int r = 0; r < 6; ++r) {
                 const size_t o = (size_t)(6 * col + r) * K + 3 * (size_t)W.e_pt[e];
                 W.GA[o] = 0.0; W.GA[o + 1] = 0.0; W.GA[o + 2] = 0.0;
-                W.GB[o] = 0.0; W.GB[o + 1] = 0.0; W.GB[o + 2] = 0.0;
             }
         }
     }
 }
 
-// Zeroes the k ranges of GA / GB the window's structure can touch (a solve starts from whatever the slab held before);
-// grid (x, row tile, window), one double2 per thread and step.
+// Zeroes the k ranges of the Schur operand the window's structure can touch (a solve starts from whatever the slab held before):
+// per row tile the union of its range as the product's A operand and as its B operand (the tile with the right-hand side's row:
+// every point).  Grid (x, row tile, window), one double2 per thread and step.
 __global__ __launch_bounds__(256) void k_zero_operands(BaWin* wins) {
     const BaWin& W = wins[blockIdx.z];
     const int t = blockIdx.y;
     if (t >= W.Npad / BA_TILE) return;
     const size_t K = (size_t)W.Kpad;
-    for (int m = 0; m < 2; ++m) {
-        const int lo = m ? W.tile_blo[t] : W.tile_alo[t], hi = m ? W.tile_bhi[t] : W.tile_ahi[t];
-        gdouble* M = (gdouble*)(m ? W.GB : W.GA) + (size_t)(BA_TILE * t) * K;
-        const int wdt = (hi - lo) >> 1;   // double2 per row (ranges are multiples of BA_KC)
-        if (wdt <= 0) continue;
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)BA_TILE * wdt; i += (long)gridDim.x * 256) {
-            const int r = (int)(i / wdt), c = (int)(i - (long)r * wdt);
-            gdouble* q = M + (size_t)r * K + lo + 2 * c;
-            q[0] = 0.0; q[1] = 0.0;
-        }
+    const bool ha = W.tile_ahi[t] > W.tile_alo[t], hb = W.tile_bhi[t] > W.tile_blo[t];
+    if (!ha && !hb) return;
+    const int lo = ha && hb ? min(W.tile_alo[t], W.tile_blo[t]) : ha ? W.tile_alo[t] : W.tile_blo[t];
+    const int hi = ha && hb ? max(W.tile_ahi[t], W.tile_bhi[t]) : ha ? W.tile_ahi[t] : W.tile_bhi[t];
+    gdouble* M = (gdouble*)W.GA + (size_t)(BA_TILE * t) * K;
+    const int wdt = (hi - lo) >> 1;   // double2 per row (ranges are multiples of BA_KC)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)BA_TILE * wdt; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / wdt), c = (int)(i - (long)r * wdt);
+        gdouble* q = M + (size_t)r * K + lo + 2 * c;
+        q[0] = 0.0; q[1] = 0.0;
     }
 }
 

@@ -64,10 +64,10 @@ struct BaWin {
     int32_t nrow;      // residual rows per edge record: 2 (every edge monocular) or 3 (the window has stereo observations)
     int32_t pad0;
     // Structure of the window (host, ba_api.hip), conservative for both stages.  Points are stored sorted by the first
-    // free keyframe that observes them, so the non-zeros of a 64-row tile of GA / GB sit in ONE k range, and the reduced
+    // free keyframe that observes them, so the non-zeros of a 64-row tile of the Schur operand GA sit in ONE k range, and the reduced
     // system has a row envelope (first coupled column per pose) that LDLt without pivoting never leaves.
     int32_t tile_alo[BA_MAX_TILES], tile_ahi[BA_MAX_TILES];   // k range (multiples of BA_KC) of GA's rows 64 t .. 64 t + 63
-    int32_t tile_blo[BA_MAX_TILES], tile_bhi[BA_MAX_TILES];   // ... of GB's (the tile that holds row nS = bl spans every point)
+    int32_t tile_blo[BA_MAX_TILES], tile_bhi[BA_MAX_TILES];   // ... as the product's B operand (the tile that holds row nS, the right-hand side's row, spans every point)
     int16_t panel_hi[BA_MAX_PANELS];   // last matrix row with an entry in the 32 columns of LDLt panel i (>= the panel's last row)
     int16_t back_lo[BA_MAX_PANELS];    // first column any row of panel i's 32 rows reaches (back-substitution)
     int32_t band;      // half bandwidth of the reduced system's row envelope: max over rows r of r - first column of r (nS - 1: full)
@@ -75,7 +75,7 @@ struct BaWin {
     // Schur product over FLOATING row windows (host, ba_api.hip; sf_groups == 0: 64 x 64 tile pairs over k ranges as above).  The points are sorted
     // by their first observing keyframe, so the rows with non-zeros in one k slab of 32 (about eleven points) are a short run -- 48 rows
     // when every point is seen by eight consecutive keyframes.  Consecutive slabs whose rows fit ONE run of BA_SF_ROWS rows form a group:
-    // one workgroup multiplies GA(rows, slabs) GB(rows + the right-hand side's row, slabs)^T into a 64 x 64 partial tile, and
+    // one workgroup multiplies GA(rows, slabs) GA(rows + the right-hand side's row, slabs)^T into a 64 x 64 partial tile, and
     // k_schur_reduce adds, for an entry (r, c), the tiles of the groups whose window holds both rows -- a contiguous run of groups,
     // in group order.  Aligned 64 x 64 tile pairs multiply 3.8 x as many zeros on such a window.
     int32_t sf_groups, pad1;
@@ -107,8 +107,8 @@ struct BaWin {
     BA_G double* Dinv;      // n_pt x 6
     BA_G double* Hpp;       // n_free x 36
     BA_G double* bp;        // n_free x 6
-    BA_G double* GA;        // Npad x Kpad : (Hpl * Dinv) scattered, row = pose dof, col = 3*pt + j
-    BA_G double* GB;        // Npad x Kpad : Hpl scattered; row nS holds bl
+    BA_G double* GA;        // Npad x Kpad : the Schur operand G = Hpl Ci^T scattered (row = pose dof, col = 3*pt + j; Ci = inverse Cholesky factor of Hll + lambda I,
+                            // ba_kernels.hip point_chol): S = Hpp - G G^T; row nS holds Ci bl, so that G (row nS)^T is the right-hand side's coefficient
     BA_G double* part;      // BA_SPLITS x Npad x Npad partial products
     BA_G double* S;         // Npad x Npad reduced system (symmetric, full)
     BA_G double* Sb;        // (Npad + 1) x 64: the same system as the banded solve's LDS image (rows of ldlt_band_rs(band) doubles; k_schur_reduce
