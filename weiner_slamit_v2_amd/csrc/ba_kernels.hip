@@ -592,37 +592,44 @@ __device__ __forceinline__ void schur_body(const BaWin& W, const BaState* st, in
             srcB[u] = (const gdouble2s*)((const gdouble*)W.GA + (size_t)(r == BA_TILE - 1 ? lastB : min(rbaseB + r, lastrow)) * K + c);
         }
     }
-    // (a floating window's B rows are its A rows, but for the last: only the lanes of row 63 fetch a B operand of their own)
-    const bool own_b3 = !W.sf_groups || (tid >> 4) == 15;
-    const bool own_b = !W.sf_groups;
+    // A floating window's B rows are its A rows but for the last: its lanes copy three of their four B operands from the A loads and
+    // fetch the fourth (row 63's lanes: the right-hand side's row; the others their A row once more, a cache hit) -- every load of
+    // either form is unconditional, a load behind a branch would be waited for on its own.
     double2_t pa[4], pb[4];
-    if (kend > k0) {
+    auto product = [&](auto sf_c) {
+        constexpr bool SF = decltype(sf_c)::value;
+        auto fetch = [&](int k) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { pa[u] = srcA[u][k0 >> 1]; pb[u] = pa[u]; if (u == 3 ? own_b3 : own_b) pb[u] = srcB[u][k0 >> 1]; }
-    }
-    for (int kk = k0; kk < kend; kk += BA_KC) {
-        __syncthreads();
+            for (int u = 0; u < 4; ++u) pa[u] = srcA[u][k >> 1];
+            if (SF) { pb[0] = pa[0]; pb[1] = pa[1]; pb[2] = pa[2]; pb[3] = srcB[3][k >> 1]; }
+            else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + 256 * u, r = i >> 4, c = (i & 15) * 2;
-            *reinterpret_cast<double2_t*>(&As[r * LDS_PITCH + c]) = pa[u];
-            *reinterpret_cast<double2_t*>(&Bs[r * LDS_PITCH + c]) = pb[u];
-        }
-        __syncthreads();
-        if (kk + BA_KC < kend) {
+                for (int u = 0; u < 4; ++u) pb[u] = srcB[u][k >> 1];
+            }
+        };
+        if (kend > k0) fetch(k0);
+        for (int kk = k0; kk < kend; kk += BA_KC) {
+            __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { pa[u] = srcA[u][(kk + BA_KC) >> 1]; pb[u] = pa[u]; if (u == 3 ? own_b3 : own_b) pb[u] = srcB[u][(kk + BA_KC) >> 1]; }
-        }
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + 256 * u, r = i >> 4, c = (i & 15) * 2;
+                *reinterpret_cast<double2_t*>(&As[r * LDS_PITCH + c]) = pa[u];
+                *reinterpret_cast<double2_t*>(&Bs[r * LDS_PITCH + c]) = pb[u];
+            }
+            __syncthreads();
+            if (kk + BA_KC < kend) fetch(kk + BA_KC);
 #pragma unroll
-        for (int ks = 0; ks < BA_KC; ks += 4) {
-            const double a = As[(16 * wv + (lane & 15)) * LDS_PITCH + ks + (lane >> 4)];
+            for (int ks = 0; ks < BA_KC; ks += 4) {
+                const double a = As[(16 * wv + (lane & 15)) * LDS_PITCH + ks + (lane >> 4)];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double b = Bs[(16 * j + (lane & 15)) * LDS_PITCH + ks + (lane >> 4)];
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const double b = Bs[(16 * j + (lane & 15)) * LDS_PITCH + ks + (lane >> 4)];
+                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+                }
             }
         }
-    }
+    };
+    if (W.sf_groups) product(std::true_type{}); else product(std::false_type{});
     // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int j = 0; j < 4; ++j)
