@@ -195,9 +195,12 @@ int slamit_ba_solve_batch(slamit_ba* h, int nwin, const slamit_ba_problem* probs
 // GetVectorCovisibleKeyFrames) instead of along the trajectory gives the same graph in a scattered order.  If a reverse Cuthill-McKee
 // order of the co-visibility graph (free keyframes; an edge = a shared point) has a narrower band than the caller's, `col` is renumbered
 // to it; g2o orders the same system by approximate minimum degree (linear_solver_eigen.h:77-92) -- any order gives the same solution up
-// to rounding.  The caller's order is kept when it is already as narrow (SLAMIT_BA_KEEP_ORDER=1: always).
-static void ba_order_columns(const slamit_ba_problem& P, int32_t* col, int nfree) {
-    if (nfree < 3 || getenv("SLAMIT_BA_KEEP_ORDER")) return;
+// to rounding.  The caller's order is kept when the banded solve takes it as it is, or when no order is narrower (SLAMIT_BA_KEEP_ORDER=1: always).
+// `span` = the widest point of the caller's order (last - first column it is seen from), `complete` = some point is seen from every
+// free keyframe (the graph is complete: no order is narrower): both come out of the pass over the edges the caller makes anyway, and
+// decide without one of their own -- an order whose band the banded solve already takes (<= 9 keyframes) is kept as it is.
+static bool ba_order_columns(const slamit_ba_problem& P, int32_t* col, int nfree, int span, bool complete) {
+    if (nfree < 3 || complete || 6 * span + 5 <= 59 || getenv("SLAMIT_BA_KEEP_ORDER")) return false;
     const int W64 = (nfree + 63) / 64;
     std::vector<uint64_t> adj((size_t)nfree * W64, 0), seen((size_t)std::max(P.n_pt, 1) * W64, 0);
     for (int e = 0; e < P.n_edge; ++e) {
@@ -226,7 +229,7 @@ static void ba_order_columns(const slamit_ba_problem& P, int32_t* col, int nfree
         for (int w = 0; w < W64; ++w) deg[a] += __builtin_popcountll(adj[(size_t)a * W64 + w]);
     }
     const int band0 = band_of(ident);
-    if (band0 <= 1) return;
+    if (band0 <= 1) return false;
     // Cuthill-McKee per component from a node of minimum degree, neighbours by increasing degree (ties: the caller's order), then reversed
     std::vector<int> order; order.reserve(nfree);
     std::vector<char> used(nfree, 0);
@@ -245,8 +248,9 @@ static void ba_order_columns(const slamit_ba_problem& P, int32_t* col, int nfree
     std::reverse(order.begin(), order.end());
     std::vector<int> pos(nfree);
     for (int i = 0; i < nfree; ++i) pos[order[i]] = i;
-    if (band_of(pos) >= band0) return;
+    if (band_of(pos) >= band0) return false;
     for (int k = 0; k < P.n_kf; ++k) if (col[k] >= 0) col[k] = pos[col[k]];
+    return true;
 }
 
 static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* probs, const slamit_ba_opts* opts,
@@ -321,7 +325,6 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         int32_t* col = H.pose_col;
         int nfree = 0;
         for (int k = 0; k < P.n_kf; ++k) col[k] = P.kf_fixed[k] ? -1 : nfree++;
-        ba_order_columns(P, col, nfree);   // (edge indices were checked above)
         w.n_free = nfree; w.nS = 6 * nfree;
         w.Npad = (int)rup((size_t)w.nS + 1, BA_TILE);
         w.Kpad = (int)rup((size_t)std::max(3 * P.n_pt, 1), (size_t)BA_KC * BA_SPLITS);
@@ -338,9 +341,25 @@ static int ba_solve_batch_impl(slamit_ba* h, int nwin, const slamit_ba_problem* 
         // Points are stored on the device sorted by the first free keyframe that observes them: the rows of the Schur operand GA that
         // belong to a 64-row tile then have their non-zeros in one k range, and the Schur product skips the rest.
         std::vector<int32_t> minc(P.n_pt, INT32_MAX), maxc(P.n_pt, -1);
-        for (int e = 0; e < P.n_edge; ++e) {
-            const int c = col[P.edge_kf[e]], p2 = P.edge_pt[e];
-            if (c >= 0) { minc[p2] = std::min(minc[p2], c); maxc[p2] = std::max(maxc[p2], c); }
+        {
+            std::vector<int32_t> seen_by(P.n_pt, 0);
+            for (int e = 0; e < P.n_edge; ++e) {
+                const int c = col[P.edge_kf[e]], p2 = P.edge_pt[e];
+                if (c >= 0) { minc[p2] = std::min(minc[p2], c); maxc[p2] = std::max(maxc[p2], c); ++seen_by[p2]; }
+            }
+            int span = 0;
+            bool complete = false;
+            for (int p2 = 0; p2 < P.n_pt; ++p2) {
+                if (maxc[p2] >= 0) span = std::max(span, maxc[p2] - minc[p2]);
+                complete = complete || (maxc[p2] - minc[p2] + 1 == nfree && seen_by[p2] >= nfree);
+            }
+            if (ba_order_columns(P, col, nfree, span, complete)) {   // renumbered: the points' column ranges once more
+                std::fill(minc.begin(), minc.end(), INT32_MAX); std::fill(maxc.begin(), maxc.end(), -1);
+                for (int e = 0; e < P.n_edge; ++e) {
+                    const int c = col[P.edge_kf[e]], p2 = P.edge_pt[e];
+                    if (c >= 0) { minc[p2] = std::min(minc[p2], c); maxc[p2] = std::max(maxc[p2], c); }
+                }
+            }
         }
         std::vector<int32_t>& new2old = perm[b];
         new2old.resize(P.n_pt);
