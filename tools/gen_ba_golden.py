@@ -33,6 +33,9 @@ CASES = {
     "stereo_mixed": (20, 600, 6, 52, 2, 1.0, 0.5),      # half of the observations without a right-image match
     "stereo_rough": (8, 150, 4, 56, 1, 80.0, 0.6),      # very large initial error: a rejected LM trial, most edges gated out
     "stereo_window8": (50, 2000, 8, 54, 1, 1.0, 0.8),   # BASELINE config 4 geometry with 80 % stereo observations
+    # a window-8 window whose keyframes are listed in a random order (ORB-SLAM2 lists them by co-visibility weight, Optimizer.cc:456-470):
+    # the free keyframes are renumbered on the host (csrc/ba_api.hip ba_order_columns) -- an 8th field = the seed of the permutation
+    "shuffled": (50, 1000, 8, 61, 2, 1.0, 0.0, 9),
 }
 # name -> (its_robust, its_final, huber_delta); everything else uses the local-BA schedule of Optimizer.cc:507-743
 SCHEDULE = {"global_init": (20, 0, float(np.float32(np.sqrt(5.99)))), "global_map": (10, 0, float(np.float32(np.sqrt(5.99))))}
@@ -51,6 +54,13 @@ def make(name):
             prob["kf_pose"][i, :9] = (dR @ R).reshape(-1)
             prob["kf_pose"][i, 9:] = dR @ t + dt
         prob["kf_pose"] = prob["kf_pose"].astype(np.float32).astype(np.float64)
+    if len(CASES[name]) > 7:   # the same window, its keyframes in a random order
+        perm = np.random.RandomState(CASES[name][7]).permutation(k)   # new position i holds old keyframe perm[i]
+        inv = np.empty(k, np.int64)
+        inv[perm] = np.arange(k)
+        for key in ("kf_pose", "kf_fixed", "kf_intr"):
+            prob[key] = np.ascontiguousarray(np.asarray(prob[key])[perm])
+        prob["edge_kf"] = inv[np.asarray(prob["edge_kf"])].astype(np.int32)
     return prob
 
 
