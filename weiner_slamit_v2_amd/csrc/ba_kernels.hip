@@ -1309,16 +1309,21 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_blocked(BaWin* wins) {
         const int rows = below + 1;          // + the rhs row, which is matrix row n
 #define GROW(r) ((r) < below ? base + (r) : n)
         const int rows16 = (rows + 15) & ~15;
-        for (int i = tid; i < nb * LD_NB; i += LD_THREADS) {
+        // The staging and write-back loops of a panel index with `tp`, the thread id behind an empty asm: their dozens of LDS / matrix
+        // addresses are then formed per panel (an add and a shift each) instead of being hoisted out of the panel loop, where they
+        // had to live in registers across the whole kernel -- and were spilled to scratch and reloaded per panel (27 VGPRs).
+        int tp = tid;
+        asm volatile("" : "+v"(tp));
+        for (int i = tp; i < nb * LD_NB; i += LD_THREADS) {
             const int r = i >> 5, c = i & 31;
             if (c < nb) Dg[r * LD_P + c] = S[(size_t)(jb + r) * N + jb + c];
         }
         if (nb < LD_NB)
-            for (int i = tid; i < LD_NB * LD_NB; i += LD_THREADS) {
+            for (int i = tp; i < LD_NB * LD_NB; i += LD_THREADS) {
                 const int r = i >> 5, c = i & 31;
                 if (r >= nb || c >= nb) Dg[r * LD_P + c] = 0.0;
             }
-        for (int i0 = tid; i0 < rows16 * LD_NB; i0 += 8 * LD_THREADS) {
+        for (int i0 = tp; i0 < rows16 * LD_NB; i0 += 8 * LD_THREADS) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {   // issue all loads first: the L2 round trip is paid once per batch
@@ -1341,11 +1346,11 @@ __global__ __launch_bounds__(LD_THREADS) void k_ldlt_blocked(BaWin* wins) {
         __syncthreads();
         STAMP(2);
         // write back the factored panel: L11 / D, and L21 = (L*d) / d
-        for (int i = tid; i < nb * LD_NB; i += LD_THREADS) {
+        for (int i = tp; i < nb * LD_NB; i += LD_THREADS) {
             const int r = i >> 5, c = i & 31;
             if (c <= r) S[(size_t)(jb + r) * N + jb + c] = Dg[r * LD_P + c];
         }
-        for (int i = tid; i < rows * LD_NB; i += LD_THREADS) {
+        for (int i = tp; i < rows * LD_NB; i += LD_THREADS) {
             const int r = i >> 5, c = i & 31;
             if (c < nb) S[(size_t)GROW(r) * N + jb + c] = Wd[r * LD_P + c] * s_invd[c];
         }
